@@ -1,0 +1,287 @@
+/*
+ * tpsrhs.h -- C ABI of the MI355X-native replacement for the explicit DG right-hand side of the
+ * TPS compressible solver (M2ulPhyS): RHSoperator::Mult.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the pecos/tps
+ * source tree).  Only plain C types cross this boundary: pointers, sizes, PODs.  No torch, no
+ * MFEM, no C++ types.
+ *
+ * Conventions shared with the reference (part of the contract):
+ *   - state vectors are "byNODES": U[n + eq * NDofs]            (src/M2ulPhyS.cpp:575-579)
+ *   - gradients:  gradUp[n + eq*NDofs + d*num_equation*NDofs]   (src/rhs_operator.cpp:521)
+ *   - DG L2 space: dof n = element * dofs_per_element + local,  local = i + j*(p+1) + k*(p+1)^2
+ *     (lexicographic in the element's reference frame; MFEM L2_{Quadrilateral,Hexahedron}Element)
+ *   - conserved state  [rho, rho u (nvel), rho E, rho Y_sp (active) ..., (rho e_e)]
+ *     primitive state  [rho, u (nvel), T_h, n_sp (active) ..., (T_e)]   (src/equation_of_state.cpp:679-700)
+ *   - element vertex order is MFEM's (quad: counter-clockwise; hex: bottom ccw then top ccw).
+ */
+#ifndef TPSRHS_H_
+#define TPSRHS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- capacity limits: src/dataStructures.hpp:41-65 (gpudata::MAX*) ------------------------- */
+#define TPSRHS_MAXDIM 3
+#define TPSRHS_MAXSPECIES 8
+#define TPSRHS_MAXEQUATIONS (TPSRHS_MAXDIM + 2 + TPSRHS_MAXSPECIES)
+#define TPSRHS_MAXREACTIONS 34
+#define TPSRHS_MAXCHEMPARAMS 3
+#define TPSRHS_MAXTABLE 1000
+#define TPSRHS_MAXORDER 5 /* MAXDOFS = 216 = hex p=5 */
+
+/* ---- status codes (the reference uses assert/exit/MPI_Abort; src/equation_of_state.cpp:643-650) */
+enum tpsrhs_status {
+  TPSRHS_OK = 0,
+  TPSRHS_ERR_INVALID_ARGUMENT = 1,
+  TPSRHS_ERR_UNSUPPORTED = 2, /* a configuration outside the built hot-path scope */
+  TPSRHS_ERR_MESH = 3,        /* inconsistent connectivity / boundary faces */
+  TPSRHS_ERR_DEVICE = 4,      /* HIP runtime error */
+  TPSRHS_ERR_NO_DEVICE = 5,   /* no gfx950 device visible: the library never falls back to CPU */
+  TPSRHS_ERR_HALO = 6         /* halo-exchange callback failed */
+};
+
+/* ---- enums with the reference's names and values: src/dataStructures.hpp:67-196 -------------- */
+enum tpsrhs_equations { TPSRHS_EULER = 0, TPSRHS_NS = 1, TPSRHS_NS_PASSIVE = 2 };
+enum tpsrhs_working_fluid { TPSRHS_DRY_AIR = 0, TPSRHS_USER_DEFINED = 1, TPSRHS_LTE_FLUID = 2 };
+enum tpsrhs_transport_model {
+  TPSRHS_ARGON_MINIMAL = 0,
+  TPSRHS_ARGON_MIXTURE = 1,
+  TPSRHS_CONSTANT = 2,
+  TPSRHS_LTE_TRANSPORT = 3,
+  TPSRHS_MIXING_LENGTH = 4
+};
+enum tpsrhs_reaction_model {
+  TPSRHS_ARRHENIUS = 0,
+  TPSRHS_HOFFERTLIEN = 1,
+  TPSRHS_TABULATED_RXN = 2,
+  TPSRHS_GRIDFUNCTION_RXN = 3,
+  TPSRHS_RADIATIVE_DECAY = 4
+};
+enum tpsrhs_radiation_model { TPSRHS_NONE_RAD = 0, TPSRHS_NET_EMISSION = 1 };
+enum tpsrhs_gas_params {
+  TPSRHS_SPECIES_MW = 0,
+  TPSRHS_SPECIES_CHARGES = 1,
+  TPSRHS_FORMATION_ENERGY = 2,
+  TPSRHS_SPECIES_DEGENERACY = 3,
+  TPSRHS_NUM_GASPARAMS = 4
+};
+enum tpsrhs_gas_coll {
+  TPSRHS_CLMB_ATT = 0,
+  TPSRHS_CLMB_REP = 1,
+  TPSRHS_AR_AR1P = 2,
+  TPSRHS_AR_E = 3,
+  TPSRHS_AR_AR = 4,
+  TPSRHS_NONE_ARGCOLL = 5
+};
+enum tpsrhs_bc_category { TPSRHS_INLET = 0, TPSRHS_OUTLET = 1, TPSRHS_WALL = 2 };
+enum tpsrhs_inlet_type { TPSRHS_UNI_DENS_VEL = 0, TPSRHS_INTERPOLATE = 1, TPSRHS_SUB_DENS_VEL = 2 };
+enum tpsrhs_outlet_type { TPSRHS_SUB_P = 0 };
+enum tpsrhs_wall_type {
+  TPSRHS_INV = 0,
+  TPSRHS_SLIP = 1,
+  TPSRHS_VISC_ADIAB = 2,
+  TPSRHS_VISC_ISOTH = 3,
+  TPSRHS_VISC_GNRL = 4
+};
+enum tpsrhs_basis_type { TPSRHS_BASIS_GAUSS_LEGENDRE = 0, TPSRHS_BASIS_GAUSS_LOBATTO = 1 };
+
+/* ---- mesh: what the reference takes from mfem::ParMesh (src/M2ulPhyS.cpp:296-470) ------------ */
+typedef struct tpsrhs_mesh {
+  int dim;          /* 2 (quadrilaterals) or 3 (hexahedra) */
+  int num_vertices; /* topological vertices (periodic images identified) */
+  int num_elements;
+  const int *elem_vertices;   /* [num_elements * 2^dim] topological vertex ids, MFEM order */
+  const double *elem_coords;  /* [num_elements * 2^dim * dim] coordinates of each element's own
+                                 vertices (order-1 discontinuous nodes: periodic meshes keep their
+                                 geometry, as with mfem::Mesh::MakePeriodic) */
+  int num_bdr_faces;
+  const int *bdr_vertices;    /* [num_bdr_faces * 2^(dim-1)] */
+  const int *bdr_attributes;  /* [num_bdr_faces], matched to tpsrhs_bc::attribute */
+  /* faces shared with other ranks (mfem::ParMesh shared faces; src/rhs_operator.cpp:716-773).
+   * Listed in the same order on both ranks of a pair, grouped by neighbour rank. */
+  int num_shared_faces;
+  const int *shared_vertices;       /* [num_shared_faces * 2^(dim-1)] local vertex ids, ordered by
+                                       ascending GLOBAL vertex id (identical physical order on both
+                                       sides) */
+  const int *shared_neighbor_rank;  /* [num_shared_faces] */
+} tpsrhs_mesh;
+
+/* ---- discretisation: [flow] order/basisType/integrationRule (src/M2ulPhyS.cpp:557-579,2670) -- */
+typedef struct tpsrhs_disc {
+  int order;             /* polynomial order p, 1..TPSRHS_MAXORDER */
+  int basis_type;        /* tpsrhs_basis_type (reference basisType) */
+  int int_rule_type;     /* 0 Gauss-Legendre, 1 Gauss-Lobatto (reference integrationRule) */
+  int axisymmetric;      /* dim must be 2; nvel = 3 */
+  int use_bc_in_grad;    /* boundaryConditions/useBCinGrad (src/M2ulPhyS.cpp:3480) */
+} tpsrhs_disc;
+
+/* ---- physics parameter blocks: the PODs of src/dataStructures.hpp:537-729 -------------------- */
+typedef struct tpsrhs_dry_air { /* DryAirInput + SutherlandData + visc multipliers */
+  double specific_heat_ratio;   /* 1.4     (src/M2ulPhyS.cpp:2882) */
+  double gas_constant;          /* 287.058 (src/M2ulPhyS.cpp:2883) */
+  double visc_mult;             /* flow/viscosityMultiplier */
+  double bulk_visc_mult;        /* flow/bulkViscosityMultiplier */
+  double sutherland_C1;         /* 1.458e-6 */
+  double sutherland_S0;         /* 110.4 */
+  double sutherland_Pr;         /* 0.71 */
+} tpsrhs_dry_air;
+
+typedef struct tpsrhs_perfect_mixture { /* PerfectMixtureInput */
+  int num_species;
+  int is_electron_included;
+  int ambipolar;
+  int two_temperature;
+  double gas_params[TPSRHS_MAXSPECIES * TPSRHS_NUM_GASPARAMS]; /* [sp + param * num_species] */
+  double molar_cv[TPSRHS_MAXSPECIES];                          /* J/(mol K) */
+} tpsrhs_perfect_mixture;
+
+typedef struct tpsrhs_constant_transport { /* constantTransportData */
+  double viscosity;
+  double bulk_viscosity;
+  double diffusivity[TPSRHS_MAXSPECIES];
+  double thermal_conductivity;
+  double electron_thermal_conductivity;
+  double mt_freq[TPSRHS_MAXSPECIES];
+  int electron_index;
+} tpsrhs_constant_transport;
+
+typedef struct tpsrhs_gas_transport { /* GasTransportInput */
+  int neutral_index;
+  int ion_index;
+  int electron_index;
+  int third_order_k_electron;
+  int collision_index[TPSRHS_MAXSPECIES * TPSRHS_MAXSPECIES]; /* tpsrhs_gas_coll, [i + j*nsp] */
+  int multiply;
+  double flux_trns_multiplier[4];
+  double spcs_trns_multiplier[1];
+  double diff_mult;
+  double mobil_mult;
+} tpsrhs_gas_transport;
+
+typedef struct tpsrhs_table { /* TableInput (order 1 interpolation only, src/table.cpp:52-110) */
+  int n_data;
+  const double *x_data;
+  const double *f_data;
+  int x_log_scale;
+  int f_log_scale;
+} tpsrhs_table;
+
+typedef struct tpsrhs_chemistry { /* ChemistryInput */
+  int num_reactions;
+  int electron_index;
+  double reaction_energies[TPSRHS_MAXREACTIONS];
+  int detailed_balance[TPSRHS_MAXREACTIONS];
+  int16_t reactant_stoich[TPSRHS_MAXSPECIES * TPSRHS_MAXREACTIONS]; /* [sp + r * num_species] */
+  int16_t product_stoich[TPSRHS_MAXSPECIES * TPSRHS_MAXREACTIONS];
+  int reaction_models[TPSRHS_MAXREACTIONS];                          /* tpsrhs_reaction_model */
+  double equilibrium_constant_params[TPSRHS_MAXCHEMPARAMS * TPSRHS_MAXREACTIONS];
+  double rate_params[TPSRHS_MAXCHEMPARAMS * TPSRHS_MAXREACTIONS];    /* A, b, E of the model */
+  tpsrhs_table rate_tables[TPSRHS_MAXREACTIONS];                     /* TABULATED_RXN only */
+  double minimum_temperature;
+} tpsrhs_chemistry;
+
+typedef struct tpsrhs_radiation { /* RadiationInput */
+  int model; /* tpsrhs_radiation_model */
+  tpsrhs_table nec_table;
+} tpsrhs_radiation;
+
+typedef struct tpsrhs_physics {
+  int eq_system;        /* tpsrhs_equations */
+  int working_fluid;    /* tpsrhs_working_fluid */
+  tpsrhs_dry_air dry_air;
+  tpsrhs_perfect_mixture mixture;
+  int transport_model;  /* tpsrhs_transport_model (USER_DEFINED fluids) */
+  tpsrhs_constant_transport constant_transport;
+  tpsrhs_gas_transport gas_transport;
+  tpsrhs_chemistry chemistry;
+  tpsrhs_radiation radiation;
+} tpsrhs_physics;
+
+/* ---- boundary conditions: [boundaryConditions/...] (src/M2ulPhyS.cpp:3480-3700) --------------- */
+typedef struct tpsrhs_bc {
+  int attribute; /* mesh boundary attribute ("patch") */
+  int category;  /* tpsrhs_bc_category */
+  int type;      /* tpsrhs_inlet_type | tpsrhs_outlet_type | tpsrhs_wall_type */
+  /* inlet SUB_DENS_VEL: rho, u, v, w, then active species (src/inletBC.cpp:729-757)
+   * outlet SUB_P:       p                                  (src/outletBC.cpp:731-737)
+   * wall VISC_ISOTH:    T_wall                             (src/wallBC.cpp:96-111) */
+  double data[4 + TPSRHS_MAXSPECIES];
+} tpsrhs_bc;
+
+/* ---- runtime: device, stream and the halo-exchange hook -------------------------------------- */
+/* Called twice per Mult on a partitioned mesh, where the reference posts MPI_Isend/Irecv of
+ * neighbour-element data (src/rhs_operator.cpp:775-831).  `send` and `recv` are DEVICE buffers of
+ * doubles; segment r of each (offsets[r] .. offsets[r+1]) goes to / comes from neighbor_ranks[r].
+ * The callback must enqueue or complete the exchange so that `recv` is valid for work submitted to
+ * `stream` after it returns (RCCL send/recv on that stream, or a blocking GPU-aware MPI call).
+ * phase 0: U/Up face traces, phase 1: viscous normal-flux traces.  Return 0 on success. */
+typedef int (*tpsrhs_halo_fn)(void *ctx, int phase, const double *send, double *recv,
+                              int num_neighbors, const int *neighbor_ranks,
+                              const int64_t *send_offsets, const int64_t *recv_offsets, void *stream);
+
+typedef struct tpsrhs_runtime {
+  int device;            /* HIP device ordinal (reference: rank % numGpusPerRank, src/tps.cpp:196) */
+  void *stream;          /* hipStream_t for all work of this operator, NULL = default stream */
+  tpsrhs_halo_fn halo;   /* required when mesh.num_shared_faces > 0 */
+  void *halo_ctx;
+} tpsrhs_runtime;
+
+typedef struct tpsrhs_operator *tpsrhs_handle;
+
+/* Replaces the RHSoperator constructor and everything it precomputes (Me_inv, Ke, face tables:
+ * src/rhs_operator.cpp:39-322, src/gradients.cpp:84-133, src/M2ulPhyS.cpp:816-1486). */
+int tpsrhs_create(const tpsrhs_mesh *mesh, const tpsrhs_disc *disc, const tpsrhs_physics *physics,
+                  int num_bcs, const tpsrhs_bc *bcs, const tpsrhs_runtime *runtime,
+                  tpsrhs_handle *out);
+
+/* RHSoperator::~RHSoperator (src/rhs_operator.cpp:324-341). */
+int tpsrhs_destroy(tpsrhs_handle h);
+
+/* RHSoperator::Mult(const Vector &x, Vector &y) const  (src/rhs_operator.hpp:157,
+ * src/rhs_operator.cpp:343-464).  x, y: DEVICE pointers, num_equation*NDofs doubles, byNODES.
+ * `time` is TimeDependentOperator::GetTime() (src/rhs_operator.cpp:459).  When max_char_speed is
+ * non-NULL the rank-local maximum of |u|+c over the nodes (src/rhs_operator.cpp:549-553) is copied
+ * to that HOST address (this synchronises the stream; pass NULL to stay asynchronous; the
+ * MPI_Allreduce(MAX) of src/rhs_operator.cpp:558 is the caller's). */
+int tpsrhs_mult(tpsrhs_handle h, const double *x, double *y, double time, double *max_char_speed);
+
+/* Same with HOST vectors (copies over PCIe; for the MFEM adapter when Vectors live on the host). */
+int tpsrhs_mult_host(tpsrhs_handle h, const double *x, double *y, double time,
+                     double *max_char_speed);
+
+/* RHSoperator::updatePrimitives + updateGradients (src/rhs_operator.cpp:623-713): refresh the
+ * operator-owned Up / gradUp from x (device pointer). */
+int tpsrhs_update_gradients(tpsrhs_handle h, const double *x);
+
+/* Up / gradUp grid functions Mult refreshes as a side effect (src/rhs_operator.hpp:74-77):
+ * copy the operator-owned device arrays to a DEVICE buffer (neq*NDofs / dim*neq*NDofs doubles). */
+int tpsrhs_get_primitives(tpsrhs_handle h, double *up_out);
+int tpsrhs_get_gradients(tpsrhs_handle h, double *gradup_out);
+
+/* A->Height() (src/rhs_operator.cpp:49), vfes->GetNDofs(), num_equation. */
+int64_t tpsrhs_height(tpsrhs_handle h);
+int64_t tpsrhs_num_dofs(tpsrhs_handle h);
+int tpsrhs_num_equation(tpsrhs_handle h);
+
+/* Per-kernel device time of the LAST tpsrhs_mult, measured with hipEvents on the operator's
+ * stream (enable first; adds event records only).  names[i] are static strings.  Returns the
+ * number of kernels written (<= capacity). */
+int tpsrhs_enable_kernel_timing(tpsrhs_handle h, int enable);
+int tpsrhs_kernel_times(tpsrhs_handle h, int capacity, const char **names, double *milliseconds);
+
+/* Algorithmic HBM bytes one tpsrhs_mult moves per kernel (DESIGN.md "bytes per unit"), matching
+ * the order of tpsrhs_kernel_times. */
+int tpsrhs_kernel_bytes(tpsrhs_handle h, int capacity, const char **names, double *bytes);
+
+const char *tpsrhs_status_string(int status);
+const char *tpsrhs_last_error(void); /* thread-local text of the last failure */
+const char *tpsrhs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPSRHS_H_ */

@@ -1,0 +1,697 @@
+// TEST INFRASTRUCTURE -- CPU oracle, never shipped, never on the product path.
+//
+// Point-wise physics of the TPS compressible solver, restated function by function from the
+// reference (paths relative to the pecos/tps tree).  Same call structure as the reference (virtual
+// mixture / transport objects, raw-pointer state in, raw-pointer result out) so that the timed CPU
+// baseline pays what the reference pays.
+#ifndef TPS_ORACLE_PHYSICS_HPP_
+#define TPS_ORACLE_PHYSICS_HPP_
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include "../include/tpsrhs.h"
+
+namespace tpsoracle {
+
+constexpr int MAXEQ = TPSRHS_MAXEQUATIONS;
+constexpr int MAXSP = TPSRHS_MAXSPECIES;
+constexpr int MAXDIM = 3;
+
+// src/equation_of_state.hpp:55-67
+constexpr double UNIVERSALGASCONSTANT = 8.3144598;
+constexpr double AVOGADRONUMBER = 6.0221409e+23;
+constexpr double BOLTZMANNCONSTANT = UNIVERSALGASCONSTANT / AVOGADRONUMBER;
+constexpr double VACUUMPERMITTIVITY = 8.8541878128e-12;
+constexpr double ELECTRONCHARGE = 1.60218e-19;
+constexpr double MOLARELECTRONCHARGE = ELECTRONCHARGE * AVOGADRONUMBER;
+constexpr double PI_ = 3.14159265358979323846;
+
+enum FluxTrns { VISCOSITY, BULK_VISCOSITY, HEAVY_THERMAL_CONDUCTIVITY, ELECTRON_THERMAL_CONDUCTIVITY, NUM_FLUX_TRANS };
+enum SrcTrns { ELECTRIC_CONDUCTIVITY, NUM_SRC_TRANS };
+enum SpeciesTrns { MF_FREQUENCY, NUM_SPECIES_COEFFS };
+
+// src/dataStructures.hpp:575-605
+struct BoundaryViscousFluxData {
+  double normal[MAXDIM];
+  double primFlux[MAXEQ];
+  bool primFluxIdxs[MAXEQ];
+};
+struct BoundaryPrimitiveData {
+  double prim[MAXEQ];
+  bool primIdxs[MAXEQ];
+};
+
+// ------------------------------------------------------------------------------------------
+// GasMixture (src/equation_of_state.hpp:72-330)
+// ------------------------------------------------------------------------------------------
+class GasMixture {
+ public:
+  int dim = 0, nvel = 0, num_equation = 0;
+  int numSpecies = 1, numActiveSpecies = 0;
+  bool ambipolar = false, twoTemperature = false;
+  int iTh = 0;  // index of the heavy-species energy / temperature
+
+  virtual ~GasMixture() {}
+  virtual double ComputePressure(const double *state, double *electronPressure = nullptr) const = 0;
+  virtual double ComputeTemperature(const double *state) const = 0;
+  virtual double ComputeMaxCharSpeed(const double *state) const = 0;
+  virtual void GetPrimitivesFromConservatives(const double *conserv, double *primit) const = 0;
+  virtual void GetConservativesFromPrimitives(const double *primit, double *conserv) const = 0;
+  virtual void computeSpeciesEnthalpies(const double *state, double *speciesEnthalpies) const = 0;
+  virtual void computeStagnationState(const double *stateIn, double *stagnationState) const = 0;
+  virtual void computeStagnantStateWithTemp(const double *stateIn, double Temp, double *stateOut) const = 0;
+  virtual void modifyEnergyForPressure(const double *stateIn, double *stateOut, double p,
+                                       bool modifyElectronEnergy = false) const = 0;
+  virtual double GetGasConstant() const { return 0.0; }
+  virtual double GetSpecificHeatRatio() const { return 0.0; }
+  virtual double GetGasParams(int sp, int param) const { return 0.0; }
+};
+
+// DryAir: src/equation_of_state.cpp:146-412, inline parts src/equation_of_state.hpp:605-628
+class DryAir : public GasMixture {
+ public:
+  double specific_heat_ratio, gas_constant;
+  DryAir(const tpsrhs_dry_air &in, int dim_, int nvel_) {
+    dim = dim_;
+    nvel = nvel_;
+    specific_heat_ratio = in.specific_heat_ratio;
+    gas_constant = in.gas_constant;
+    numSpecies = 1;
+    numActiveSpecies = 0;
+    num_equation = nvel + 2;  // setNumEquations, :197-201
+    iTh = nvel + 1;
+  }
+  double GetGasConstant() const override { return gas_constant; }
+  double GetSpecificHeatRatio() const override { return specific_heat_ratio; }
+  double ComputePressure(const double *state, double *electronPressure = nullptr) const override {
+    if (electronPressure != nullptr) *electronPressure = 0.0;
+    double den_vel2 = 0;
+    for (int d = 0; d < nvel; d++) den_vel2 += state[d + 1] * state[d + 1];
+    den_vel2 /= state[0];
+    return (specific_heat_ratio - 1.0) * (state[1 + nvel] - 0.5 * den_vel2);
+  }
+  double ComputeTemperature(const double *state) const override {
+    double den_vel2 = 0;
+    for (int d = 0; d < nvel; d++) den_vel2 += state[d + 1] * state[d + 1];
+    den_vel2 /= state[0];
+    return (specific_heat_ratio - 1.0) / gas_constant * (state[1 + nvel] - 0.5 * den_vel2) / state[0];
+  }
+  double ComputeMaxCharSpeed(const double *state) const override {  // :278-292
+    const double den = state[0];
+    double den_vel2 = 0;
+    for (int d = 0; d < nvel; d++) den_vel2 += state[d + 1] * state[d + 1];
+    den_vel2 /= den;
+    const double pres = ComputePressure(state);
+    const double sound = std::sqrt(specific_heat_ratio * pres / den);
+    const double vel = std::sqrt(den_vel2 / den);
+    return vel + sound;
+  }
+  void GetPrimitivesFromConservatives(const double *conserv, double *primit) const override {  // :321-335
+    const double T = ComputeTemperature(conserv);
+    for (int eq = 0; eq < num_equation; eq++) primit[eq] = conserv[eq];
+    for (int d = 0; d < nvel; d++) primit[1 + d] /= conserv[0];
+    primit[iTh] = T;
+  }
+  void GetConservativesFromPrimitives(const double *primit, double *conserv) const override {  // :298-315
+    for (int eq = 0; eq < num_equation; eq++) conserv[eq] = primit[eq];
+    double v2 = 0.;
+    for (int d = 0; d < nvel; d++) {
+      v2 += primit[1 + d] * primit[1 + d];
+      conserv[1 + d] *= primit[0];
+    }
+    conserv[iTh] = gas_constant * primit[0] * primit[iTh] / (specific_heat_ratio - 1.) + 0.5 * primit[0] * v2;
+  }
+  void computeSpeciesEnthalpies(const double *, double *h) const override {
+    for (int sp = 0; sp < numSpecies; sp++) h[sp] = 0.0;
+  }
+  void computeStagnationState(const double *stateIn, double *out) const override {  // :367-378
+    const double p = ComputePressure(stateIn);
+    for (int eq = 0; eq < num_equation; eq++) out[eq] = stateIn[eq];
+    for (int d = 0; d < nvel; d++) out[1 + d] = 0.;
+    out[iTh] = p / (specific_heat_ratio - 1.);
+  }
+  void computeStagnantStateWithTemp(const double *stateIn, double Temp, double *out) const override {  // :380-387
+    for (int eq = 0; eq < num_equation; eq++) out[eq] = stateIn[eq];
+    for (int d = 0; d < nvel; d++) out[1 + d] = 0.;
+    out[iTh] = gas_constant / (specific_heat_ratio - 1.) * stateIn[0] * Temp;
+  }
+  void modifyEnergyForPressure(const double *stateIn, double *stateOut, double p, bool) const override {  // :402-411
+    double tmp[MAXEQ];
+    for (int eq = 0; eq < num_equation; eq++) tmp[eq] = stateIn[eq];
+    double ke = 0.;
+    for (int d = 0; d < nvel; d++) ke += stateIn[1 + d] * stateIn[1 + d];
+    ke *= 0.5 / stateIn[0];
+    for (int eq = 0; eq < num_equation; eq++) stateOut[eq] = tmp[eq];
+    stateOut[iTh] = p / (specific_heat_ratio - 1.) + ke;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// TransportProperties (src/transport_properties.hpp:48-260)
+// ------------------------------------------------------------------------------------------
+class TransportProperties {
+ public:
+  GasMixture *mixture;
+  int numSpecies, dim, nvel, numActiveSpecies, num_equation;
+  bool ambipolar, twoTemperature;
+  const double Xeps_ = 1.0e-30;
+  explicit TransportProperties(GasMixture *m) : mixture(m) {
+    numSpecies = m->numSpecies;
+    dim = m->dim;
+    nvel = m->nvel;
+    numActiveSpecies = m->numActiveSpecies;
+    ambipolar = m->ambipolar;
+    twoTemperature = m->twoTemperature;
+    num_equation = m->num_equation;
+  }
+  virtual ~TransportProperties() {}
+  virtual void ComputeFluxTransportProperties(const double *state, const double *gradUp, const double *Efield,
+                                              double radius, double distance, double *transportBuffer,
+                                              double *diffusionVelocity) = 0;
+  virtual void ComputeSourceTransportProperties(const double *state, const double *Up, const double *gradUp,
+                                                const double *Efield, double distance, double *globalTransport,
+                                                double *speciesTransport, double *diffusionVelocity,
+                                                double *n_sp) = 0;
+  virtual void GetViscosities(const double *conserved, const double *primitive, double *visc) = 0;
+
+  // src/transport_properties.cpp:59-201
+  void correctMassDiffusionFlux(const double *Y_sp, double *diffusionVelocity) const {
+    double Vc[MAXDIM];
+    for (int v = 0; v < nvel; v++) Vc[v] = 0.0;
+    for (int sp = 0; sp < numSpecies; sp++)
+      for (int d = 0; d < nvel; d++) Vc[d] += Y_sp[sp] * diffusionVelocity[sp + d * numSpecies];
+    for (int sp = 0; sp < numSpecies; sp++)
+      for (int d = 0; d < nvel; d++) diffusionVelocity[sp + d * numSpecies] -= Vc[d];
+  }
+  double computeMixtureElectricConductivity(const double *mobility, const double *n_sp) const {
+    double mho = 0.0;
+    for (int sp = 0; sp < numSpecies; sp++)
+      mho += mobility[sp] * n_sp[sp] * mixture->GetGasParams(sp, TPSRHS_SPECIES_CHARGES);
+    return mho;
+  }
+  void addAmbipolarEfield(const double *mobility, const double *n_sp, double *diffusionVelocity) const {
+    const double mho = computeMixtureElectricConductivity(mobility, n_sp);
+    double ambE[MAXDIM];
+    for (int v = 0; v < nvel; v++) ambE[v] = 0.0;
+    for (int sp = 0; sp < numSpecies; sp++)
+      for (int d = 0; d < nvel; d++)
+        ambE[d] -= diffusionVelocity[sp + d * numSpecies] * n_sp[sp] *
+                   mixture->GetGasParams(sp, TPSRHS_SPECIES_CHARGES);
+    for (int d = 0; d < nvel; d++) ambE[d] /= (mho + Xeps_);
+    for (int sp = 0; sp < numSpecies; sp++)
+      for (int d = 0; d < nvel; d++) diffusionVelocity[sp + d * numSpecies] += mobility[sp] * ambE[d];
+  }
+  void addMixtureDrift(const double *mobility, const double *, const double *Efield,
+                       double *diffusionVelocity) const {
+    for (int sp = 0; sp < numSpecies; sp++) {
+      if (mixture->GetGasParams(sp, TPSRHS_SPECIES_CHARGES) == 0.0) continue;
+      for (int d = 0; d < nvel; d++) diffusionVelocity[sp + d * numSpecies] += mobility[sp] * Efield[d];
+    }
+  }
+  double linearAverage(const double *X_sp, const double *speciesTransport) const {
+    double average = 0.0;
+    for (int sp = 0; sp < numSpecies; sp++) average += X_sp[sp] * speciesTransport[sp];
+    return average;
+  }
+  void CurtissHirschfelder(const double *X_sp, const double *Y_sp, const double *binaryDiff,
+                           double *avgDiff) const {
+    for (int sp = 0; sp < numSpecies; sp++) avgDiff[sp] = 0.0;
+    for (int spI = 0; spI < numSpecies; spI++) {
+      for (int spJ = 0; spJ < numSpecies; spJ++) {
+        if (spI == spJ) continue;
+        avgDiff[spI] += (X_sp[spJ] + Xeps_) / binaryDiff[spI + spJ * numSpecies];
+      }
+      avgDiff[spI] = (1.0 - Y_sp[spI]) / avgDiff[spI];
+    }
+  }
+};
+
+// DryAirTransport: src/transport_properties.cpp:205-330
+class DryAirTransport : public TransportProperties {
+ public:
+  double visc_mult, bulk_visc_mult, C1_, S0_, Pr_, Sc, gas_constant, cp_div_pr;
+  DryAirTransport(GasMixture *m, const tpsrhs_dry_air &in) : TransportProperties(m) {
+    visc_mult = in.visc_mult;
+    bulk_visc_mult = in.bulk_visc_mult;
+    C1_ = in.sutherland_C1;
+    S0_ = in.sutherland_S0;
+    Pr_ = in.sutherland_Pr;
+    Sc = 0.71;
+    gas_constant = m->GetGasConstant();
+    const double g = m->GetSpecificHeatRatio();
+    cp_div_pr = g * gas_constant / (Pr_ * (g - 1.));
+  }
+  void ComputeFluxTransportProperties(const double *state, const double *, const double *, double, double,
+                                      double *transportBuffer, double *diffusionVelocity) override {  // :224-266
+    const double p = mixture->ComputePressure(state);
+    const double temp = p / gas_constant / state[0];
+    for (int i = 0; i < NUM_FLUX_TRANS; i++) transportBuffer[i] = 0.0;
+    const double viscosity = (C1_ * visc_mult * std::pow(temp, 1.5) / (temp + S0_));
+    transportBuffer[VISCOSITY] = viscosity;
+    transportBuffer[BULK_VISCOSITY] = bulk_visc_mult * viscosity;
+    transportBuffer[HEAVY_THERMAL_CONDUCTIVITY] = cp_div_pr * transportBuffer[VISCOSITY];
+    for (int v = 0; v < nvel; v++)
+      for (int sp = 0; sp < numSpecies; sp++) diffusionVelocity[sp + v * numSpecies] = 0.0;
+  }
+  void ComputeSourceTransportProperties(const double *, const double *, const double *, const double *, double,
+                                        double *globalTransport, double *speciesTransport,
+                                        double *diffusionVelocity, double *n_sp) override {
+    for (int i = 0; i < NUM_SRC_TRANS; i++) globalTransport[i] = 0.0;
+    for (int i = 0; i < numSpecies; i++) speciesTransport[i] = 0.0;
+    for (int i = 0; i < numSpecies * nvel; i++) diffusionVelocity[i] = 0.0;
+    for (int i = 0; i < numSpecies; i++) n_sp[i] = 0.0;
+  }
+  void GetViscosities(const double *conserved, const double *, double *visc) override {  // :268-276
+    const double p = mixture->ComputePressure(conserved);
+    const double temp = p / gas_constant / conserved[0];
+    visc[0] = (C1_ * visc_mult * std::pow(temp, 1.5) / (temp + S0_));
+    visc[1] = bulk_visc_mult * visc[0];
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Fluxes (src/fluxes.cpp)
+// ------------------------------------------------------------------------------------------
+class Fluxes {
+ public:
+  GasMixture *mixture;
+  TransportProperties *transport;
+  int eqSystem, dim, nvel, num_equation, numActiveSpecies;
+  bool axisymmetric;
+  Fluxes(GasMixture *m, int eqSys, TransportProperties *t, int neq, int dim_, bool axisym)
+      : mixture(m), transport(t), eqSystem(eqSys), dim(dim_), num_equation(neq), axisymmetric(axisym) {
+    nvel = m->nvel;
+    numActiveSpecies = m->numActiveSpecies;
+  }
+
+  // src/fluxes.cpp:135-170
+  void ComputeConvectiveFluxes(const double *state, double *flux) const {
+    double Pe = 0.0;
+    const double pres = mixture->ComputePressure(state, &Pe);
+    for (int d = 0; d < dim; d++) {
+      flux[0 + d * num_equation] = state[d + 1];
+      for (int i = 0; i < nvel; i++) flux[1 + i + d * num_equation] = state[i + 1] * state[d + 1] / state[0];
+      flux[1 + d + d * num_equation] += pres;
+    }
+    const double H = (state[1 + nvel] + pres) / state[0];
+    for (int d = 0; d < dim; d++) flux[1 + nvel + d * num_equation] = state[d + 1] * H;
+    for (int sp = 0; sp < numActiveSpecies; sp++)
+      for (int d = 0; d < dim; d++)
+        flux[nvel + 2 + sp + d * num_equation] = state[nvel + 2 + sp] * state[1 + d] / state[0];
+    if (mixture->twoTemperature) {
+      const double electronEnthalpy = (state[num_equation - 1] + Pe) / state[0];
+      for (int d = 0; d < dim; d++) flux[num_equation - 1 + d * num_equation] = electronEnthalpy * state[1 + d];
+    }
+  }
+
+  // src/fluxes.cpp:178-335 (SGS models and the viscous sponge are outside the hot-path scope)
+  void ComputeViscousFluxes(const double *state, const double *gradUp, const double *transip, double /*delta*/,
+                            double distance, double *flux) const {
+    for (int d = 0; d < dim; d++)
+      for (int eq = 0; eq < num_equation; eq++) flux[eq + d * num_equation] = 0.;
+    if (eqSystem == TPSRHS_EULER) return;
+
+    double radius = -1;
+    if (axisymmetric) radius = transip[0];
+
+    double vel[MAXDIM], vtmp[MAXDIM], stress[MAXDIM * MAXDIM];
+    double Efield[MAXDIM];
+    for (int v = 0; v < nvel; v++) Efield[v] = 0.0;
+
+    const int numSpecies = mixture->numSpecies;
+    const bool twoT = mixture->twoTemperature;
+
+    double speciesEnthalpies[MAXSP];
+    mixture->computeSpeciesEnthalpies(state, speciesEnthalpies);
+
+    double transportBuffer[NUM_FLUX_TRANS];
+    double diffusionVelocity[MAXSP * MAXDIM];
+    transport->ComputeFluxTransportProperties(state, gradUp, Efield, radius, distance, transportBuffer,
+                                              diffusionVelocity);
+    double visc = transportBuffer[VISCOSITY];
+    double bulkViscosity = transportBuffer[BULK_VISCOSITY];
+    bulkViscosity -= 2. / 3. * visc;
+    double k = transportBuffer[HEAVY_THERMAL_CONDUCTIVITY];
+    double ke = transportBuffer[ELECTRON_THERMAL_CONDUCTIVITY];
+
+    if (twoT) {
+      for (int d = 0; d < dim; d++) {
+        double qeFlux = ke * gradUp[num_equation - 1 + d * num_equation];
+        flux[1 + nvel + d * num_equation] += qeFlux;
+        flux[num_equation - 1 + d * num_equation] += qeFlux;
+        flux[num_equation - 1 + d * num_equation] -=
+            speciesEnthalpies[numSpecies - 2] * diffusionVelocity[numSpecies - 2 + d * numSpecies];
+      }
+    } else {
+      k += ke;
+    }
+
+    const double ur = (axisymmetric ? state[1] / state[0] : 0);
+    const double ut = (axisymmetric ? state[3] / state[0] : 0);
+
+    for (int d = 0; d < dim; d++) flux[0 + d * num_equation] = 0.;
+
+    double divV = 0.;
+    for (int i = 0; i < dim; i++) {
+      for (int j = 0; j < dim; j++)
+        stress[i + j * dim] = gradUp[(1 + j) + i * num_equation] + gradUp[(1 + i) + j * num_equation];
+      divV += gradUp[(1 + i) + i * num_equation];
+    }
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) stress[i + j * dim] *= visc;
+    if (axisymmetric && radius > 0) divV += ur / radius;
+    for (int i = 0; i < dim; i++) stress[i + i * dim] += bulkViscosity * divV;
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) flux[(1 + i) + j * num_equation] = stress[i + j * dim];
+
+    double tau_tr = 0, tau_tz = 0;
+    if (axisymmetric) {
+      const double ut_r = gradUp[3 + 0 * num_equation];
+      const double ut_z = gradUp[3 + 1 * num_equation];
+      tau_tr = ut_r;
+      if (radius > 0) tau_tr -= ut / radius;
+      tau_tr *= visc;
+      tau_tz = visc * ut_z;
+      flux[(1 + 2) + 0 * num_equation] = tau_tr;
+      flux[(1 + 2) + 1 * num_equation] = tau_tz;
+    }
+
+    for (int d = 0; d < dim; d++) vel[d] = state[1 + d] / state[0];
+    for (int i = 0; i < dim; i++) {
+      vtmp[i] = 0.0;
+      for (int j = 0; j < dim; j++) vtmp[i] += stress[i + j * dim] * vel[j];
+    }
+    for (int d = 0; d < dim; d++) {
+      flux[(1 + nvel) + d * num_equation] += vtmp[d];
+      flux[(1 + nvel) + d * num_equation] += k * gradUp[(1 + nvel) + d * num_equation];
+      for (int sp = 0; sp < numSpecies; sp++)
+        flux[(1 + nvel) + d * num_equation] -= speciesEnthalpies[sp] * diffusionVelocity[sp + d * numSpecies];
+    }
+    if (axisymmetric) {
+      flux[(1 + nvel) + 0 * num_equation] += ut * tau_tr;
+      flux[(1 + nvel) + 1 * num_equation] += ut * tau_tz;
+    }
+    for (int sp = 0; sp < numActiveSpecies; sp++)
+      for (int d = 0; d < dim; d++)
+        flux[(nvel + 2 + sp) + d * num_equation] = -state[nvel + 2 + sp] * diffusionVelocity[sp + d * numSpecies];
+  }
+
+  // src/fluxes.cpp:344-505
+  void ComputeBdrViscousFluxes(const double *state, const double *gradUp, const double *transip, double /*delta*/,
+                               double distance, const BoundaryViscousFluxData &bcFlux, double *normalFlux) const {
+    for (int eq = 0; eq < num_equation; eq++) normalFlux[eq] = 0.;
+    if (eqSystem == TPSRHS_EULER) return;
+
+    double radius = -1;
+    if (axisymmetric) radius = transip[0];
+
+    double stress[MAXDIM * MAXDIM];
+    double Efield[MAXDIM];
+    for (int v = 0; v < nvel; v++) Efield[v] = 0.0;
+
+    const int numSpecies = mixture->numSpecies;
+    const bool twoT = mixture->twoTemperature;
+
+    double speciesEnthalpies[MAXSP];
+    mixture->computeSpeciesEnthalpies(state, speciesEnthalpies);
+
+    double transportBuffer[NUM_FLUX_TRANS];
+    double diffusionVelocity[MAXSP * MAXDIM];
+    transport->ComputeFluxTransportProperties(state, gradUp, Efield, radius, distance, transportBuffer,
+                                              diffusionVelocity);
+    double visc = transportBuffer[VISCOSITY];
+    double bulkViscosity = transportBuffer[BULK_VISCOSITY];
+    bulkViscosity -= 2. / 3. * visc;
+    double k = transportBuffer[HEAVY_THERMAL_CONDUCTIVITY];
+    double ke = transportBuffer[ELECTRON_THERMAL_CONDUCTIVITY];
+
+    const int primFluxSize = twoT ? numSpecies + nvel + 2 : numSpecies + nvel + 1;
+    double normalPrimFlux[MAXEQ + 2];
+    for (int eq = 0; eq < primFluxSize; eq++) normalPrimFlux[eq] = 0.0;
+
+    for (int sp = 0; sp < numSpecies; sp++)
+      for (int d = 0; d < dim; d++) normalPrimFlux[sp] += diffusionVelocity[sp + d * numSpecies] * bcFlux.normal[d];
+    for (int i = 0; i < numSpecies; i++)
+      if (bcFlux.primFluxIdxs[i]) normalPrimFlux[i] = bcFlux.primFlux[i];
+
+    const double ur = (axisymmetric ? state[1] / state[0] : 0);
+    const double ut = (axisymmetric ? state[3] / state[0] : 0);
+
+    double divV = 0.;
+    for (int i = 0; i < dim; i++) {
+      for (int j = 0; j < dim; j++)
+        stress[i + j * dim] = gradUp[(1 + j) + i * num_equation] + gradUp[(1 + i) + j * num_equation];
+      divV += gradUp[(1 + i) + i * num_equation];
+    }
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) stress[i + j * dim] *= visc;
+    if (axisymmetric && radius > 0) divV += ur / radius;
+    for (int i = 0; i < dim; i++) stress[i + i * dim] += bulkViscosity * divV;
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) normalPrimFlux[numSpecies + i] += stress[i + j * dim] * bcFlux.normal[j];
+
+    if (axisymmetric) {
+      const double ut_r = gradUp[3 + 0 * num_equation];
+      const double ut_z = gradUp[3 + 1 * num_equation];
+      double tau_tr = ut_r;
+      if (radius > 0) tau_tr -= ut / radius;
+      tau_tr *= visc;
+      const double tau_tz = visc * ut_z;
+      normalPrimFlux[numSpecies + nvel - 1] += tau_tr * bcFlux.normal[0];
+      normalPrimFlux[numSpecies + nvel - 1] += tau_tz * bcFlux.normal[1];
+    }
+
+    if (twoT) {
+      for (int d = 0; d < dim; d++)
+        normalPrimFlux[primFluxSize - 1] -= ke * gradUp[(num_equation - 1) + d * num_equation] * bcFlux.normal[d];
+      normalPrimFlux[primFluxSize - 1] += speciesEnthalpies[numSpecies - 2] * normalPrimFlux[numSpecies - 2];
+    } else {
+      k += ke;
+    }
+    for (int d = 0; d < dim; d++)
+      normalPrimFlux[numSpecies + nvel] -= k * gradUp[(1 + nvel) + d * num_equation] * bcFlux.normal[d];
+    for (int sp = 0; sp < numSpecies; sp++) {
+      if (twoT && (sp == numSpecies - 2)) continue;
+      normalPrimFlux[numSpecies + nvel] += speciesEnthalpies[sp] * normalPrimFlux[sp];
+    }
+    for (int i = numSpecies; i < primFluxSize; i++)
+      if (bcFlux.primFluxIdxs[i]) normalPrimFlux[i] = bcFlux.primFlux[i];
+
+    double vel0[MAXDIM];
+    for (int d = 0; d < nvel; d++) vel0[d] = state[1 + d] / state[0];
+
+    for (int sp = 0; sp < numActiveSpecies; sp++)
+      normalFlux[nvel + 2 + sp] = -state[nvel + 2 + sp] * normalPrimFlux[sp];
+    for (int d = 0; d < nvel; d++) normalFlux[d + 1] = normalPrimFlux[numSpecies + d];
+    for (int d = 0; d < nvel; d++) normalFlux[nvel + 1] += normalPrimFlux[numSpecies + d] * vel0[d];
+    normalFlux[nvel + 1] -= normalPrimFlux[numSpecies + nvel];
+    if (twoT) {
+      normalFlux[nvel + 1] -= normalPrimFlux[primFluxSize - 1];
+      normalFlux[num_equation - 1] = -normalPrimFlux[primFluxSize - 1];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// RiemannSolverTPS (src/riemann_solver.cpp:53-115), Lax-Friedrichs only
+// ------------------------------------------------------------------------------------------
+class RiemannSolver {
+ public:
+  int num_equation;
+  GasMixture *mixture;
+  Fluxes *fluxClass;
+  RiemannSolver(int neq, GasMixture *m, Fluxes *f) : num_equation(neq), mixture(m), fluxClass(f) {}
+  void ComputeFluxDotN(const double *state, const double *nor, double *fluxN) const {
+    const int dim = mixture->dim;
+    double fluxes[MAXEQ * MAXDIM];
+    fluxClass->ComputeConvectiveFluxes(state, fluxes);
+    for (int eq = 0; eq < num_equation; eq++) {
+      fluxN[eq] = 0;
+      for (int d = 0; d < dim; d++) fluxN[eq] += fluxes[eq + d * num_equation] * nor[d];
+    }
+  }
+  void Eval_LF(const double *state1, const double *state2, const double *nor, double *flux) const {
+    const int dim = mixture->dim;
+    const double maxE1 = mixture->ComputeMaxCharSpeed(state1);
+    const double maxE2 = mixture->ComputeMaxCharSpeed(state2);
+    const double maxE = std::fmax(maxE1, maxE2);
+    double flux1[MAXEQ], flux2[MAXEQ];
+    ComputeFluxDotN(state1, nor, flux1);
+    ComputeFluxDotN(state2, nor, flux2);
+    double normag = 0;
+    for (int i = 0; i < dim; i++) normag += nor[i] * nor[i];
+    normag = std::sqrt(normag);
+    for (int i = 0; i < num_equation; i++)
+      flux[i] = 0.5 * (flux1[i] + flux2[i]) - 0.5 * maxE * (state2[i] - state1[i]) * normag;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Boundary conditions: the types of SURVEY.md 8a(a9)
+// ------------------------------------------------------------------------------------------
+class BoundaryCondition {
+ public:
+  int category, type;
+  GasMixture *mixture;
+  Fluxes *fluxClass;
+  RiemannSolver *rsolver;
+  int dim, nvel, num_equation, numActiveSpecies;
+  bool useBCinGrad;
+  double inputState[4 + MAXSP];
+  double wallTemp = 0.0;
+  BoundaryViscousFluxData bcFlux;
+
+  BoundaryCondition(const tpsrhs_bc &bc, GasMixture *m, Fluxes *f, RiemannSolver *r, bool axisym, bool bcInGrad)
+      : category(bc.category), type(bc.type), mixture(m), fluxClass(f), rsolver(r), useBCinGrad(bcInGrad) {
+    dim = m->dim;
+    nvel = m->nvel;
+    num_equation = m->num_equation;
+    numActiveSpecies = m->numActiveSpecies;
+    for (int i = 0; i < 4 + MAXSP; i++) inputState[i] = bc.data[i];
+    const int numSpecies = m->numSpecies;
+    const int primFluxSize = m->twoTemperature ? numSpecies + nvel + 2 : numSpecies + nvel + 1;
+    for (int i = 0; i < MAXEQ; i++) {
+      bcFlux.primFlux[i] = 0.0;
+      bcFlux.primFluxIdxs[i] = false;
+    }
+    (void)primFluxSize;
+    if (category == TPSRHS_WALL) {  // src/wallBC.cpp:65-148
+      switch (type) {
+        case TPSRHS_INV:
+          for (int i = 0; i < numSpecies; i++) bcFlux.primFluxIdxs[i] = true;
+          if (axisym) {
+            bcFlux.primFluxIdxs[numSpecies + nvel] = true;
+            if (m->twoTemperature) bcFlux.primFluxIdxs[numSpecies + nvel + 1] = true;
+          }
+          break;
+        case TPSRHS_VISC_ADIAB:
+          for (int i = 0; i < numSpecies; i++) bcFlux.primFluxIdxs[i] = true;
+          bcFlux.primFluxIdxs[numSpecies + nvel] = true;
+          if (m->twoTemperature) bcFlux.primFluxIdxs[numSpecies + nvel + 1] = true;
+          break;
+        case TPSRHS_VISC_ISOTH:
+          for (int i = 0; i < numSpecies; i++) bcFlux.primFluxIdxs[i] = true;
+          wallTemp = bc.data[0];
+          break;
+        default:
+          throw std::runtime_error("wall type outside the hot-path scope");
+      }
+    } else if (category == TPSRHS_INLET) {
+      if (type != TPSRHS_SUB_DENS_VEL) throw std::runtime_error("inlet type outside the hot-path scope");
+    } else if (category == TPSRHS_OUTLET) {
+      if (type != TPSRHS_SUB_P) throw std::runtime_error("outlet type outside the hot-path scope");
+    }
+  }
+
+  // src/wallBC.cpp:241-266 (only the isothermal wall alters the gradient ghost state)
+  void computeBdrPrimitiveStateForGradient(const double *primIn, double *primBC) const {
+    for (int eq = 0; eq < num_equation; eq++) primBC[eq] = primIn[eq];
+    if (category == TPSRHS_WALL && type == TPSRHS_VISC_ISOTH) {
+      for (int i = 0; i < nvel; i++) primBC[1 + i] = 0.0;
+      primBC[nvel + 1] = wallTemp;
+    }
+  }
+
+  void computeBdrFlux(const double *normal, const double *stateIn, const double *gradState, const double *transip,
+                      double delta, double distance, double *bdrFlux) {
+    if (category == TPSRHS_INLET) {  // src/inletBC.cpp:729-757
+      const double p = mixture->ComputePressure(stateIn);
+      double state2[MAXEQ];
+      for (int eq = 0; eq < num_equation; eq++) state2[eq] = stateIn[eq];
+      state2[0] = inputState[0];
+      state2[1] = inputState[0] * inputState[1];
+      state2[2] = inputState[0] * inputState[2];
+      if (nvel == 3) state2[3] = inputState[0] * inputState[3];
+      for (int sp = 0; sp < numActiveSpecies; sp++) state2[nvel + 2 + sp] = inputState[4 + sp];
+      mixture->modifyEnergyForPressure(state2, state2, p, true);
+      rsolver->Eval_LF(stateIn, state2, normal, bdrFlux);
+      return;
+    }
+    if (category == TPSRHS_OUTLET) {  // src/outletBC.cpp:731-737
+      double state2[MAXEQ];
+      mixture->modifyEnergyForPressure(stateIn, state2, inputState[0]);
+      rsolver->Eval_LF(stateIn, state2, normal, bdrFlux);
+      return;
+    }
+    switch (type) {
+      case TPSRHS_INV: {  // src/wallBC.cpp:277-320
+        double vel[MAXDIM];
+        for (int d = 0; d < nvel; d++) vel[d] = stateIn[1 + d] / stateIn[0];
+        double norm = 0.;
+        for (int d = 0; d < dim; d++) norm += normal[d] * normal[d];
+        norm = std::sqrt(norm);
+        double unitN[MAXDIM];
+        for (int d = 0; d < dim; d++) unitN[d] = normal[d] / norm;
+        double vn = 0;
+        for (int d = 0; d < dim; d++) vn += vel[d] * unitN[d];
+        double stateMirror[MAXEQ];
+        for (int eq = 0; eq < num_equation; eq++) stateMirror[eq] = stateIn[eq];
+        stateMirror[1] = stateIn[0] * (vel[0] - 2. * vn * unitN[0]);
+        stateMirror[2] = stateIn[0] * (vel[1] - 2. * vn * unitN[1]);
+        if (dim == 3) stateMirror[3] = stateIn[0] * (vel[2] - 2. * vn * unitN[2]);
+        if ((nvel == 3) && (dim == 2)) stateMirror[3] = stateIn[0] * vel[2];
+        rsolver->Eval_LF(stateIn, stateMirror, normal, bdrFlux);
+        double wallViscF[MAXEQ], viscF[MAXEQ * MAXDIM], viscFw[MAXEQ * MAXDIM];
+        fluxClass->ComputeViscousFluxes(stateMirror, gradState, transip, delta, distance, viscFw);
+        for (int eq = 0; eq < num_equation; eq++) {
+          wallViscF[eq] = 0.0;
+          for (int d = 0; d < dim; d++) wallViscF[eq] += viscFw[eq + d * num_equation] * normal[d];
+        }
+        fluxClass->ComputeViscousFluxes(stateIn, gradState, transip, delta, distance, viscF);
+        for (int eq = 1; eq < num_equation; eq++) {
+          bdrFlux[eq] -= 0.5 * wallViscF[eq];
+          for (int d = 0; d < dim; d++) bdrFlux[eq] -= 0.5 * viscF[eq + d * num_equation] * normal[d];
+        }
+      } break;
+      case TPSRHS_VISC_ADIAB: {  // src/wallBC.cpp:430-469
+        double wallState[MAXEQ];
+        mixture->computeStagnationState(stateIn, wallState);
+        rsolver->Eval_LF(stateIn, wallState, normal, bdrFlux);
+        double viscF[MAXEQ * MAXDIM];
+        fluxClass->ComputeViscousFluxes(stateIn, gradState, transip, delta, 0.0, viscF);
+        double normN = 0.;
+        for (int d = 0; d < dim; d++) normN += normal[d] * normal[d];
+        for (int d = 0; d < dim; d++) bcFlux.normal[d] = normal[d] * (1. / std::sqrt(normN));
+        double wallViscF[MAXEQ];
+        fluxClass->ComputeBdrViscousFluxes(wallState, gradState, transip, delta, 0.0, bcFlux, wallViscF);
+        for (int eq = 0; eq < num_equation; eq++) wallViscF[eq] *= std::sqrt(normN);
+        for (int eq = 1; eq < num_equation; eq++) {
+          bdrFlux[eq] -= 0.5 * wallViscF[eq];
+          for (int d = 0; d < dim; d++) bdrFlux[eq] -= 0.5 * viscF[eq + d * num_equation] * normal[d];
+        }
+      } break;
+      case TPSRHS_VISC_ISOTH: {  // src/wallBC.cpp:471-510
+        double wallState[MAXEQ];
+        for (int eq = 0; eq < num_equation; eq++) wallState[eq] = stateIn[eq];
+        if (useBCinGrad) {
+          for (int i = 0; i < nvel; i++) wallState[i + 1] *= -1.0;
+        } else {
+          mixture->computeStagnantStateWithTemp(stateIn, wallTemp, wallState);
+        }
+        rsolver->Eval_LF(stateIn, wallState, normal, bdrFlux);
+        double normN = 0.;
+        for (int d = 0; d < dim; d++) normN += normal[d] * normal[d];
+        for (int d = 0; d < dim; d++) bcFlux.normal[d] = normal[d] * (1. / std::sqrt(normN));
+        mixture->computeStagnantStateWithTemp(stateIn, wallTemp, wallState);
+        double wallViscF[MAXEQ];
+        fluxClass->ComputeBdrViscousFluxes(wallState, gradState, transip, delta, 0.0, bcFlux, wallViscF);
+        for (int eq = 0; eq < num_equation; eq++) wallViscF[eq] *= std::sqrt(normN);
+        double viscF[MAXEQ * MAXDIM];
+        fluxClass->ComputeViscousFluxes(stateIn, gradState, transip, delta, 0.0, viscF);
+        for (int eq = 1; eq < num_equation; eq++) {
+          bdrFlux[eq] -= 0.5 * wallViscF[eq];
+          for (int d = 0; d < dim; d++) bdrFlux[eq] -= 0.5 * viscF[eq + d * num_equation] * normal[d];
+        }
+      } break;
+      default:
+        throw std::runtime_error("wall type outside the hot-path scope");
+    }
+  }
+};
+
+}  // namespace tpsoracle
+#endif

@@ -1,0 +1,662 @@
+// TEST INFRASTRUCTURE -- CPU oracle, never shipped, never on the product path.
+//
+// CPU restatement of RHSoperator::Mult (pecos/tps, src/rhs_operator.cpp:343-464) in the reference's
+// own dense formulation: per-element Ke (src/gradients.cpp:84-133), inverse mass matrices
+// (src/rhs_operator.cpp:173-224), the assembled (v, grad w) block matrix
+// (src/domain_integrator.cpp:45-99), per-face quadrature loops with CalcShape at every point
+// (src/face_integrator.cpp:194-352, src/faceGradientIntegration.cpp:40-140,
+// src/BCintegrator.cpp:295-441).  No sum factorisation, no fusion: it doubles as the timed CPU
+// baseline ("port").  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// load this library.
+//
+// PARITY UNPINNED for the assembled operator: the reference's golden solutions are git-LFS
+// pointers and MFEM is absent.  Pinned pieces: see oracle/README.md.
+#include <omp.h>
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "fe.hpp"
+#include "physics.hpp"
+#include "plasma.hpp"
+
+namespace tpsoracle {
+
+struct Operator {
+  Mesh mesh;
+  Element fe;
+  tpsrhs_disc disc;
+  tpsrhs_physics phys;
+  int dim, nvel, neq, dof, ne;
+  int64_t ndofs;
+  bool axisym;
+
+  std::unique_ptr<GasMixture> mixture;
+  std::unique_ptr<TransportProperties> transport;
+  std::unique_ptr<Fluxes> fluxes;
+  std::unique_ptr<RiemannSolver> rsolver;
+  std::unique_ptr<SourceTerm> source;
+  std::map<int, std::unique_ptr<BoundaryCondition>> bcs;
+
+  RuleND volRule;   // order 2p
+  RuleND faceRule;  // order OrderW + 2p on the reference segment/square
+  std::vector<Dense> Ke, MeInv, Aflux;
+  std::vector<double> coords;  // byNODES [n + d*ndofs]
+  std::vector<double> Up, gradUp;
+  double max_char_speed = 0.0;
+  // scratch
+  std::vector<double> z, flux, faceContrib;
+
+  void setup(const tpsrhs_mesh *m, const tpsrhs_disc *d, const tpsrhs_physics *p, int nbc, const tpsrhs_bc *bc) {
+    disc = *d;
+    phys = *p;
+    dim = m->dim;
+    axisym = d->axisymmetric != 0;
+    if (axisym && dim != 2) throw std::runtime_error("axisymmetric requires dim == 2");
+    nvel = axisym ? 3 : dim;
+    mesh.build(m->dim, m->num_vertices, m->num_elements, m->elem_vertices, m->elem_coords, m->num_bdr_faces,
+               m->bdr_vertices, m->bdr_attributes);
+    ne = mesh.ne;
+    fe.init(dim, d->order, d->basis_type);
+    dof = fe.dof;
+    ndofs = static_cast<int64_t>(ne) * dof;
+
+    if (p->working_fluid == TPSRHS_DRY_AIR) {
+      mixture.reset(new DryAir(p->dry_air, dim, nvel));
+      transport.reset(new DryAirTransport(mixture.get(), p->dry_air));
+    } else if (p->working_fluid == TPSRHS_USER_DEFINED) {
+      PerfectMixture *pm = new PerfectMixture(p->mixture, dim, nvel);
+      mixture.reset(pm);
+      transport.reset(make_transport(pm, *p));
+    } else {
+      throw std::runtime_error("working fluid outside the hot-path scope");
+    }
+    neq = mixture->num_equation;
+    fluxes.reset(new Fluxes(mixture.get(), p->eq_system, transport.get(), neq, dim, axisym));
+    rsolver.reset(new RiemannSolver(neq, mixture.get(), fluxes.get()));
+    if (p->working_fluid != TPSRHS_DRY_AIR) {  // src/rhs_operator.cpp:125-129
+      source.reset(new SourceTerm(dim, neq, static_cast<PerfectMixture *>(mixture.get()), transport.get(), *p));
+    }
+    for (int i = 0; i < nbc; i++)
+      bcs[bc[i].attribute].reset(
+          new BoundaryCondition(bc[i], mixture.get(), fluxes.get(), rsolver.get(), axisym, d->use_bc_in_grad != 0));
+    for (const Face &F : mesh.faces)
+      if (F.e2 < 0 && bcs.find(F.attr) == bcs.end())
+        throw std::runtime_error("no boundary condition for attribute " + std::to_string(F.attr));
+
+    const int p_ = d->order;
+    volRule.init(dim, segment_rule(d->int_rule_type, 2 * p_));
+    const int orderW = dim * 1 - 1;  // IsoparametricTransformation::OrderW, Qk order-1 geometry
+    faceRule.init(dim - 1, segment_rule(d->int_rule_type, orderW + 2 * p_));
+
+    // node coordinates (mesh->GetNodes(*coordsDof), src/rhs_operator.cpp:139-142)
+    coords.assign(static_cast<size_t>(ndofs) * dim, 0.0);
+    for (int e = 0; e < ne; e++)
+      for (int k = 0; k < dof; k++) {
+        double xi[3], x[3], J[9];
+        fe.node_ref(k, xi);
+        mesh.transform(e, xi, x, J);
+        for (int dd = 0; dd < dim; dd++) coords[static_cast<size_t>(e) * dof + k + dd * ndofs] = x[dd];
+      }
+
+    assemble();
+    Up.assign(static_cast<size_t>(neq) * ndofs, 0.0);
+    gradUp.assign(static_cast<size_t>(neq) * ndofs * dim, 0.0);
+    z.assign(static_cast<size_t>(neq) * ndofs, 0.0);
+    flux.assign(static_cast<size_t>(neq) * ndofs * dim, 0.0);
+    faceContrib.assign(static_cast<size_t>(neq) * ndofs * dim, 0.0);
+  }
+
+  void assemble() {
+    Ke.resize(ne);
+    MeInv.resize(ne);
+    Aflux.resize(ne);
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < ne; e++) {
+      std::vector<double> shape(dof), dshape(static_cast<size_t>(dof) * dim), dphys(static_cast<size_t>(dof) * dim);
+      Dense K(dof, dim * dof), M(dof, dof), A(dof, dim * dof);
+      for (int q = 0; q < volRule.npts; q++) {
+        const double *xi = &volRule.x[q * dim];
+        double x[3], J[9], Ji[9];
+        mesh.transform(e, xi, x, J);
+        const double det = det_and_inverse(dim, J, Ji);
+        fe.calc_shape(xi, shape.data());
+        fe.calc_dshape(xi, dshape.data());
+        // CalcPhysDShape: dphys(k,d) = sum_m dshape(k,m) Jinv(m,d)
+        for (int k = 0; k < dof; k++)
+          for (int dd = 0; dd < dim; dd++) {
+            double s = 0.0;
+            for (int mm = 0; mm < dim; mm++) s += dshape[k + mm * dof] * Ji[mm + dd * dim];
+            dphys[k + dd * dof] = s;
+          }
+        const double detJac = det * volRule.w[q];
+        // Ke (src/gradients.cpp:104-121)
+        for (int dd = 0; dd < dim; dd++)
+          for (int k = 0; k < dof; k++)
+            for (int j = 0; j < dof; j++) K(j, k + dd * dof) += shape[j] * dphys[k + dd * dof] * detJac;
+        // MassIntegrator at order 2p (src/rhs_operator.cpp:179-185); weight r if axisymmetric (:198-201)
+        const double mw = axisym ? detJac * x[0] : detJac;
+        for (int j = 0; j < dof; j++)
+          for (int k = 0; k < dof; k++) M(k, j) += shape[k] * shape[j] * mw;
+        // DomainIntegrator (src/domain_integrator.cpp:71-97): shape*w (*r), dshapedr * adj(J)
+        double sw = volRule.w[q];
+        if (axisym) sw *= x[0];
+        for (int dd = 0; dd < dim; dd++)
+          for (int j = 0; j < dof; j++) {
+            double dx = 0.0;  // dshapedx(j,dd) = sum_m dshapedr(j,m) adjJ(m,dd), adjJ = det * Jinv
+            for (int mm = 0; mm < dim; mm++) dx += dshape[j + mm * dof] * (det * Ji[mm + dd * dim]);
+            for (int k = 0; k < dof; k++) A(j, k + dd * dof) += shape[k] * sw * dx;
+          }
+      }
+      invert_dense(M);
+      Ke[e] = std::move(K);
+      MeInv[e] = std::move(M);
+      Aflux[e] = std::move(A);
+    }
+    if (axisym) {
+      // the gradient uses the plain (unweighted) inverse mass matrix (src/rhs_operator.cpp:245-246
+      // passes Me_inv); rebuild it separately
+      MeInvGrad.resize(ne);
+#pragma omp parallel for schedule(static)
+      for (int e = 0; e < ne; e++) {
+        std::vector<double> shape(dof);
+        Dense M(dof, dof);
+        for (int q = 0; q < volRule.npts; q++) {
+          const double *xi = &volRule.x[q * dim];
+          double x[3], J[9], Ji[9];
+          mesh.transform(e, xi, x, J);
+          const double det = det_and_inverse(dim, J, Ji);
+          fe.calc_shape(xi, shape.data());
+          const double mw = det * volRule.w[q];
+          for (int j = 0; j < dof; j++)
+            for (int k = 0; k < dof; k++) M(k, j) += shape[k] * shape[j] * mw;
+        }
+        invert_dense(M);
+        MeInvGrad[e] = std::move(M);
+      }
+    }
+  }
+  std::vector<Dense> MeInvGrad;
+  const Dense &gradMassInv(int e) const { return axisym ? MeInvGrad[e] : MeInv[e]; }
+
+  // src/rhs_operator.cpp:642-649
+  void updatePrimitives(const double *x) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < ndofs; i++) {
+      double s[MAXEQ], pr[MAXEQ];
+      for (int eq = 0; eq < neq; eq++) s[eq] = x[i + eq * ndofs];
+      mixture->GetPrimitivesFromConservatives(s, pr);
+      for (int eq = 0; eq < neq; eq++) Up[i + eq * ndofs] = pr[eq];
+    }
+  }
+
+  // per-face geometric data at a face quadrature point
+  struct FacePoint {
+    double xi1[3], xi2[3], x[3], nor[3], w;
+  };
+  void facePoint(const Face &F, int q, FacePoint &fp) const {
+    const double *t = &faceRule.x[q * (dim - 1)];
+    double J[9];
+    mesh.face_ref_point(F.f1, t, fp.xi1);
+    mesh.transform(F.e1, fp.xi1, fp.x, J);
+    mesh.face_normal(F.f1, J, fp.nor);
+    fp.w = faceRule.w[q];
+    if (F.e2 >= 0) {
+      double t2[2] = {0.0, 0.0};
+      Mesh::map_tangent(F, dim, t, t2);
+      mesh.face_ref_point(F.f2, t2, fp.xi2);
+    }
+  }
+
+  // src/gradients.cpp:144-232
+  void computeGradients() {
+    const int64_t N = ndofs;
+    // volume part: gradUp = -(Ke Up)
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < ne; e++) {
+      const Dense &K = Ke[e];
+      for (int eq = 0; eq < neq; eq++)
+        for (int d = 0; d < dim; d++)
+          for (int j = 0; j < dof; j++) {
+            double s = 0.0;
+            for (int k = 0; k < dof; k++) s += K(j, k + d * dof) * Up[static_cast<int64_t>(e) * dof + k + eq * N];
+            gradUp[static_cast<int64_t>(e) * dof + j + eq * N + d * neq * N] = -s;
+          }
+    }
+    // face part (GradFaceIntegrator::AssembleFaceVector, src/faceGradientIntegration.cpp:40-140)
+    std::fill(faceContrib.begin(), faceContrib.end(), 0.0);
+    const int nf = static_cast<int>(mesh.faces.size());
+    std::vector<double> fbuf(static_cast<size_t>(nf) * 2 * dof * neq * dim, 0.0);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int f = 0; f < nf; f++) {
+      const Face &F = mesh.faces[f];
+      std::vector<double> shape1(dof), shape2(dof);
+      double *el1 = &fbuf[static_cast<size_t>(f) * 2 * dof * neq * dim];
+      double *el2 = el1 + static_cast<size_t>(dof) * neq * dim;
+      for (int q = 0; q < faceRule.npts; q++) {
+        FacePoint fp;
+        facePoint(F, q, fp);
+        fe.calc_shape(fp.xi1, shape1.data());
+        double iUp1[MAXEQ], iUp2[MAXEQ], mean[MAXEQ];
+        for (int eq = 0; eq < neq; eq++) {
+          double s = 0.0;
+          for (int k = 0; k < dof; k++) s += Up[static_cast<int64_t>(F.e1) * dof + k + eq * N] * shape1[k];
+          iUp1[eq] = s;
+        }
+        if (F.e2 < 0) {
+          shape2 = shape1;
+          if (disc.use_bc_in_grad) {
+            bcs.at(F.attr)->computeBdrPrimitiveStateForGradient(iUp1, iUp2);
+          } else {
+            for (int eq = 0; eq < neq; eq++) iUp2[eq] = iUp1[eq];
+          }
+        } else {
+          fe.calc_shape(fp.xi2, shape2.data());
+          for (int eq = 0; eq < neq; eq++) {
+            double s = 0.0;
+            for (int k = 0; k < dof; k++) s += Up[static_cast<int64_t>(F.e2) * dof + k + eq * N] * shape2[k];
+            iUp2[eq] = s;
+          }
+        }
+        for (int eq = 0; eq < neq; eq++) mean[eq] = 0.5 * iUp1[eq] + 0.5 * iUp2[eq];
+        double nor[3];
+        for (int d = 0; d < dim; d++) nor[d] = fp.nor[d] * fp.w;
+        for (int d = 0; d < dim; d++)
+          for (int eq = 0; eq < neq; eq++) {
+            const double du1n = (mean[eq] - iUp1[eq]) * nor[d];
+            const double du2n = (iUp2[eq] - mean[eq]) * nor[d];
+            for (int k = 0; k < dof; k++) {
+              el1[k + (eq + d * neq) * dof] += shape1[k] * du1n;
+              el2[k + (eq + d * neq) * dof] += shape2[k] * du2n;
+            }
+          }
+      }
+    }
+    // scatter (ParNonlinearForm::Mult adds elvect of element 1 and, for interior faces, element 2)
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < ne; e++)
+      for (int lf = 0; lf < 2 * dim; lf++) {
+        const int f = mesh.elem_faces[e][lf];
+        const Face &F = mesh.faces[f];
+        const bool first = (F.e1 == e && F.f1 == lf);
+        const double *el = &fbuf[static_cast<size_t>(f) * 2 * dof * neq * dim] +
+                           (first ? 0 : static_cast<size_t>(dof) * neq * dim);
+        for (int d = 0; d < dim; d++)
+          for (int eq = 0; eq < neq; eq++)
+            for (int k = 0; k < dof; k++)
+              faceContrib[static_cast<int64_t>(e) * dof + k + eq * N + d * neq * N] += el[k + (eq + d * neq) * dof];
+      }
+    // inverse mass (src/gradients.cpp:198-229)
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < ne; e++) {
+      const Dense &Mi = gradMassInv(e);
+      std::vector<double> rhs(dof), aux(dof);
+      for (int d = 0; d < dim; d++)
+        for (int eq = 0; eq < neq; eq++) {
+          const int64_t off = static_cast<int64_t>(e) * dof + eq * N + d * neq * N;
+          for (int k = 0; k < dof; k++) rhs[k] = -gradUp[off + k] + faceContrib[off + k];
+          for (int j = 0; j < dof; j++) {
+            double s = 0.0;
+            for (int k = 0; k < dof; k++) s += Mi(j, k) * rhs[k];
+            aux[j] = s;
+          }
+          for (int k = 0; k < dof; k++) gradUp[off + k] = aux[k];
+        }
+    }
+  }
+
+  void interpGrad(int e, const double *shape, double *g) const {
+    const int64_t N = ndofs;
+    for (int eq = 0; eq < neq; eq++)
+      for (int d = 0; d < dim; d++) {
+        double s = 0.0;
+        for (int k = 0; k < dof; k++) s += gradUp[static_cast<int64_t>(e) * dof + k + eq * N + d * neq * N] * shape[k];
+        g[eq + d * neq] = s;
+      }
+  }
+
+  // A->Mult: interior faces (src/face_integrator.cpp:194-352) + boundary (src/BCintegrator.cpp:295-441)
+  void faceFluxes(const double *x, double /*time*/) {
+    const int64_t N = ndofs;
+    const int nf = static_cast<int>(mesh.faces.size());
+    std::vector<double> fbuf(static_cast<size_t>(nf) * 2 * dof * neq, 0.0);
+    const int nAct = mixture->numActiveSpecies;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int f = 0; f < nf; f++) {
+      const Face &F = mesh.faces[f];
+      std::vector<double> shape1(dof), shape2(dof);
+      double *el1 = &fbuf[static_cast<size_t>(f) * 2 * dof * neq];
+      double *el2 = el1 + static_cast<size_t>(dof) * neq;
+      for (int q = 0; q < faceRule.npts; q++) {
+        FacePoint fp;
+        facePoint(F, q, fp);
+        fe.calc_shape(fp.xi1, shape1.data());
+        double u1[MAXEQ], u2[MAXEQ], g1[MAXEQ * MAXDIM], g2[MAXEQ * MAXDIM], fluxN[MAXEQ];
+        for (int eq = 0; eq < neq; eq++) {
+          double s = 0.0;
+          for (int k = 0; k < dof; k++) s += x[static_cast<int64_t>(F.e1) * dof + k + eq * N] * shape1[k];
+          u1[eq] = s;
+        }
+        for (int sp = 0; sp < nAct; sp++) u1[nvel + 2 + sp] = std::max(u1[nvel + 2 + sp], 0.0);
+        interpGrad(F.e1, shape1.data(), g1);
+        double transip[3] = {fp.x[0], fp.x[1], dim == 3 ? fp.x[2] : 0.0};
+        if (F.e2 >= 0) {
+          fe.calc_shape(fp.xi2, shape2.data());
+          for (int eq = 0; eq < neq; eq++) {
+            double s = 0.0;
+            for (int k = 0; k < dof; k++) s += x[static_cast<int64_t>(F.e2) * dof + k + eq * N] * shape2[k];
+            u2[eq] = s;
+          }
+          for (int sp = 0; sp < nAct; sp++) u2[nvel + 2 + sp] = std::max(u2[nvel + 2 + sp], 0.0);
+          interpGrad(F.e2, shape2.data(), g2);
+          rsolver->Eval_LF(u1, u2, fp.nor, fluxN);
+          double v1[MAXEQ * MAXDIM], v2[MAXEQ * MAXDIM];
+          fluxes->ComputeViscousFluxes(u1, g1, transip, 0.0, 0.0, v1);
+          fluxes->ComputeViscousFluxes(u2, g2, transip, 0.0, 0.0, v2);
+          for (int i = 0; i < neq * dim; i++) v1[i] = -0.5 * (v1[i] + v2[i]);
+          for (int eq = 0; eq < neq; eq++)
+            for (int d = 0; d < dim; d++) fluxN[eq] += v1[eq + d * neq] * fp.nor[d];
+          for (int eq = 0; eq < neq; eq++) fluxN[eq] *= fp.w;
+          if (axisym)
+            for (int eq = 0; eq < neq; eq++) fluxN[eq] *= transip[0];
+          for (int eq = 0; eq < neq; eq++)
+            for (int k = 0; k < dof; k++) {
+              el2[k + eq * dof] += shape2[k] * fluxN[eq];
+              el1[k + eq * dof] -= shape1[k] * fluxN[eq];
+            }
+        } else {
+          bcs.at(F.attr)->computeBdrFlux(fp.nor, u1, g1, transip, 0.0, 0.0, fluxN);
+          for (int eq = 0; eq < neq; eq++) fluxN[eq] *= fp.w;
+          if (axisym)
+            for (int eq = 0; eq < neq; eq++) fluxN[eq] *= transip[0];
+          for (int eq = 0; eq < neq; eq++)
+            for (int k = 0; k < dof; k++) el1[k + eq * dof] -= fluxN[eq] * shape1[k];
+        }
+      }
+    }
+    std::fill(z.begin(), z.end(), 0.0);
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < ne; e++)
+      for (int lf = 0; lf < 2 * dim; lf++) {
+        const int f = mesh.elem_faces[e][lf];
+        const Face &F = mesh.faces[f];
+        const bool first = (F.e1 == e && F.f1 == lf);
+        const double *el = &fbuf[static_cast<size_t>(f) * 2 * dof * neq] + (first ? 0 : static_cast<size_t>(dof) * neq);
+        for (int eq = 0; eq < neq; eq++)
+          for (int k = 0; k < dof; k++) z[static_cast<int64_t>(e) * dof + k + eq * N] += el[k + eq * dof];
+      }
+  }
+
+  // src/rhs_operator.cpp:493-559 ; flux(i,d,k) stored [i + d*N + k*N*dim]
+  void getFlux(const double *x) {
+    const int64_t N = ndofs;
+    const int nAct = mixture->numActiveSpecies;
+    double mcs_all = 0.0;
+#pragma omp parallel for schedule(static) reduction(max : mcs_all)
+    for (int64_t i = 0; i < N; i++) {
+      double state[MAXEQ], g[MAXEQ * MAXDIM], f[MAXEQ * MAXDIM], fv[MAXEQ * MAXDIM];
+      for (int k = 0; k < neq; k++) state[k] = x[i + k * N];
+      for (int sp = 0; sp < nAct; sp++) state[nvel + 2 + sp] = std::max(state[nvel + 2 + sp], 0.0);
+      for (int eq = 0; eq < neq; eq++)
+        for (int d = 0; d < dim; d++) g[eq + d * neq] = gradUp[i + eq * N + d * neq * N];
+      double xyz[3] = {0, 0, 0};
+      for (int d = 0; d < dim; d++) xyz[d] = coords[i + d * N];
+      fluxes->ComputeConvectiveFluxes(state, f);
+      if (phys.eq_system != TPSRHS_EULER) {
+        fluxes->ComputeViscousFluxes(state, g, xyz, 0.0, 0.0, fv);
+        for (int k = 0; k < neq * dim; k++) f[k] -= fv[k];
+      }
+      for (int d = 0; d < dim; d++)
+        for (int k = 0; k < neq; k++) flux[i + d * N + k * N * dim] = f[k + d * neq];
+      const double mcs = mixture->ComputeMaxCharSpeed(state);
+      if (mcs > mcs_all) mcs_all = mcs;
+    }
+    max_char_speed = mcs_all;
+  }
+
+  void mult(const double *x, double *y, double time) {
+    const int64_t N = ndofs;
+    max_char_speed = 0.0;
+    updatePrimitives(x);
+    computeGradients();
+    faceFluxes(x, time);
+    getFlux(x);
+    // for eq: Aflux->AddMult(flux(eq), z(eq))  (src/rhs_operator.cpp:379-391)
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < ne; e++) {
+      const Dense &A = Aflux[e];
+      for (int eq = 0; eq < neq; eq++)
+        for (int j = 0; j < dof; j++) {
+          double s = 0.0;
+          for (int d = 0; d < dim; d++)
+            for (int k = 0; k < dof; k++)
+              s += A(j, k + d * dof) * flux[static_cast<int64_t>(e) * dof + k + d * N + eq * N * dim];
+          z[static_cast<int64_t>(e) * dof + j + eq * N] += s;
+        }
+    }
+    // inverse mass (src/rhs_operator.cpp:432-448)
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < ne; e++) {
+      const Dense &Mi = MeInv[e];
+      for (int eq = 0; eq < neq; eq++)
+        for (int j = 0; j < dof; j++) {
+          double s = 0.0;
+          for (int k = 0; k < dof; k++) s += Mi(j, k) * z[static_cast<int64_t>(e) * dof + k + eq * N];
+          y[static_cast<int64_t>(e) * dof + j + eq * N] = s;
+        }
+    }
+    // forcing terms (src/rhs_operator.cpp:451-461)
+    if (source) source->updateTerms(x, Up.data(), gradUp.data(), ndofs, y);
+    if (axisym) axisymmetricSource(x, y);
+  }
+
+  // AxisymmetricSource::updateTerms, src/forcing_terms.cpp:255-382 (CPU branch)
+  void axisymmetricSource(const double *x, double *y);
+
+  // L2 norm of a nodal field difference (exact mass; stands in for GridFunction::ComputeLpError)
+  double l2_norm(const double *a, const double *b) const {
+    RuleND rule;
+    rule.init(dim, gauss_legendre(fe.p + 3));
+    double tot = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : tot)
+    for (int e = 0; e < ne; e++) {
+      std::vector<double> shape(dof);
+      for (int q = 0; q < rule.npts; q++) {
+        const double *xi = &rule.x[q * dim];
+        double x[3], J[9], Ji[9];
+        mesh.transform(e, xi, x, J);
+        const double det = det_and_inverse(dim, J, Ji);
+        fe.calc_shape(xi, shape.data());
+        double v = 0.0;
+        for (int k = 0; k < dof; k++) {
+          const int64_t n = static_cast<int64_t>(e) * dof + k;
+          v += shape[k] * (a[n] - (b ? b[n] : 0.0));
+        }
+        tot += v * v * det * rule.w[q];
+      }
+    }
+    return std::sqrt(tot);
+  }
+};
+
+void Operator::axisymmetricSource(const double *x, double *y) {
+  const int64_t N = ndofs;
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < N; n++) {
+    double U[MAXEQ], prim[MAXEQ], g[MAXEQ * MAXDIM];
+    for (int eq = 0; eq < neq; eq++) {
+      U[eq] = x[n + eq * N];
+      prim[eq] = Up[n + eq * N];
+      for (int d = 0; d < dim; d++) g[eq + d * neq] = gradUp[n + eq * N + d * neq * N];
+    }
+    axisym_source_point(*mixture, *transport, phys.eq_system, neq, dim, coords[n + 0 * N], U, prim, g, n, N, y);
+  }
+}
+
+}  // namespace tpsoracle
+
+// --------------------------------------------------------------------------------------------
+// C entry points (ctypes)
+// --------------------------------------------------------------------------------------------
+using tpsoracle::Operator;
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *tpsoracle_last_error() { return g_err.c_str(); }
+
+int tpsoracle_create(const tpsrhs_mesh *mesh, const tpsrhs_disc *disc, const tpsrhs_physics *phys, int nbc,
+                     const tpsrhs_bc *bcs, void **out) {
+  try {
+    Operator *op = new Operator();
+    op->setup(mesh, disc, phys, nbc, bcs);
+    *out = op;
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+int tpsoracle_destroy(void *h) {
+  delete static_cast<Operator *>(h);
+  return 0;
+}
+int64_t tpsoracle_num_dofs(void *h) { return static_cast<Operator *>(h)->ndofs; }
+int tpsoracle_num_equation(void *h) { return static_cast<Operator *>(h)->neq; }
+int tpsoracle_set_threads(int n) {
+  omp_set_num_threads(n);
+  return omp_get_max_threads();
+}
+int tpsoracle_mult(void *h, const double *x, double *y, double time, double *max_char_speed) {
+  try {
+    Operator *op = static_cast<Operator *>(h);
+    op->mult(x, y, time);
+    if (max_char_speed) *max_char_speed = op->max_char_speed;
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+// Gradients::computeGradients on a caller-supplied primitive field (test/test_gradient.cpp:161-162)
+int tpsoracle_compute_gradients(void *h, const double *up_in) {
+  try {
+    Operator *op = static_cast<Operator *>(h);
+    if (up_in) std::memcpy(op->Up.data(), up_in, op->Up.size() * sizeof(double));
+    op->computeGradients();
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+int tpsoracle_update_primitives(void *h, const double *x) {
+  static_cast<Operator *>(h)->updatePrimitives(x);
+  return 0;
+}
+int tpsoracle_get_primitives(void *h, double *out) {
+  Operator *op = static_cast<Operator *>(h);
+  std::memcpy(out, op->Up.data(), op->Up.size() * sizeof(double));
+  return 0;
+}
+int tpsoracle_get_gradients(void *h, double *out) {
+  Operator *op = static_cast<Operator *>(h);
+  std::memcpy(out, op->gradUp.data(), op->gradUp.size() * sizeof(double));
+  return 0;
+}
+int tpsoracle_node_coords(void *h, double *out) {
+  Operator *op = static_cast<Operator *>(h);
+  std::memcpy(out, op->coords.data(), op->coords.size() * sizeof(double));
+  return 0;
+}
+double tpsoracle_l2_norm(void *h, const double *a, const double *b) { return static_cast<Operator *>(h)->l2_norm(a, b); }
+// sum_e 1^T M_e y_e for one scalar field (discrete conservation checks)
+double tpsoracle_integral(void *h, const double *a) {
+  Operator *op = static_cast<Operator *>(h);
+  tpsoracle::RuleND rule;
+  rule.init(op->dim, tpsoracle::gauss_legendre(op->fe.p + 2));
+  double tot = 0.0;
+  std::vector<double> shape(op->dof);
+  for (int e = 0; e < op->ne; e++)
+    for (int q = 0; q < rule.npts; q++) {
+      const double *xi = &rule.x[q * op->dim];
+      double x[3], J[9], Ji[9];
+      op->mesh.transform(e, xi, x, J);
+      const double det = tpsoracle::det_and_inverse(op->dim, J, Ji);
+      op->fe.calc_shape(xi, shape.data());
+      double v = 0.0;
+      for (int k = 0; k < op->dof; k++) v += shape[k] * a[static_cast<int64_t>(e) * op->dof + k];
+      tot += v * det * rule.w[q] * (op->axisym ? x[0] : 1.0);
+    }
+  return tot;
+}
+
+// ---- point-wise entry points for unit tests (tests/test_oracle_physics.py) -------------------
+int tpsoracle_point_prim(void *h, const double *state, double *prim) {
+  static_cast<Operator *>(h)->mixture->GetPrimitivesFromConservatives(state, prim);
+  return 0;
+}
+int tpsoracle_point_cons(void *h, const double *prim, double *state) {
+  static_cast<Operator *>(h)->mixture->GetConservativesFromPrimitives(prim, state);
+  return 0;
+}
+double tpsoracle_point_pressure(void *h, const double *state) {
+  return static_cast<Operator *>(h)->mixture->ComputePressure(state);
+}
+double tpsoracle_point_max_char_speed(void *h, const double *state) {
+  return static_cast<Operator *>(h)->mixture->ComputeMaxCharSpeed(state);
+}
+int tpsoracle_point_convective_flux(void *h, const double *state, double *flux) {
+  static_cast<Operator *>(h)->fluxes->ComputeConvectiveFluxes(state, flux);
+  return 0;
+}
+int tpsoracle_point_viscous_flux(void *h, const double *state, const double *gradUp, double radius, double *flux) {
+  double transip[3] = {radius, 0, 0};
+  static_cast<Operator *>(h)->fluxes->ComputeViscousFluxes(state, gradUp, transip, 0.0, 0.0, flux);
+  return 0;
+}
+int tpsoracle_point_bdr_viscous_flux(void *h, const double *state, const double *gradUp, double radius,
+                                     const double *normal, const double *primFlux, const int *primFluxIdxs,
+                                     double *normalFlux) {
+  Operator *op = static_cast<Operator *>(h);
+  tpsoracle::BoundaryViscousFluxData bc;
+  for (int d = 0; d < 3; d++) bc.normal[d] = d < op->dim ? normal[d] : 0.0;
+  for (int i = 0; i < tpsoracle::MAXEQ; i++) {
+    bc.primFlux[i] = primFlux ? primFlux[i] : 0.0;
+    bc.primFluxIdxs[i] = primFluxIdxs ? primFluxIdxs[i] != 0 : false;
+  }
+  double transip[3] = {radius, 0, 0};
+  op->fluxes->ComputeBdrViscousFluxes(state, gradUp, transip, 0.0, 0.0, bc, normalFlux);
+  return 0;
+}
+int tpsoracle_point_lf(void *h, const double *s1, const double *s2, const double *nor, double *flux) {
+  static_cast<Operator *>(h)->rsolver->Eval_LF(s1, s2, nor, flux);
+  return 0;
+}
+int tpsoracle_point_bdr_flux(void *h, int attr, const double *nor, const double *state, const double *gradUp,
+                             double radius, double *flux) {
+  try {
+    double transip[3] = {radius, 0, 0};
+    static_cast<Operator *>(h)->bcs.at(attr)->computeBdrFlux(nor, state, gradUp, transip, 0.0, 0.0, flux);
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+int tpsoracle_point_flux_transport(void *h, const double *state, const double *gradUp, double *buffer4,
+                                   double *diffVel) {
+  Operator *op = static_cast<Operator *>(h);
+  double E[3] = {0, 0, 0};
+  op->transport->ComputeFluxTransportProperties(state, gradUp, E, -1.0, 0.0, buffer4, diffVel);
+  return 0;
+}
+int tpsoracle_point_source(void *h, const double *state, const double *prim, const double *gradUp, double *src) {
+  Operator *op = static_cast<Operator *>(h);
+  if (!op->source) return 1;
+  op->source->point(state, prim, gradUp, src);
+  return 0;
+}
+}

@@ -1,0 +1,199 @@
+"""Loader of the CPU oracle (test infrastructure).  Imported by tests/, smoke() and bench.py's
+cpu_baseline leg only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from tps_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libtpsoracle.so")
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        L = C.CDLL(ORACLE_SO)
+        vp = C.c_void_p
+        L.tpsoracle_create.argtypes = [C.POINTER(capi.Mesh), C.POINTER(capi.Disc), C.POINTER(capi.Physics), C.c_int,
+                                       C.POINTER(capi.BC), C.POINTER(vp)]
+        L.tpsoracle_last_error.restype = C.c_char_p
+        L.tpsoracle_num_dofs.restype = C.c_int64
+        L.tpsoracle_num_dofs.argtypes = [vp]
+        L.tpsoracle_num_equation.argtypes = [vp]
+        L.tpsoracle_destroy.argtypes = [vp]
+        L.tpsoracle_mult.argtypes = [vp, _dp, _dp, C.c_double, _dp]
+        L.tpsoracle_compute_gradients.argtypes = [vp, _dp]
+        L.tpsoracle_update_primitives.argtypes = [vp, _dp]
+        L.tpsoracle_get_primitives.argtypes = [vp, _dp]
+        L.tpsoracle_get_gradients.argtypes = [vp, _dp]
+        L.tpsoracle_node_coords.argtypes = [vp, _dp]
+        L.tpsoracle_l2_norm.restype = C.c_double
+        L.tpsoracle_l2_norm.argtypes = [vp, _dp, _dp]
+        L.tpsoracle_integral.restype = C.c_double
+        L.tpsoracle_integral.argtypes = [vp, _dp]
+        L.tpsoracle_point_pressure.restype = C.c_double
+        L.tpsoracle_point_max_char_speed.restype = C.c_double
+        for name in ("tpsoracle_point_prim", "tpsoracle_point_cons", "tpsoracle_point_convective_flux"):
+            getattr(L, name).argtypes = [vp, _dp, _dp]
+        L.tpsoracle_point_pressure.argtypes = [vp, _dp]
+        L.tpsoracle_point_max_char_speed.argtypes = [vp, _dp]
+        L.tpsoracle_point_viscous_flux.argtypes = [vp, _dp, _dp, C.c_double, _dp]
+        L.tpsoracle_point_bdr_viscous_flux.argtypes = [vp, _dp, _dp, C.c_double, _dp, _dp, C.POINTER(C.c_int), _dp]
+        L.tpsoracle_point_lf.argtypes = [vp, _dp, _dp, _dp, _dp]
+        L.tpsoracle_point_bdr_flux.argtypes = [vp, C.c_int, _dp, _dp, _dp, C.c_double, _dp]
+        L.tpsoracle_point_flux_transport.argtypes = [vp, _dp, _dp, _dp, _dp]
+        L.tpsoracle_point_source.argtypes = [vp, _dp, _dp, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Oracle:
+    """CPU restatement of RHSoperator (oracle/tps_oracle.cpp)."""
+
+    def __init__(self, host_mesh, disc, physics, bcs=(), threads=None):
+        L = lib()
+        if threads is not None:
+            L.tpsoracle_set_threads(int(threads))
+        self._margs = capi.MeshArgs(host_mesh)
+        self.disc, self.physics = disc, physics
+        self._bcs = (capi.BC * max(1, len(bcs)))(*bcs)
+        h = C.c_void_p()
+        st = L.tpsoracle_create(C.byref(self._margs.c), C.byref(disc), C.byref(physics), len(bcs), self._bcs,
+                                C.byref(h))
+        if st != 0:
+            raise RuntimeError("oracle: " + L.tpsoracle_last_error().decode())
+        self.h = h
+        self.dim = host_mesh.dim
+        self.ndofs = int(L.tpsoracle_num_dofs(h))
+        self.neq = int(L.tpsoracle_num_equation(h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().tpsoracle_destroy(self.h)
+            self.h = None
+
+    def node_coords(self):
+        out = np.zeros((self.dim, self.ndofs))
+        lib().tpsoracle_node_coords(self.h, _p(out))
+        return out
+
+    def mult(self, x, time=0.0):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        mcs = C.c_double(0.0)
+        st = lib().tpsoracle_mult(self.h, _p(x), _p(y), float(time), C.byref(mcs))
+        if st != 0:
+            raise RuntimeError("oracle: " + lib().tpsoracle_last_error().decode())
+        self.max_char_speed = mcs.value
+        return y
+
+    def compute_gradients(self, up=None):
+        if up is not None:
+            up = np.ascontiguousarray(up, dtype=np.float64)
+        st = lib().tpsoracle_compute_gradients(self.h, _p(up) if up is not None else None)
+        if st != 0:
+            raise RuntimeError("oracle: " + lib().tpsoracle_last_error().decode())
+        return self.gradients()
+
+    def primitives(self):
+        out = np.zeros((self.neq, self.ndofs))
+        lib().tpsoracle_get_primitives(self.h, _p(out))
+        return out
+
+    def gradients(self):
+        out = np.zeros((self.dim, self.neq, self.ndofs))
+        lib().tpsoracle_get_gradients(self.h, _p(out))
+        return out
+
+    def l2_norm(self, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.float64)
+        return lib().tpsoracle_l2_norm(self.h, _p(a), _p(b) if b is not None else None)
+
+    def integral(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return lib().tpsoracle_integral(self.h, _p(a))
+
+    # ---- point-wise ----
+    def prim(self, state):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        out = np.zeros(self.neq)
+        lib().tpsoracle_point_prim(self.h, _p(s), _p(out))
+        return out
+
+    def cons(self, prim):
+        s = np.ascontiguousarray(prim, dtype=np.float64)
+        out = np.zeros(self.neq)
+        lib().tpsoracle_point_cons(self.h, _p(s), _p(out))
+        return out
+
+    def pressure(self, state):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        return lib().tpsoracle_point_pressure(self.h, _p(s))
+
+    def max_char_speed_point(self, state):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        return lib().tpsoracle_point_max_char_speed(self.h, _p(s))
+
+    def convective_flux(self, state):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        out = np.zeros(self.neq * self.dim)
+        lib().tpsoracle_point_convective_flux(self.h, _p(s), _p(out))
+        return out.reshape(self.dim, self.neq)
+
+    def viscous_flux(self, state, grad, radius=-1.0):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        g = np.ascontiguousarray(grad, dtype=np.float64)  # (dim, neq): gradUp[eq + d*neq]
+        out = np.zeros(self.neq * self.dim)
+        lib().tpsoracle_point_viscous_flux(self.h, _p(s), _p(g), float(radius), _p(out))
+        return out.reshape(self.dim, self.neq)
+
+    def bdr_viscous_flux(self, state, grad, normal, prim_flux=None, prim_flux_idxs=None, radius=-1.0):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        g = np.ascontiguousarray(grad, dtype=np.float64)
+        n = np.zeros(3)
+        n[: len(normal)] = normal
+        pf = np.zeros(capi.MAXEQUATIONS) if prim_flux is None else np.ascontiguousarray(prim_flux, dtype=np.float64)
+        pi = np.zeros(capi.MAXEQUATIONS, dtype=np.int32) if prim_flux_idxs is None else np.ascontiguousarray(
+            prim_flux_idxs, dtype=np.int32)
+        out = np.zeros(self.neq)
+        lib().tpsoracle_point_bdr_viscous_flux(self.h, _p(s), _p(g), float(radius), _p(n), _p(pf),
+                                               pi.ctypes.data_as(C.POINTER(C.c_int)), _p(out))
+        return out
+
+    def lf(self, s1, s2, nor):
+        s1 = np.ascontiguousarray(s1, dtype=np.float64)
+        s2 = np.ascontiguousarray(s2, dtype=np.float64)
+        n = np.zeros(3)
+        n[: len(nor)] = nor
+        out = np.zeros(self.neq)
+        lib().tpsoracle_point_lf(self.h, _p(s1), _p(s2), _p(n), _p(out))
+        return out
+
+    def bdr_flux(self, attr, nor, state, grad, radius=-1.0):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        g = np.ascontiguousarray(grad, dtype=np.float64)
+        n = np.zeros(3)
+        n[: len(nor)] = nor
+        out = np.zeros(self.neq)
+        st = lib().tpsoracle_point_bdr_flux(self.h, int(attr), _p(n), _p(s), _p(g), float(radius), _p(out))
+        if st != 0:
+            raise RuntimeError("oracle: " + lib().tpsoracle_last_error().decode())
+        return out
