@@ -597,7 +597,10 @@ class BoundaryCondition {
   }
 
   void computeBdrFlux(const double *normal, const double *stateIn, const double *gradState, const double *transip,
-                      double delta, double distance, double *bdrFlux) {
+                      double delta, double distance, double *bdrFlux) const {
+    // the reference stores the unit normal in the member bcFlux_ (src/wallBC.cpp:448,492); the
+    // oracle's face loop is threaded, so each call works on its own copy
+    BoundaryViscousFluxData bcFlux = this->bcFlux;
     if (category == TPSRHS_INLET) {  // src/inletBC.cpp:729-757
       const double p = mixture->ComputePressure(stateIn);
       double state2[MAXEQ];

@@ -1,0 +1,321 @@
+// Device point-wise physics, dry air (gamma-law gas, Sutherland viscosity).
+//
+// Flattened restatement of the reference's virtual hierarchy for WorkingFluid::DRY_AIR:
+//   DryAir                 src/equation_of_state.cpp:146-412, src/equation_of_state.hpp:605-628
+//   DryAirTransport        src/transport_properties.cpp:205-266
+//   Fluxes                 src/fluxes.cpp:135-170 (convective), :178-335 (viscous), :344-505 (boundary)
+//   RiemannSolverTPS       src/riemann_solver.cpp:53-115 (Lax-Friedrichs)
+//   Inlet/Outlet/WallBC    src/inletBC.cpp:729-757, src/outletBC.cpp:731-737, src/wallBC.cpp:277-510
+// The pressure / temperature / viscosity of a state are computed once per point and reused
+// (the reference recomputes them in every call, src/fluxes.hpp:59-64).
+#ifndef TPSRHS_PHYSICS_DRYAIR_HPP_
+#define TPSRHS_PHYSICS_DRYAIR_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/tpsrhs.h"
+
+namespace tpsrhs {
+
+struct BcDev {
+  int category, type;
+  double data[4 + TPSRHS_MAXSPECIES];
+};
+constexpr int MAXBC = 16;
+
+struct DryAirParams {
+  double gamma, Rg, visc_mult, bulk_mult, C1, S0, cp_div_pr;
+  int eq_system;  // tpsrhs_equations
+  int use_bc_in_grad;
+  int num_bcs;
+  BcDev bc[MAXBC];
+};
+
+template <int DIM_>
+struct DryAirPhys {
+  static constexpr int DIM = DIM_;
+  static constexpr int NVEL = DIM_;
+  static constexpr int NEQ = DIM_ + 2;
+  static constexpr int NACTIVE = 0;
+  static constexpr bool HAS_SOURCE = false;
+  typedef DryAirParams Params;
+
+  __device__ static inline double pressure(const Params &p, const double *U) {
+    double k = 0.0;
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) k += U[1 + d] * U[1 + d];
+    k /= U[0];
+    return (p.gamma - 1.0) * (U[1 + NVEL] - 0.5 * k);
+  }
+
+  // GetPrimitivesFromConservatives, src/equation_of_state.cpp:321-335
+  __device__ static inline void prim(const Params &p, const double *U, double *Up) {
+    double k = 0.0;
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) k += U[1 + d] * U[1 + d];
+    k /= U[0];
+    const double T = (p.gamma - 1.0) / p.Rg * (U[1 + NVEL] - 0.5 * k) / U[0];
+    Up[0] = U[0];
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) Up[1 + d] = U[1 + d] / U[0];
+    Up[1 + NVEL] = T;
+  }
+
+  __device__ static inline void clamp_species(double *) {}
+
+  // ComputeMaxCharSpeed, src/equation_of_state.cpp:278-292
+  __device__ static inline double max_char_speed(const Params &p, const double *U) {
+    double k = 0.0;
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) k += U[1 + d] * U[1 + d];
+    k /= U[0];
+    const double pres = (p.gamma - 1.0) * (U[1 + NVEL] - 0.5 * k);
+    return sqrt(k / U[0]) + sqrt(p.gamma * pres / U[0]);
+  }
+
+  // F(U).n, src/fluxes.cpp:135-170 contracted with n as in RiemannSolverTPS::ComputeFluxDotN
+  __device__ static inline void conv_flux_n(const Params &p, const double *U, const double *n, double *Fn) {
+    const double pres = pressure(p, U);
+    double mn = 0.0;  // rho u . n
+#pragma unroll
+    for (int d = 0; d < DIM; d++) mn += U[1 + d] * n[d];
+    const double un = mn / U[0];
+    Fn[0] = mn;
+#pragma unroll
+    for (int i = 0; i < NVEL; i++) Fn[1 + i] = U[1 + i] * un + (i < DIM ? pres * n[i] : 0.0);
+    Fn[1 + NVEL] = un * (U[1 + NVEL] + pres);
+  }
+
+  // full convective flux tensor F[eq + d*NEQ]
+  __device__ static inline void conv_flux(const Params &p, const double *U, double *F) {
+    const double pres = pressure(p, U);
+    const double H = (U[1 + NVEL] + pres) / U[0];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      F[0 + d * NEQ] = U[1 + d];
+#pragma unroll
+      for (int i = 0; i < NVEL; i++) F[1 + i + d * NEQ] = U[1 + i] * U[1 + d] / U[0];
+      F[1 + d + d * NEQ] += pres;
+      F[1 + NVEL + d * NEQ] = U[1 + d] * H;
+    }
+  }
+
+  // Lax-Friedrichs flux with the area-weighted normal, src/riemann_solver.cpp:89-115
+  __device__ static inline void lax_friedrichs(const Params &p, const double *U1, const double *U2, const double *n,
+                                               double *F) {
+    const double l1 = max_char_speed(p, U1), l2 = max_char_speed(p, U2);
+    const double lam = fmax(l1, l2);
+    double f1[NEQ], f2[NEQ];
+    conv_flux_n(p, U1, n, f1);
+    conv_flux_n(p, U2, n, f2);
+    double nm = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
+    nm = sqrt(nm);
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) F[eq] = 0.5 * (f1[eq] + f2[eq]) - 0.5 * lam * (U2[eq] - U1[eq]) * nm;
+  }
+
+  struct Transport {
+    double visc, bulk, k;  // bulk already has -2/3 visc applied
+  };
+  // DryAirTransport::ComputeFluxMolecularTransport, src/transport_properties.cpp:224-266
+  __device__ static inline Transport transport(const Params &p, const double *U) {
+    const double pres = pressure(p, U);
+    const double T = pres / p.Rg / U[0];
+    Transport t;
+    t.visc = p.C1 * p.visc_mult * (T * sqrt(T)) / (T + p.S0);
+    t.bulk = p.bulk_mult * t.visc - 2.0 / 3.0 * t.visc;
+    t.k = p.cp_div_pr * t.visc;
+    return t;
+  }
+
+  // ComputeViscousFluxes, src/fluxes.cpp:178-335; g[eq + d*NEQ] = d(Up_eq)/dx_d; F[eq + d*NEQ]
+  __device__ static inline void visc_flux(const Params &p, const double *U, const double *g, double *F) {
+#pragma unroll
+    for (int i = 0; i < NEQ * DIM; i++) F[i] = 0.0;
+    if (p.eq_system == TPSRHS_EULER) return;
+    const Transport t = transport(p, U);
+    double divV = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
+    double stress[DIM * DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; i++)
+#pragma unroll
+      for (int j = 0; j < DIM; j++) stress[i + j * DIM] = t.visc * (g[(1 + j) + i * NEQ] + g[(1 + i) + j * NEQ]);
+#pragma unroll
+    for (int i = 0; i < DIM; i++) stress[i + i * DIM] += t.bulk * divV;
+#pragma unroll
+    for (int i = 0; i < DIM; i++)
+#pragma unroll
+      for (int j = 0; j < DIM; j++) F[(1 + i) + j * NEQ] = stress[i + j * DIM];
+    double vel[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) vel[d] = U[1 + d] / U[0];
+#pragma unroll
+    for (int i = 0; i < DIM; i++) {
+      double vt = 0.0;
+#pragma unroll
+      for (int j = 0; j < DIM; j++) vt += stress[i + j * DIM] * vel[j];
+      F[(1 + NVEL) + i * NEQ] = vt + t.k * g[(1 + NVEL) + i * NEQ];
+    }
+  }
+
+  // F_v(U, g) . n
+  __device__ static inline void visc_flux_n(const Params &p, const double *U, const double *g, const double *n,
+                                            double *Fn) {
+    double F[NEQ * DIM];
+    visc_flux(p, U, g, F);
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) {
+      double s = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) s += F[eq + d * NEQ] * n[d];
+      Fn[eq] = s;
+    }
+  }
+
+  // ComputeBdrViscousFluxes with zero prescribed species flux and, when `adiabatic`, zero heat
+  // flux (src/fluxes.cpp:344-505 with the bcFlux_ of src/wallBC.cpp:86-111); nu = unit normal
+  __device__ static inline void bdr_visc_flux(const Params &p, const double *Uw, const double *g, const double *nu,
+                                              bool adiabatic, double *Fn) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) Fn[eq] = 0.0;
+    if (p.eq_system == TPSRHS_EULER) return;
+    const Transport t = transport(p, Uw);
+    double divV = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
+    double sn[DIM];  // stress . n
+#pragma unroll
+    for (int i = 0; i < DIM; i++) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < DIM; j++) {
+        double st = t.visc * (g[(1 + j) + i * NEQ] + g[(1 + i) + j * NEQ]);
+        if (i == j) st += t.bulk * divV;
+        s += st * nu[j];
+      }
+      sn[i] = s;
+    }
+    double q = 0.0;  // heat flux (standard sign): -k dT/dn
+    if (!adiabatic) {
+#pragma unroll
+      for (int d = 0; d < DIM; d++) q -= t.k * g[(1 + NVEL) + d * NEQ] * nu[d];
+    }
+    double e = -q;
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) {
+      Fn[1 + d] = sn[d];
+      e += sn[d] * (Uw[1 + d] / Uw[0]);
+    }
+    Fn[1 + NVEL] = e;
+  }
+
+  // ---- boundary conditions ------------------------------------------------------------------
+  // ghost (second) state handed to the Riemann solver
+  __device__ static inline void bc_ghost(const Params &p, const BcDev &bc, const double *U, const double *n,
+                                         double *Ug) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) Ug[eq] = U[eq];
+    if (bc.category == TPSRHS_INLET) {  // SUB_DENS_VEL, src/inletBC.cpp:729-757
+      const double pres = pressure(p, U);
+      Ug[0] = bc.data[0];
+      double k = 0.0;
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) {
+        Ug[1 + d] = bc.data[0] * bc.data[1 + d];
+        k += Ug[1 + d] * Ug[1 + d];
+      }
+      k *= 0.5 / Ug[0];
+      Ug[1 + NVEL] = pres / (p.gamma - 1.0) + k;  // modifyEnergyForPressure, :402-411
+    } else if (bc.category == TPSRHS_OUTLET) {  // SUB_P, src/outletBC.cpp:731-737
+      double k = 0.0;
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) k += U[1 + d] * U[1 + d];
+      k *= 0.5 / U[0];
+      Ug[1 + NVEL] = bc.data[0] / (p.gamma - 1.0) + k;
+    } else if (bc.type == TPSRHS_INV) {  // mirrored normal momentum, src/wallBC.cpp:277-301
+      double nm = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
+      nm = sqrt(nm);
+      double vn = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) vn += (U[1 + d] / U[0]) * (n[d] / nm);
+#pragma unroll
+      for (int d = 0; d < DIM; d++) Ug[1 + d] = U[0] * (U[1 + d] / U[0] - 2.0 * vn * (n[d] / nm));
+    } else if (bc.type == TPSRHS_VISC_ADIAB) {  // computeStagnationState, :367-378
+      const double pres = pressure(p, U);
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) Ug[1 + d] = 0.0;
+      Ug[1 + NVEL] = pres / (p.gamma - 1.0);
+    } else {  // VISC_ISOTH, src/wallBC.cpp:471-485
+      if (p.use_bc_in_grad) {
+#pragma unroll
+        for (int d = 0; d < NVEL; d++) Ug[1 + d] = -U[1 + d];
+      } else {
+#pragma unroll
+        for (int d = 0; d < NVEL; d++) Ug[1 + d] = 0.0;
+        Ug[1 + NVEL] = p.Rg / (p.gamma - 1.0) * U[0] * bc.data[0];  // computeStagnantStateWithTemp, :380-387
+      }
+    }
+  }
+
+  // additive viscous part of the boundary flux: what the wall routines subtract from bdrFlux
+  // after the Riemann solve (src/wallBC.cpp:303-319, 439-468, 487-509); zero for inlet/outlet
+  __device__ static inline void bc_visc_term(const Params &p, const BcDev &bc, const double *U, const double *g,
+                                             const double *n, double *out) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) out[eq] = 0.0;
+    if (bc.category != TPSRHS_WALL || p.eq_system == TPSRHS_EULER) return;
+    double nm = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
+    nm = sqrt(nm);
+    double fin[NEQ];
+    visc_flux_n(p, U, g, n, fin);
+    double fw[NEQ];
+    if (bc.type == TPSRHS_INV) {
+      double Ug[NEQ];
+      bc_ghost(p, bc, U, n, Ug);
+      visc_flux_n(p, Ug, g, n, fw);
+    } else {
+      double Uw[NEQ], nu[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) nu[d] = n[d] / nm;
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) Uw[eq] = U[eq];
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) Uw[1 + d] = 0.0;
+      if (bc.type == TPSRHS_VISC_ADIAB) {
+        Uw[1 + NVEL] = pressure(p, U) / (p.gamma - 1.0);
+        bdr_visc_flux(p, Uw, g, nu, true, fw);
+      } else {
+        Uw[1 + NVEL] = p.Rg / (p.gamma - 1.0) * U[0] * bc.data[0];
+        bdr_visc_flux(p, Uw, g, nu, false, fw);
+      }
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) fw[eq] *= nm;
+    }
+#pragma unroll
+    for (int eq = 1; eq < NEQ; eq++) out[eq] = -0.5 * fw[eq] - 0.5 * fin[eq];
+  }
+
+  // ghost primitive state of the gradient jump (useBCinGrad), src/wallBC.cpp:241-266
+  __device__ static inline void bc_grad_prim(const Params &p, const BcDev &bc, const double *Up, double *UpB) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) UpB[eq] = Up[eq];
+    if (p.use_bc_in_grad && bc.category == TPSRHS_WALL && bc.type == TPSRHS_VISC_ISOTH) {
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) UpB[1 + d] = 0.0;
+      UpB[1 + NVEL] = bc.data[0];
+    }
+  }
+
+  __device__ static inline void source(const Params &, const double *, const double *, const double *, double *) {}
+};
+
+}  // namespace tpsrhs
+#endif

@@ -1,0 +1,166 @@
+"""Python image of the reference's ``RHSoperator`` (``src/rhs_operator.hpp:59-235``) over the C ABI.
+
+The class keeps the reference's method names and argument meaning -- ``Mult(x, y)``,
+``updatePrimitives``/``updateGradients``, ``getGradients`` -- so that tests read like
+``utils/compute_rhs.cpp:60-102`` and ``test/test_gradient.cpp:159-162``.  ``x`` and ``y`` are
+torch CUDA tensors (float64, ``num_equation * NDofs``, byNODES); torch is used only to own device
+memory and streams.  Everything is computed by ``libtpsrhs.so``; a missing library or a missing
+GPU raises -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+class TpsRhsError(RuntimeError):
+    def __init__(self, status, where):
+        lib = capi.load()
+        self.status = status
+        msg = lib.tpsrhs_last_error().decode()
+        super().__init__(f"{where}: {lib.tpsrhs_status_string(status).decode()}: {msg}")
+
+
+class RHSoperator:
+    """``RHSoperator : mfem::TimeDependentOperator`` -- one instance per rank / per GPU.
+
+    Parameters mirror what ``M2ulPhyS::initVariables`` hands the reference constructor
+    (``src/M2ulPhyS.cpp:745-749``): the (local) mesh, the discretisation, the physics parameter
+    blocks, the boundary conditions.  ``halo`` is the neighbour-exchange hook used on partitioned
+    meshes (see :mod:`tps_amd.halo`).
+    """
+
+    def __init__(self, host_mesh, disc, physics, bcs=(), device=0, halo=None, stream=None):
+        self._lib = capi.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("tps_amd.RHSoperator needs a HIP device (torch.cuda.is_available() is False)")
+        self.device = torch.device("cuda", device)
+        self._margs = capi.MeshArgs(host_mesh)
+        self._disc, self._physics = disc, physics
+        self._bcs = (capi.BC * max(1, len(bcs)))(*bcs)
+        rt = capi.Runtime()
+        rt.device = device
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._stream = st
+        rt.stream = C.c_void_p(st.cuda_stream)
+        self._halo = halo
+        if halo is not None:
+            self._halo_cb = capi.HALO_FN(halo.callback)
+            rt.halo = self._halo_cb
+        self._rt = rt
+        h = C.c_void_p()
+        st_code = self._lib.tpsrhs_create(C.byref(self._margs.c), C.byref(disc), C.byref(physics), len(bcs),
+                                          self._bcs, C.byref(rt), C.byref(h))
+        if st_code != 0:
+            raise TpsRhsError(st_code, "tpsrhs_create")
+        self._h = h
+        self.dim = host_mesh.dim
+        self.num_equation = int(self._lib.tpsrhs_num_equation(h))
+        self.NDofs = int(self._lib.tpsrhs_num_dofs(h))
+        self.max_char_speed = 0.0
+        self._time = 0.0
+
+    # -- mfem::Operator / TimeDependentOperator surface ------------------------------------
+    def Height(self) -> int:
+        return int(self._lib.tpsrhs_height(self._h))
+
+    def SetTime(self, t: float):
+        self._time = float(t)
+
+    def GetTime(self) -> float:
+        return self._time
+
+    def Mult(self, x: torch.Tensor, y: torch.Tensor, want_max_char_speed: bool = False):
+        """``y = RHS(x)`` (``src/rhs_operator.cpp:343-464``).  Asynchronous on the operator's stream
+        unless ``want_max_char_speed`` (the reference's ``max_char_speed`` side effect)."""
+        self._check(x)
+        self._check(y)
+        mcs = C.c_double(0.0)
+        st = self._lib.tpsrhs_mult(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), self._time,
+                                   C.byref(mcs) if want_max_char_speed else None)
+        if st != 0:
+            raise TpsRhsError(st, "tpsrhs_mult")
+        if want_max_char_speed:
+            self.max_char_speed = mcs.value
+
+    def updateGradients(self, x: torch.Tensor):
+        self._check(x)
+        st = self._lib.tpsrhs_update_gradients(self._h, C.c_void_p(x.data_ptr()))
+        if st != 0:
+            raise TpsRhsError(st, "tpsrhs_update_gradients")
+
+    def getPrimitives(self) -> torch.Tensor:
+        out = torch.empty(self.num_equation * self.NDofs, dtype=torch.float64, device=self.device)
+        st = self._lib.tpsrhs_get_primitives(self._h, C.c_void_p(out.data_ptr()))
+        if st != 0:
+            raise TpsRhsError(st, "tpsrhs_get_primitives")
+        return out.view(self.num_equation, self.NDofs)
+
+    def getGradients(self) -> torch.Tensor:
+        out = torch.empty(self.dim * self.num_equation * self.NDofs, dtype=torch.float64, device=self.device)
+        st = self._lib.tpsrhs_get_gradients(self._h, C.c_void_p(out.data_ptr()))
+        if st != 0:
+            raise TpsRhsError(st, "tpsrhs_get_gradients")
+        return out.view(self.dim, self.num_equation, self.NDofs)
+
+    # -- measurement helpers -----------------------------------------------------------------
+    def enable_kernel_timing(self, on=True):
+        self._lib.tpsrhs_enable_kernel_timing(self._h, 1 if on else 0)
+
+    def kernel_times(self):
+        names = (C.c_char_p * 8)()
+        ms = (C.c_double * 8)()
+        n = self._lib.tpsrhs_kernel_times(self._h, 8, names, ms)
+        return {names[i].decode(): ms[i] for i in range(n)}
+
+    def kernel_bytes(self):
+        names = (C.c_char_p * 8)()
+        b = (C.c_double * 8)()
+        n = self._lib.tpsrhs_kernel_bytes(self._h, 8, names, b)
+        return {names[i].decode(): b[i] for i in range(n)}
+
+    def _check(self, t: torch.Tensor):
+        if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.numel() != self.Height():
+            raise ValueError("expected a contiguous float64 CUDA tensor of num_equation*NDofs entries")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tpsrhs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def node_coordinates(host_mesh, order: int) -> np.ndarray:
+    """Physical coordinates of the DG nodes, ``(dim, NDofs)``: the role of
+    ``mesh->GetNodes(*coordsDof)`` (``src/rhs_operator.cpp:139-142``) for a GL nodal basis on
+    order-1 geometry.  Host-side input generation only."""
+    dim = host_mesh.dim
+    n1 = order + 1
+    x, _ = np.polynomial.legendre.leggauss(n1)
+    x = 0.5 * (x + 1.0)
+    ex = host_mesh.elem_coords  # (ne, 2^dim, dim), MFEM order
+    if dim == 3:
+        corners = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+        k, j, i = np.meshgrid(x, x, x, indexing="ij")
+        xi = [i.ravel(), j.ravel(), k.ravel()]
+    else:
+        corners = [(0, 0), (1, 0), (1, 1), (0, 1)]
+        j, i = np.meshgrid(x, x, indexing="ij")
+        xi = [i.ravel(), j.ravel()]
+    out = np.zeros((dim, host_mesh.num_elements, xi[0].size))
+    for v, c in enumerate(corners):
+        shp = np.ones_like(xi[0])
+        for d in range(dim):
+            shp = shp * (xi[d] if c[d] else 1.0 - xi[d])
+        for d in range(dim):
+            out[d] += ex[:, v, d][:, None] * shp[None, :]
+    return out.reshape(dim, -1)
