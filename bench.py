@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: RHSoperator::Mult on the 3-D p=3 Navier-Stokes cylinder workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one ``Mult`` (one explicit DG right-hand-side evaluation) over state resident in HBM.
+N = 1: BASELINE.json configs[1] (28x112x16 = 50 176 hexes, p = 3, 3 211 264 nodes, 5 equations).
+N > 1 (launched by ``torch.distributed.run``, one rank per GPU): every rank owns one such block --
+spanwise slabs of an N-times longer cylinder -- and exchanges the traces of its two shared planes
+with RCCL send/recv (weak scaling, no collective on the data path).
+
+Prints ONE JSON line (rank 0).  ``value`` = DOFs of x processed per second by the whole job / 1e6.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0
+
+
+def algorithmic_bytes_per_node(neq, dim, p):
+    """bytes per node per Mult of the two mandatory sweeps (gradient, flux)."""
+    n1 = p + 1
+    qf = (((dim - 1) + 2 * p) // 2 + 1) ** (dim - 1)
+    dof = n1**dim
+    b_face = 8.0 * 2 * (dim + 1) * qf * dim / dof
+    sweep1 = 8.0 * (neq + dim * neq + dim * dim + 1) + 0.5 * b_face
+    sweep2 = 8.0 * (2 * neq + dim * neq + dim * dim + 1) + 0.5 * b_face
+    return {"k_gradient": sweep1, "k_flux": sweep2, "mult": sweep1 + sweep2}
+
+
+def cpu_baseline(neq, order, budget_s=20.0):
+    """The oracle (CPU restatement, reference-faithful dense formulation) timed on this host on a
+    bounded sample of the same workload: a 7x28x4 = 784-element O-grid block of the cylinder at the
+    same order, physics and boundary conditions."""
+    import numpy as np
+    from oracle_lib import Oracle
+
+    from tps_amd import capi, cases
+
+    c = cases.cyl3d(7, 28, 4, order, capi.NS, capi.VISC_ISOTH)
+    # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    o = Oracle(c.mesh, c.disc, c.physics, c.bcs, threads=threads)
+    U = c.state()
+    o.mult(U)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 50):
+        o.mult(U)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    ndofs = U.shape[1]
+    return {"value": ndofs * neq / dt / 1e6, "unit": "MDOF/s", "cores": threads, "kind": "port",
+            "sample": f"cyl3d O-grid 7x28x4 = {c.mesh.num_elements} hexes, p={order}, NS dry air, "
+                      f"{ndofs} nodes, {n} Mult calls, OpenMP over elements/faces/nodes",
+            "evals_per_s_on_sample": 1.0 / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--nr", type=int, default=28)
+    ap.add_argument("--ntheta", type=int, default=112)
+    ap.add_argument("--nz", type=int, default=16)
+    ap.add_argument("--order", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from tps_amd import capi, cases, meshgen
+    from tps_amd.halo import HaloExchange
+    from tps_amd.rhs_operator import RHSoperator, node_coordinates
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    halo = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        halo = HaloExchange(device=torch.device("cuda", local_rank))
+
+    order = args.order
+    mesh = meshgen.ogrid_cylinder_slab(args.nr, args.ntheta, args.nz, rank, world)
+    disc = capi.Disc(order, 0, 0, 0, 0)
+    physics = capi.dry_air_physics(capi.NS)
+    bcs = cases.cylinder_bcs(capi.VISC_ISOTH, 300.0)
+    X = node_coordinates(mesh, order)
+    U = cases.dry_air_state(X, seed=12345)
+    del X
+
+    op = RHSoperator(mesh, disc, physics, bcs, device=local_rank, halo=halo)
+    neq, ndofs = op.num_equation, op.NDofs
+    x = torch.tensor(U.ravel(), dtype=torch.float64, device=op.device)
+    y = torch.empty_like(x)
+    del U
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        op.Mult(x, y)
+    torch.cuda.synchronize()
+    barrier()
+    op.enable_kernel_timing(True)  # hipEvent records on the operator's stream, no synchronisation
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        op.Mult(x, y)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=op.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ktimes = op.kernel_times()  # ms, averaged over the timed Mults
+    op.enable_kernel_timing(False)
+    finite = bool(torch.isfinite(y).all().item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        evals_per_s = args.steps / dt
+        total_dofs = world * ndofs * neq
+        value = total_dofs * evals_per_s / 1e6
+        alg = algorithmic_bytes_per_node(neq, mesh.dim, order)
+        dom = max((k for k in ktimes if k in alg), key=lambda k: ktimes[k])
+        achieved = alg[dom] * ndofs / (ktimes[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("nodes") == ndofs and dom in tj.get("bytes_per_launch", {}):
+                    traffic = tj["bytes_per_launch"][dom]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "DG RHS evals/sec (MDOF/s) for 3D p=3 reacting cyl at 1/2/4/8 MI355X",
+            "value": value, "unit": "MDOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} hexes per GPU, p={order}, "
+                                   "perfect-gas Navier-Stokes (dry air, Sutherland), GL basis + GL rule, "
+                                   "inlet SUB_DENS_VEL / outlet SUB_P / isothermal wall (BASELINE.json configs[1])",
+                       "elements_per_gpu": mesh.num_elements, "nodes_per_gpu": ndofs, "num_equation": neq,
+                       "partition": "spanwise slabs, RCCL send/recv of face traces" if world > 1 else "single GPU"},
+            "rhs_evals_per_s": evals_per_s,
+            "kernel_ms": ktimes,
+            "finite": finite,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_node": alg[dom],
+                         "mult_algorithmic_GBps": alg["mult"] * ndofs / (ms_per_step * 1e-3) / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(neq, order)
+        print(json.dumps(out))
+    op.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

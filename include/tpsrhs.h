@@ -267,15 +267,26 @@ int64_t tpsrhs_height(tpsrhs_handle h);
 int64_t tpsrhs_num_dofs(tpsrhs_handle h);
 int tpsrhs_num_equation(tpsrhs_handle h);
 
-/* Per-kernel device time of the LAST tpsrhs_mult, measured with hipEvents on the operator's
- * stream (enable first; adds event records only).  names[i] are static strings.  Returns the
- * number of kernels written (<= capacity). */
+/* Per-kernel device time, averaged over the tpsrhs_mult calls since timing was enabled (at most the
+ * last 128), measured with hipEvents on the operator's stream (enabling adds event records only;
+ * reading synchronises the stream).  names[i] are static strings.  Returns the number of kernels
+ * written (<= capacity).  With a halo callback the k_gradient / k_flux intervals include it. */
 int tpsrhs_enable_kernel_timing(tpsrhs_handle h, int enable);
 int tpsrhs_kernel_times(tpsrhs_handle h, int capacity, const char **names, double *milliseconds);
 
 /* Algorithmic HBM bytes one tpsrhs_mult moves per kernel (DESIGN.md "bytes per unit"), matching
  * the order of tpsrhs_kernel_times. */
 int tpsrhs_kernel_bytes(tpsrhs_handle h, int capacity, const char **names, double *bytes);
+
+/* Host-only view of the face topology tpsrhs_create derives from a mesh (the role of the
+ * indirection arrays of src/M2ulPhyS.cpp:816-1486); touches no device.  Outputs (caller-allocated):
+ *   face_nbr[ne*2*dim]   >= 0: trace slot (element*2*dim + local face) of the neighbour, slots
+ *                        >= ne*2*dim are halo slots in shared-face order; < 0: -(bc index + 1)
+ *   face_orient[ne*2*dim] 3-bit code (swap | flip_a<<1 | flip_b<<2) from my face frame to the
+ *                        neighbour's (interior) or to the canonical frame (shared)
+ *   shared_slot[nshared], shared_orient[nshared]: own slot / frame code of every shared face */
+int tpsrhs_face_tables(const tpsrhs_mesh *mesh, int num_bcs, const tpsrhs_bc *bcs, int32_t *face_nbr,
+                       uint8_t *face_orient, int32_t *shared_slot, uint8_t *shared_orient);
 
 const char *tpsrhs_status_string(int status);
 const char *tpsrhs_last_error(void); /* thread-local text of the last failure */

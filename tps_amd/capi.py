@@ -179,6 +179,10 @@ def load():
         raise LibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
             "tps_amd has no CPU fallback.")
+    # torch ships its own libamdhip64; load it first so that this process holds ONE HIP runtime and
+    # the library's stream/pointer arguments mean the same thing on both sides
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.tpsrhs_create.restype = C.c_int
@@ -200,6 +204,8 @@ def load():
     lib.tpsrhs_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.tpsrhs_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_kernel_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
+    lib.tpsrhs_face_tables.restype = C.c_int
+    lib.tpsrhs_face_tables.argtypes = [C.POINTER(Mesh), C.c_int, C.POINTER(BC), vp, vp, vp, vp]
     lib.tpsrhs_status_string.restype = C.c_char_p
     lib.tpsrhs_status_string.argtypes = [C.c_int]
     lib.tpsrhs_last_error.restype = C.c_char_p
@@ -211,6 +217,27 @@ def load():
 EXPORTED_SYMBOLS = [
     "tpsrhs_create", "tpsrhs_destroy", "tpsrhs_mult", "tpsrhs_mult_host", "tpsrhs_update_gradients",
     "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
-    "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_kernel_bytes", "tpsrhs_status_string",
+    "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_kernel_bytes", "tpsrhs_face_tables",
+    "tpsrhs_status_string",
     "tpsrhs_last_error", "tpsrhs_version",
 ]
+
+
+def face_tables(host_mesh, bcs=()):
+    """Host-only call of ``tpsrhs_face_tables``: returns (face_nbr, face_orient, shared_slot, shared_orient)."""
+    lib = load()
+    ma = MeshArgs(host_mesh)
+    nlf = 2 * host_mesh.dim
+    ne = host_mesh.num_elements
+    ns = ma.c.num_shared_faces
+    fn = np.zeros(ne * nlf, dtype=np.int32)
+    fo = np.zeros(ne * nlf, dtype=np.uint8)
+    ss = np.zeros(max(ns, 1), dtype=np.int32)
+    so = np.zeros(max(ns, 1), dtype=np.uint8)
+    arr = (BC * max(1, len(bcs)))(*bcs)
+    st = lib.tpsrhs_face_tables(C.byref(ma.c), len(bcs), arr, fn.ctypes.data, fo.ctypes.data, ss.ctypes.data,
+                                so.ctypes.data)
+    if st != 0:
+        raise RuntimeError(f"tpsrhs_face_tables: {lib.tpsrhs_status_string(st).decode()}: "
+                           f"{lib.tpsrhs_last_error().decode()}")
+    return fn.reshape(ne, nlf), fo.reshape(ne, nlf), ss[:ns], so[:ns]

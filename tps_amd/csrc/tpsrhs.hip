@@ -81,10 +81,12 @@ struct tpsrhs_operator {
   double *d_send = nullptr;
   std::vector<int64_t> send_off[2], recv_off[2];
   // timing
+  // per-kernel timing: a ring of event sets so that a timed loop never synchronises
+  static constexpr int MAXSETS = 128;
   bool timing = false;
-  hipEvent_t ev[NKERN + 1] = {};
-  float last_ms[NKERN] = {};
-  bool have_times = false;
+  hipEvent_t evs[MAXSETS][NKERN + 1] = {};
+  int64_t sets_recorded = 0;
+  hipEvent_t *ev = evs[0];
 
   void (*launch)(tpsrhs_operator *, const double *, double *, bool) = nullptr;
 
@@ -106,8 +108,9 @@ struct tpsrhs_operator {
                     static_cast<void *>(d_xh), static_cast<void *>(d_yh), static_cast<void *>(d_shared_slot),
                     static_cast<void *>(d_shared_orient), static_cast<void *>(d_send)})
       if (p) (void)hipFree(p);
-    for (auto &e : ev)
-      if (e) (void)hipEventDestroy(e);
+    for (auto &set : evs)
+      for (auto &e : set)
+        if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -139,7 +142,10 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
   const int grid = (op->ne + C::EPB - 1) / C::EPB;
   const typename PH::Params &prm = op->dry;
   hipStream_t s = op->stream;
-  if (op->timing) HIP_CHECK(hipEventRecord(op->ev[0], s));
+  if (op->timing) {
+    op->ev = op->evs[op->sets_recorded % tpsrhs_operator::MAXSETS];
+    HIP_CHECK(hipEventRecord(op->ev[0], s));
+  }
   hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_Up, op->d_TA);
   HIP_CHECK(hipGetLastError());
   if (op->timing) HIP_CHECK(hipEventRecord(op->ev[1], s));
@@ -155,7 +161,7 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
   HIP_CHECK(hipGetLastError());
   if (op->timing) {
     HIP_CHECK(hipEventRecord(op->ev[3], s));
-    op->have_times = true;
+    op->sets_recorded++;
   }
 }
 
@@ -266,7 +272,8 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     op->recv_off[0] = op->send_off[0];
     op->recv_off[1] = op->send_off[1];
   }
-  for (auto &e : op->ev) HIP_CHECK(hipEventCreate(&e));
+  for (auto &set : op->evs)
+    for (auto &e : set) HIP_CHECK(hipEventCreate(&e));
 }
 
 int fail(int code, const std::string &msg) {
@@ -379,19 +386,24 @@ int tpsrhs_num_equation(tpsrhs_handle h) { return h ? h->neq : -1; }
 int tpsrhs_enable_kernel_timing(tpsrhs_handle h, int enable) {
   if (!h) return TPSRHS_ERR_INVALID_ARGUMENT;
   h->timing = enable != 0;
-  h->have_times = false;
+  h->sets_recorded = 0;
   return TPSRHS_OK;
 }
 
 int tpsrhs_kernel_times(tpsrhs_handle h, int capacity, const char **names, double *milliseconds) {
-  if (!h || !h->have_times) return 0;
-  if (hipEventSynchronize(h->ev[NKERN]) != hipSuccess) return 0;
+  if (!h || h->sets_recorded == 0) return 0;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return 0;
+  const int nsets = static_cast<int>(std::min<int64_t>(h->sets_recorded, tpsrhs_operator::MAXSETS));
   int n = 0;
   for (int k = 0; k < NKERN && n < capacity; k++, n++) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, h->ev[k], h->ev[k + 1]) != hipSuccess) return n;
+    double sum = 0.0;
+    for (int i = 0; i < nsets; i++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->evs[i][k], h->evs[i][k + 1]) != hipSuccess) return n;
+      sum += ms;
+    }
     if (names) names[n] = kKernelNames[k];
-    if (milliseconds) milliseconds[n] = ms;
+    if (milliseconds) milliseconds[n] = sum / nsets;  // average over the recorded Mults
   }
   return n;
 }
@@ -413,6 +425,18 @@ int tpsrhs_kernel_bytes(tpsrhs_handle h, int capacity, const char **names, doubl
     if (bytes) bytes[n] = b[k];
   }
   return n;
+}
+
+int tpsrhs_face_tables(const tpsrhs_mesh *mesh, int num_bcs, const tpsrhs_bc *bcs, int32_t *face_nbr,
+                       uint8_t *face_orient, int32_t *shared_slot, uint8_t *shared_orient) {
+  if (!mesh || !face_nbr || !face_orient) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_face_tables: NULL argument");
+  return guarded([&] {
+    const Topology T = build_topology(*mesh, num_bcs, bcs);
+    std::memcpy(face_nbr, T.face_nbr.data(), T.face_nbr.size() * sizeof(int32_t));
+    std::memcpy(face_orient, T.face_orient.data(), T.face_orient.size());
+    if (shared_slot && T.num_shared) std::memcpy(shared_slot, T.shared_slot.data(), T.num_shared * sizeof(int32_t));
+    if (shared_orient && T.num_shared) std::memcpy(shared_orient, T.shared_orient.data(), T.num_shared);
+  });
 }
 
 const char *tpsrhs_status_string(int status) {

@@ -1,0 +1,76 @@
+"""Neighbour (halo) exchange of face traces over ``torch.distributed``.
+
+The C ABI calls :meth:`HaloExchange.callback` twice per ``Mult`` where the reference posts its
+``MPI_Isend``/``MPI_Irecv`` of neighbour-element data (``src/rhs_operator.cpp:775-831``).  What
+travels is much smaller than there: face-node traces of U and Up (phase 0) and viscous
+normal-flux traces at the face quadrature points (phase 1) of the shared faces only, already
+permuted into a frame both ranks agree on.
+
+With the ``nccl`` backend (= RCCL on ROCm) the device buffers go straight into grouped
+send/recv over xGMI -- a neighbour all-to-all-v, every pair on its own link -- ordered after
+the pack kernel and before the consumer kernel on the operator's stream.  With ``gloo`` (CPU
+rehearsal, or several ranks sharing one GPU in tests) the segments are staged through host memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class _DevPtr:
+    """Raw device memory seen through ``__cuda_array_interface__`` (zero-copy into torch)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+class HaloExchange:
+    def __init__(self, group=None, device=None, host_buffers=False):
+        self.group = group
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.device = device
+        self.host_buffers = host_buffers  # True: pointers handed to callback are HOST memory (CPU rehearsal)
+        self.bytes_sent = 0
+        self.calls = 0
+
+    def _view(self, ptr, n):
+        if self.host_buffers:
+            arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,))
+            return torch.from_numpy(arr)
+        return torch.as_tensor(_DevPtr(ptr, n), device=self.device)
+
+    def callback(self, ctx, phase, send, recv, nnbr, ranks, send_off, recv_off, stream):
+        try:
+            ops, stage = [], []
+            for r in range(nnbr):
+                ns = send_off[r + 1] - send_off[r]
+                nr = recv_off[r + 1] - recv_off[r]
+                s = self._view(send + 8 * send_off[r], ns)
+                t = self._view(recv + 8 * recv_off[r], nr)
+                peer = ranks[r]
+                if self.backend == "nccl" or self.host_buffers:
+                    ops.append(dist.P2POp(dist.isend, s, peer, self.group))
+                    ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
+                else:  # device buffers over a CPU backend: stage through host
+                    hs = s.cpu()
+                    ht = torch.empty(nr, dtype=torch.float64)
+                    stage.append((t, ht))
+                    ops.append(dist.P2POp(dist.isend, hs, peer, self.group))
+                    ops.append(dist.P2POp(dist.irecv, ht, peer, self.group))
+                self.bytes_sent += 8 * ns
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for t, ht in stage:
+                t.copy_(ht)
+            self.calls += 1
+            return 0
+        except Exception as exc:  # never let an exception cross the C boundary
+            import traceback
+
+            traceback.print_exc()
+            self.error = exc
+            return 1

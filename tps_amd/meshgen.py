@@ -124,7 +124,9 @@ def _structured(dim, n, vertex_xyz, periodic, bdr_attr):
                 pass
             verts = ev[sel][:, fc]
             centre = ex[sel][:, fc, :].mean(axis=1)
-            attr = bdr_attr[(d, side)]
+            attr = bdr_attr.get((d, side))
+            if attr is None:  # left open: the caller turns these faces into shared faces
+                continue
             a = attr(centre) if callable(attr) else np.full(sel.size, attr)
             bv.append(verts)
             ba.append(np.asarray(a, dtype=np.int32))
@@ -194,6 +196,55 @@ def ogrid_cylinder(nr, ntheta, nz, r_in=0.5, r_out=10.0, span=2.0, stretch=1.05)
         return np.where(centre[:, 0] < 0.0, 1, 2)
 
     return _structured(3, (nr, ntheta, nz), xyz, (False, True, True), {(0, 0): 3, (0, 1): outer})
+
+
+def ogrid_cylinder_slab(nr, ntheta, nz_local, rank, nparts, r_in=0.5, r_out=10.0, span_local=2.0, stretch=1.05):
+    """Rank ``rank``'s spanwise slab of an O-grid with ``nparts * nz_local`` layers (periodic in z):
+    the structured equivalent of :func:`partition` for the weak-scaling bench, built without ever
+    forming the global mesh.  Every rank owns ``nr*ntheta*nz_local`` elements and shares its two
+    z-faces with ranks ``rank-1`` and ``rank+1`` (mod ``nparts``)."""
+    if nparts == 1:
+        return ogrid_cylinder(nr, ntheta, nz_local, r_in, r_out, span_local, stretch)
+    if abs(stretch - 1.0) < 1e-14:
+        r = np.linspace(r_in, r_out, nr + 1)
+    else:
+        dr0 = (r_out - r_in) * (stretch - 1.0) / (stretch**nr - 1.0)
+        r = r_in + dr0 * (stretch ** np.arange(nr + 1) - 1.0) / (stretch - 1.0)
+        r[-1] = r_out
+    k0 = rank * nz_local
+    nzg = nparts * nz_local
+
+    def xyz(i, j, k):
+        th = 2.0 * np.pi * j / ntheta
+        return np.stack([r[i] * np.cos(th), r[i] * np.sin(th), span_local * (k + k0) / nz_local], axis=-1)
+
+    def outer(centre):
+        return np.where(centre[:, 0] < 0.0, 1, 2)
+
+    m = _structured(3, (nr, ntheta, nz_local), xyz, (False, True, False), {(0, 0): 3, (0, 1): outer})
+    # local vertex id = i + (nr+1)*(j + ntheta*k); global id uses the global (periodic) layer index
+    nvi, nvj = nr + 1, ntheta
+    i, j = np.meshgrid(np.arange(nr), np.arange(ntheta), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    sv, sr, keys = [], [], []
+    for kl, nbr in ((0, (rank - 1) % nparts), (nz_local, (rank + 1) % nparts)):
+        kg = (k0 + kl) % nzg
+        ci = np.stack([i, i + 1, i + 1, i], axis=1)
+        cj = np.stack([j, j, (j + 1) % nvj, (j + 1) % nvj], axis=1)
+        loc = ci + nvi * (cj + nvj * kl)
+        glo = ci + nvi * (cj + nvj * kg)
+        order = np.argsort(glo, axis=1)
+        loc = np.take_along_axis(loc, order, axis=1)
+        glo = np.take_along_axis(glo, order, axis=1)
+        sv.append(loc)
+        keys.append(glo)
+        sr.append(np.full(loc.shape[0], nbr))
+    sv, keys, sr = np.concatenate(sv), np.concatenate(keys), np.concatenate(sr)
+    # group by neighbour rank (ascending), then by the sorted global key: identical on both sides
+    srt = np.lexsort((keys[:, 3], keys[:, 2], keys[:, 1], keys[:, 0], sr))
+    m.shared_vertices = sv[srt].astype(np.int32)
+    m.shared_neighbor_rank = sr[srt].astype(np.int32)
+    return m
 
 
 def annulus_quad(nr, nz, r_in=0.0, r_out=1.0, length=2.0, bdr_attr=None):
