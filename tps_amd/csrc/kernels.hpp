@@ -8,10 +8,14 @@
 //   k_flux     U + gradUp + neighbour traces -> y                   (src/face_integrator.cpp:194-352, src/BCintegrator.cpp:295-441,
 //                                                                     src/rhs_operator.cpp:493-559, src/domain_integrator.cpp:45-99,
 //                                                                     src/rhs_operator.cpp:432-461)
-// A workgroup owns EPB whole elements (one lane per node), keeps their nodal fields in LDS, and
-// applies the element-independent 1-D operators (differentiation matrix, end-point values, node ->
-// face-quadrature interpolation) by sum factorisation out of a < 1 KB LDS table.  Geometry
-// (Jacobians, area-weighted normals) is recomputed from the 2^dim vertex coordinates of the element.
+// A workgroup owns EPB whole elements (one lane per node; one 64-lane wave per hex at p=3), keeps
+// their nodal fields in LDS, and applies the element-independent 1-D operators (differentiation
+// matrix, end-point values, node -> face-quadrature interpolation) by sum factorisation out of a
+// 0.5 KB LDS table; two-dimensional face operators are factorised in two lane-parallel stages
+// through LDS.  Geometry (Jacobians, area-weighted normals) is recomputed from the 2^dim vertex
+// coordinates of the element: 192 B per hex instead of 10 doubles per node.
+// LDS is one hand-allocated pool whose regions are re-used as fields die, so that 7-8 single-wave
+// workgroups fit a CU at p=3.
 #ifndef TPSRHS_KERNELS_HPP_
 #define TPSRHS_KERNELS_HPP_
 
@@ -21,6 +25,8 @@
 
 namespace tpsrhs {
 
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
 template <int DIM_, int P_>
 struct Cfg {
   static constexpr int DIM = DIM_, P = P_, N1 = P_ + 1;
@@ -28,14 +34,24 @@ struct Cfg {
   static constexpr int NF = (DIM_ == 3) ? N1 * N1 : N1;
   static constexpr int Q1 = ((DIM_ - 1) + 2 * P_) / 2 + 1;
   static constexpr int NQ = (DIM_ == 3) ? Q1 * Q1 : Q1;
+  static constexpr int NW = (DIM_ == 3) ? Q1 * N1 : 1;  // half-interpolated face values (3-D only)
   static constexpr int NFACES = 2 * DIM_;
   static constexpr int NV = 1 << DIM_;
   static constexpr int BLOCK = (NPE <= 64) ? 64 : ((NPE <= 128) ? 128 : 256);
   static constexpr int EPB = BLOCK / NPE;  // elements per block
   static constexpr int NODES = EPB * NPE;  // active lanes in node loops
-  static constexpr int FN_ITEMS = EPB * NFACES * NF;
-  static constexpr int FQ_ITEMS = EPB * NFACES * NQ;
+  static constexpr int LF = EPB * NFACES;  // local faces per block
+  static constexpr int FN_ITEMS = LF * NF;
+  static constexpr int FQ_ITEMS = LF * NQ;
+  static constexpr int FW_ITEMS = LF * NW;
   static constexpr int FQ_ROUNDS = (FQ_ITEMS + BLOCK - 1) / BLOCK;
+};
+
+// compact LDS copy of the 1-D tables of one order
+template <class C>
+struct Tab {
+  double x[C::N1], w[C::N1], D[C::N1 * C::N1], b0[C::N1], b1[C::N1];
+  double xq[C::Q1], wq[C::Q1], B[C::Q1 * C::N1];
 };
 
 struct MeshDev {
@@ -53,7 +69,6 @@ template <class C>
 __device__ inline int stride_of(int d) {
   return d == 0 ? 1 : (d == 1 ? C::N1 : C::N1 * C::N1);
 }
-// tangential axes of face direction d
 template <class C>
 __device__ inline void tangential(int d, int &a, int &b) {
   if (C::DIM == 2) {
@@ -64,8 +79,8 @@ __device__ inline void tangential(int d, int &a, int &b) {
     b = (d == 2) ? 1 : 2;
   }
 }
-// permutation of a tangential index pair under an orientation code (n points per direction,
-// symmetric point sets): my (ia, ib) -> neighbour's flat index
+// permutation of a tangential index pair under an orientation code (n symmetric points per
+// direction): my (ia, ib) -> neighbour's flat index
 template <int DIM>
 __device__ inline int permute(int o, int n, int ia, int ib) {
   const int fa = (o >> 1) & 1, fb = (o >> 2) & 1;
@@ -81,8 +96,7 @@ __device__ inline int permute(int o, int n, int ia, int ib) {
   return ja + n * jb;
 }
 
-// Jacobian J[i + m*DIM] = dx_i/dxi_m of the multilinear element at reference point xi; V = vertex
-// coordinates [corner][DIM], lexicographic corners
+// Jacobian J[i + m*DIM] = dx_i/dxi_m of the multilinear element at reference point xi
 template <int DIM>
 __device__ inline void jacobian(const double *V, const double *xi, double *J) {
   if (DIM == 2) {
@@ -106,23 +120,6 @@ __device__ inline void jacobian(const double *V, const double *xi, double *J) {
     }
   }
 }
-template <int DIM>
-__device__ inline void position(const double *V, const double *xi, double *X) {
-  if (DIM == 2) {
-    const double x = xi[0], y = xi[1];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-      X[i] = (V[0 + i] * (1.0 - x) + V[2 + i] * x) * (1.0 - y) + (V[4 + i] * (1.0 - x) + V[6 + i] * x) * y;
-  } else {
-    const double x = xi[0], y = xi[1], z = xi[2];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const double a = (V[0 + i] * (1.0 - x) + V[3 + i] * x) * (1.0 - y) + (V[6 + i] * (1.0 - x) + V[9 + i] * x) * y;
-      const double b = (V[12 + i] * (1.0 - x) + V[15 + i] * x) * (1.0 - y) + (V[18 + i] * (1.0 - x) + V[21 + i] * x) * y;
-      X[i] = a * (1.0 - z) + b * z;
-    }
-  }
-}
 // adjugate A[m + i*DIM] = det(J) * dxi_m/dx_i and determinant
 template <int DIM>
 __device__ inline double adjugate(const double *J, double *A) {
@@ -133,7 +130,6 @@ __device__ inline double adjugate(const double *J, double *A) {
     A[1 + 1 * 2] = J[0 + 0 * 2];
     return J[0] * J[3] - J[2] * J[1];
   } else {
-    // cofactors: A(m,i) = cof(J)(i,m)
     A[0 + 0 * 3] = J[1 + 1 * 3] * J[2 + 2 * 3] - J[1 + 2 * 3] * J[2 + 1 * 3];
     A[0 + 1 * 3] = J[0 + 2 * 3] * J[2 + 1 * 3] - J[0 + 1 * 3] * J[2 + 2 * 3];
     A[0 + 2 * 3] = J[0 + 1 * 3] * J[1 + 2 * 3] - J[0 + 2 * 3] * J[1 + 1 * 3];
@@ -147,52 +143,63 @@ __device__ inline double adjugate(const double *J, double *A) {
   }
 }
 
-// a face item (le, f, index-in-face) decoded from a flat item id; `per` = NF or NQ
+// a face item decoded from a flat id: local face lf = le*NFACES + f and index inside the face
 struct FaceItem {
-  int le, f, idx;
+  int le, f, lf, idx;
 };
 template <class C>
 __device__ inline FaceItem face_item(int item, int per) {
   FaceItem r;
-  r.le = item / (C::NFACES * per);
-  const int rem = item - r.le * (C::NFACES * per);
-  r.f = rem / per;
-  r.idx = rem - r.f * per;
+  r.lf = item / per;
+  r.idx = item - r.lf * per;
+  r.le = r.lf / C::NFACES;
+  r.f = r.lf - r.le * C::NFACES;
   return r;
 }
 
-// area-weighted outward normal n[DIM], quadrature weight and position at face quadrature point
-// (f, q) of an element with vertices V
+// Area-weighted outward normal at face quadrature point q of local face f, from the face's own
+// corner coordinates: on a multilinear element the two tangents of a face are linear in the other
+// tangential coordinate, so n = +-(dx/dta x dx/dtb) costs two lerps and a cross product
+// (CalcOrtho of the face Jacobian, src/face_integrator.cpp:323).  X = position (2-D only).
 template <class C>
-__device__ inline void face_geometry(const double *V, const Tables1D &tab, int f, int q, double *n, double &wq,
+__device__ inline void face_geometry(const double *V, const Tab<C> &tab, int f, int q, double *n, double &wq,
                                      double *X) {
-  constexpr int DIM = C::DIM;
   const int d = f >> 1, s = f & 1;
-  int a, b;
-  tangential<C>(d, a, b);
-  double xi[DIM];
-  xi[d] = s;
-  if (DIM == 2) {
-    xi[a] = tab.xq[q];
+  if (C::DIM == 2) {
+    const int a = 1 - d;
+    const int c0 = (s << d), c1 = (s << d) | (1 << a);
+    const double tx = V[c1 * 2 + 0] - V[c0 * 2 + 0], ty = V[c1 * 2 + 1] - V[c0 * 2 + 1];
+    const double sg = (s ? 1.0 : -1.0) * (d == 0 ? 1.0 : -1.0);
+    n[0] = sg * ty;
+    n[1] = -sg * tx;
     wq = tab.wq[q];
+    const double t = tab.xq[q];
+    X[0] = V[c0 * 2 + 0] + t * tx;
+    X[1] = V[c0 * 2 + 1] + t * ty;
   } else {
+    const int a = (d == 0) ? 1 : 0, b = (d == 2) ? 1 : 2;
     const int qa = q % C::Q1, qb = q / C::Q1;
-    xi[a] = tab.xq[qa];
-    xi[b] = tab.xq[qb];
+    const double ta = tab.xq[qa], tb = tab.xq[qb];
     wq = tab.wq[qa] * tab.wq[qb];
-  }
-  double J[DIM * DIM], A[DIM * DIM];
-  jacobian<DIM>(V, xi, J);
-  adjugate<DIM>(J, A);
-  const double sg = s ? 1.0 : -1.0;
+    const int c00 = (s << d), c10 = c00 | (1 << a), c01 = c00 | (1 << b), c11 = c10 | (1 << b);
+    double va[3], vb[3];
 #pragma unroll
-  for (int i = 0; i < DIM; i++) n[i] = sg * A[d + i * DIM];
-  position<DIM>(V, xi, X);
+    for (int i = 0; i < 3; i++) {
+      const double p00 = V[c00 * 3 + i], p10 = V[c10 * 3 + i], p01 = V[c01 * 3 + i], p11 = V[c11 * 3 + i];
+      const double ea0 = p10 - p00, ea1 = p11 - p01, eb0 = p01 - p00, eb1 = p11 - p10;
+      va[i] = ea0 + tb * (ea1 - ea0);
+      vb[i] = eb0 + ta * (eb1 - eb0);
+    }
+    const double sg = (s ? 1.0 : -1.0) * (d == 1 ? -1.0 : 1.0);
+    n[0] = sg * (va[1] * vb[2] - va[2] * vb[1]);
+    n[1] = sg * (va[2] * vb[0] - va[0] * vb[2]);
+    n[2] = sg * (va[0] * vb[1] - va[1] * vb[0]);
+  }
 }
 
 // trace at face node (f, fn) of nodal field F (LDS, NPE values of one element): sum_i b_s(i) F[...]
 template <class C>
-__device__ inline double face_trace(const double *F, const Tables1D &tab, int f, int fn) {
+__device__ inline double face_trace(const double *F, const Tab<C> &tab, int f, int fn) {
   const int d = f >> 1, s = f & 1;
   int a, b;
   tangential<C>(d, a, b);
@@ -210,52 +217,84 @@ __device__ inline double face_trace(const double *F, const Tables1D &tab, int f,
   return acc;
 }
 
-// value at face quadrature point q of a face-node field T[NF] (LDS): sum-factorised B (x) B
-template <class C>
-__device__ inline double face_interp(const double *T, const Tables1D &tab, int q) {
-  if (C::DIM == 2) {
-    double acc = 0.0;
+// ---- two-stage face interpolation: T[fld][FN_ITEMS] -> W[fld][FW_ITEMS] -> value at a quadrature point
+// stage 1 (3-D): W[lf][qa + Q1*jb] = sum_ja B[qa][ja] T[lf][ja + N1*jb]
+template <class C, int NFLD>
+__device__ inline void interp_stage1(const double *T, double *W, const Tab<C> &tab, int tid) {
+  if (C::DIM == 2) return;
+  for (int item = tid; item < C::FW_ITEMS; item += C::BLOCK) {
+    const int lf = item / C::NW, r = item - lf * C::NW;
+    const int jb = r / C::Q1, qa = r - jb * C::Q1;
+    const double *Bq = &tab.B[qa * C::N1];
+    const double *t = T + lf * C::NF + C::N1 * jb;
 #pragma unroll
-    for (int a = 0; a < C::N1; a++) acc += tab.B[q * C::N1 + a] * T[a];
-    return acc;
-  } else {
-    const int qa = q % C::Q1, qb = q / C::Q1;
-    double acc = 0.0;
+    for (int fld = 0; fld < NFLD; fld++) {
+      double acc = 0.0;
 #pragma unroll
-    for (int jb = 0; jb < C::N1; jb++) {
-      double r = 0.0;
-#pragma unroll
-      for (int ja = 0; ja < C::N1; ja++) r += tab.B[qa * C::N1 + ja] * T[ja + C::N1 * jb];
-      acc += tab.B[qb * C::N1 + jb] * r;
+      for (int ja = 0; ja < C::N1; ja++) acc += Bq[ja] * t[fld * C::FN_ITEMS + ja];
+      W[fld * C::FW_ITEMS + item] = acc;
     }
-    return acc;
   }
 }
-// transpose: face node fn <- quadrature values R[NQ] (LDS)
+// stage 2: value of field `fld` at quadrature point (lf, q).  3-D reads W, 2-D reads T directly.
 template <class C>
-__device__ inline double face_project(const double *R, const Tables1D &tab, int fn) {
+__device__ inline double interp_stage2(const double *T, const double *W, const Tab<C> &tab, int lf, int q) {
+  double acc = 0.0;
   if (C::DIM == 2) {
-    double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < C::Q1; q++) acc += tab.B[q * C::N1 + fn] * R[q];
-    return acc;
+    for (int a = 0; a < C::N1; a++) acc += tab.B[q * C::N1 + a] * T[lf * C::NF + a];
   } else {
-    const int ja = fn % C::N1, jb = fn / C::N1;
-    double acc = 0.0;
+    const int qa = q % C::Q1, qb = q / C::Q1;
 #pragma unroll
-    for (int qb = 0; qb < C::Q1; qb++) {
-      double r = 0.0;
+    for (int jb = 0; jb < C::N1; jb++) acc += tab.B[qb * C::N1 + jb] * W[lf * C::NW + qa + C::Q1 * jb];
+  }
+  return acc;
+}
+// ---- two-stage projection (transpose): R[fld][FQ_ITEMS] -> W2[fld][FW_ITEMS] -> L[fld][FN_ITEMS]
+// stage 1 (3-D): W2[lf][ja + N1*qb] = sum_qa B[qa][ja] R[lf][qa + Q1*qb]
+template <class C, int NFLD>
+__device__ inline void project_stage1(const double *R, double *W2, const Tab<C> &tab, int tid) {
+  if (C::DIM == 2) return;
+  for (int item = tid; item < C::FW_ITEMS; item += C::BLOCK) {
+    const int lf = item / C::NW, r = item - lf * C::NW;
+    const int qb = r / C::N1, ja = r - qb * C::N1;
+    const double *rr = R + lf * C::NQ + C::Q1 * qb;
 #pragma unroll
-      for (int qa = 0; qa < C::Q1; qa++) r += tab.B[qa * C::N1 + ja] * R[qa + C::Q1 * qb];
-      acc += tab.B[qb * C::N1 + jb] * r;
+    for (int fld = 0; fld < NFLD; fld++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int qa = 0; qa < C::Q1; qa++) acc += tab.B[qa * C::N1 + ja] * rr[fld * C::FQ_ITEMS + qa];
+      W2[fld * C::FW_ITEMS + item] = acc;
     }
-    return acc;
+  }
+}
+template <class C, int NFLD>
+__device__ inline void project_stage2(const double *R, const double *W2, double *L, const Tab<C> &tab, int tid) {
+  for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
+    const int lf = item / C::NF, fn = item - lf * C::NF;
+    if (C::DIM == 2) {
+#pragma unroll
+      for (int fld = 0; fld < NFLD; fld++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < C::Q1; q++) acc += tab.B[q * C::N1 + fn] * R[fld * C::FQ_ITEMS + lf * C::NQ + q];
+        L[fld * C::FN_ITEMS + item] = acc;
+      }
+    } else {
+      const int ja = fn % C::N1, jb = fn / C::N1;
+#pragma unroll
+      for (int fld = 0; fld < NFLD; fld++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int qb = 0; qb < C::Q1; qb++) acc += tab.B[qb * C::N1 + jb] * W2[fld * C::FW_ITEMS + lf * C::NW + ja + C::N1 * qb];
+        L[fld * C::FN_ITEMS + item] = acc;
+      }
+    }
   }
 }
 // lifting to a volume node: sum over the element's faces of b_s(idx_d) L[f][fn(node)]
-// L: LDS [NFACES][NF] of one element
 template <class C>
-__device__ inline double face_lift(const double *L, const Tables1D &tab, const int *idx) {
+__device__ inline double face_lift(const double *L, const Tab<C> &tab, const int *idx) {
   double acc = 0.0;
 #pragma unroll
   for (int d = 0; d < C::DIM; d++) {
@@ -268,11 +307,28 @@ __device__ inline double face_lift(const double *L, const Tables1D &tab, const i
 }
 
 template <class C>
-__device__ inline void load_tables(Tables1D &dst, const Tables1D *src) {
-  constexpr int NW = sizeof(Tables1D) / sizeof(double);
-  double *d = reinterpret_cast<double *>(&dst);
-  const double *s = reinterpret_cast<const double *>(src);
-  for (int i = threadIdx.x; i < NW; i += C::BLOCK) d[i] = s[i];
+__device__ inline void load_tables(Tab<C> &t, const Tables1D *src) {
+  const int tid = threadIdx.x;
+  if (tid < C::N1) {
+    t.x[tid] = src->x[tid];
+    t.w[tid] = src->w[tid];
+    t.b0[tid] = src->b0[tid];
+    t.b1[tid] = src->b1[tid];
+  }
+  if (tid < C::Q1) {
+    t.xq[tid] = src->xq[tid];
+    t.wq[tid] = src->wq[tid];
+  }
+  for (int i = tid; i < C::N1 * C::N1; i += C::BLOCK) t.D[i] = src->D[i];
+  for (int i = tid; i < C::Q1 * C::N1; i += C::BLOCK) t.B[i] = src->B[i];
+}
+template <class C>
+__device__ inline void load_vertices(double *sV, const MeshDev &m, int e0) {
+  constexpr int PER = C::NV * C::DIM;
+  for (int i = threadIdx.x; i < C::EPB * PER; i += C::BLOCK) {
+    const int le = i / PER;
+    if (e0 + le < m.ne) sV[i] = m.verts[static_cast<int64_t>(e0) * PER + i];
+  }
 }
 
 // =============================================================================================
@@ -283,7 +339,7 @@ template <class C, class PH>
 __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
                                                      double *__restrict__ Upout, double *__restrict__ TA) {
   constexpr int NEQ = PH::NEQ;
-  __shared__ Tables1D tab;
+  __shared__ Tab<C> tab;
   __shared__ double sF[2 * NEQ][C::NODES];
   load_tables<C>(tab, m.tables);
   const int tid = threadIdx.x;
@@ -323,33 +379,41 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Par
 //   boundary face:          the complete additive viscous term of the boundary flux
 // =============================================================================================
 template <class C, class PH>
+struct GradLds {
+  static constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  // chunk of fields interpolated together in the viscous phase
+  static constexpr int CH = NEQ;
+  static constexpr int R0 = NEQ * C::NODES;                                           // sU
+  static constexpr int R1 = cmax(NEQ * DIM * C::NODES, NEQ * C::FQ_ITEMS);            // sG | sQ
+  static constexpr int R2 = cmax(cmax(NEQ * C::NODES, NEQ * C::FW_ITEMS), CH * C::FN_ITEMS);  // sUp | W | T chunk
+  static constexpr int R3 = cmax(NEQ * C::FN_ITEMS, CH * C::FW_ITEMS);                // sFN | sL | W chunk
+  static constexpr int O0 = 0, O1 = R0, O2 = R0 + R1, O3 = R0 + R1 + R2;
+  static constexpr int TOTAL = R0 + R1 + R2 + R3;
+};
+
+template <class C, class PH>
 __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::Params prm,
                                                        const double *__restrict__ U, const double *__restrict__ TA,
                                                        double *__restrict__ gradUp, double *__restrict__ TB) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-  constexpr int NFLD = NEQ + NEQ * DIM;  // U and gradUp, interpolated to the faces at the end
-  __shared__ Tables1D tab;
-  __shared__ double sV[C::EPB][C::NV * DIM];
-  __shared__ double sU[NEQ][C::NODES];
-  __shared__ double sG[NEQ * DIM][C::NODES];
-  // scratch: phase 1 {sUp, sFN, sQ, sL}; phase 2 sT (face-node traces of U and gradUp)
-  constexpr int SCR1 = NEQ * C::NODES + NEQ * C::FN_ITEMS + NEQ * C::FQ_ITEMS + NEQ * C::FN_ITEMS;
-  constexpr int SCR2 = NFLD * C::FN_ITEMS;
-  constexpr int SCR = SCR1 > SCR2 ? SCR1 : SCR2;
-  __shared__ double scratch[SCR];
-  double *sUp = scratch;                    // [NEQ][NODES]
-  double *sFN = sUp + NEQ * C::NODES;       // [NEQ][FN_ITEMS]
-  double *sQ = sFN + NEQ * C::FN_ITEMS;     // [NEQ][FQ_ITEMS]
-  double *sL = sQ + NEQ * C::FQ_ITEMS;      // [NEQ][FN_ITEMS]
-  double *sT = scratch;                     // [NFLD][FN_ITEMS]
+  typedef GradLds<C, PH> L;
+  __shared__ Tab<C> tab;
+  __shared__ double sV[C::EPB * C::NV * DIM];
+  __shared__ double pool[L::TOTAL];
+  double *sU = pool + L::O0;   // [NEQ][NODES]
+  double *sG = pool + L::O1;   // [NEQ*DIM][NODES]      (after the jump phase)
+  double *sQ = pool + L::O1;   // [NEQ][FQ_ITEMS]       (jump phase)
+  double *sUp = pool + L::O2;  // [NEQ][NODES]
+  double *sW = pool + L::O2;   // [NEQ][FW_ITEMS]       (after sUp is dead)
+  double *sT = pool + L::O2;   // [CH][FN_ITEMS]        (viscous phase)
+  double *sFN = pool + L::O3;  // [NEQ][FN_ITEMS]
+  double *sL = pool + L::O3;   // [NEQ][FN_ITEMS]
+  double *sWc = pool + L::O3;  // [CH][FW_ITEMS]        (viscous phase)
 
   load_tables<C>(tab, m.tables);
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * C::EPB;
-  for (int i = tid; i < C::EPB * C::NV * DIM; i += C::BLOCK) {
-    const int le = i / (C::NV * DIM);
-    if (e0 + le < m.ne) sV[le][i - le * (C::NV * DIM)] = m.verts[static_cast<int64_t>(e0) * C::NV * DIM + i];
-  }
+  load_vertices<C>(sV, m, e0);
   const bool node_on = tid < C::NODES && (e0 + tid / C::NPE) < m.ne;
   const int le_n = tid / C::NPE, nd = tid - le_n * C::NPE;
   int idx[3] = {nd % C::N1, (nd / C::N1) % C::N1, nd / (C::N1 * C::N1)};
@@ -361,13 +425,13 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
     PH::prim(prm, u, up);
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) {
-      sU[eq][tid] = u[eq];
+      sU[eq * C::NODES + tid] = u[eq];
       sUp[eq * C::NODES + tid] = up[eq];
     }
   }
   __syncthreads();
 
-  // ---- volume part: collocation derivative, Ke then M^-1 of the reference collapse to it
+  // ---- volume part: collocation derivative (Ke then M^-1 of the reference collapse to it)
   double g[NEQ * DIM];  // g[eq + d*NEQ]
   double inv_mass = 0.0;
   if (node_on) {
@@ -378,7 +442,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
       xi[d] = tab.x[idx[d]];
       wn *= tab.w[idx[d]];
     }
-    jacobian<DIM>(sV[le_n], xi, J);
+    jacobian<DIM>(&sV[le_n * C::NV * DIM], xi, J);
     const double det = adjugate<DIM>(J, A);
     const double idet = 1.0 / det;
     inv_mass = 1.0 / (wn * det);
@@ -404,14 +468,14 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
     }
   }
 
-  // ---- face part: jump of the primitives at the face nodes
+  // ---- face part: half jump of the primitives at the face nodes (own trace on boundary faces)
   for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
     const FaceItem it = face_item<C>(item, C::NF);
     const int e = e0 + it.le;
     if (e >= m.ne) continue;
     const int slot = e * C::NFACES + it.f;
     const int nb = m.face_nbr[slot];
-    double u1[NEQ], u2[NEQ];
+    double u1[NEQ];
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) u1[eq] = face_trace<C>(&sUp[eq * C::NODES + it.le * C::NPE], tab, it.f, it.idx);
     if (nb >= 0) {
@@ -419,9 +483,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
       const int pn = permute<DIM>(o, C::N1, it.idx % C::N1, it.idx / C::N1);
       const double *src = TA + static_cast<int64_t>(nb) * (2 * NEQ * C::NF) + NEQ * C::NF + pn;
 #pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) u2[eq] = src[eq * C::NF];
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) sFN[eq * C::FN_ITEMS + item] = 0.5 * (u2[eq] - u1[eq]);
+      for (int eq = 0; eq < NEQ; eq++) sFN[eq * C::FN_ITEMS + item] = 0.5 * (src[eq * C::NF] - u1[eq]);
     } else {
       // boundary: u2 = u1 (src/faceGradientIntegration.cpp:113-115); the wall ghost of useBCinGrad
       // is not polynomial in the face nodes and is applied at the quadrature points below
@@ -429,9 +491,11 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
       for (int eq = 0; eq < NEQ; eq++) sFN[eq * C::FN_ITEMS + item] = u1[eq];
     }
   }
+  __syncthreads();  // sFN complete, sUp dead
+  interp_stage1<C, NEQ>(sFN, sW, tab, tid);
   __syncthreads();
 
-  // quadrature-point values of the jump and weighted normals, kept in registers per round
+  // quadrature-point values of the half jump and the weighted normals, in registers per round
   double jq[C::FQ_ROUNDS][NEQ];
   double nw[C::FQ_ROUNDS][DIM];
 #pragma unroll
@@ -445,20 +509,20 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
       const FaceItem it = face_item<C>(item, C::NQ);
       const int e = e0 + it.le;
       if (e < m.ne) {
-        const int slot = e * C::NFACES + it.f;
-        const int nb = m.face_nbr[slot];
+        const int nb = m.face_nbr[e * C::NFACES + it.f];
         double n[DIM], wq, X[DIM];
-        face_geometry<C>(sV[it.le], tab, it.f, it.idx, n, wq, X);
+        face_geometry<C>(&sV[it.le * C::NV * DIM], tab, it.f, it.idx, n, wq, X);
 #pragma unroll
         for (int d = 0; d < DIM; d++) nw[r][d] = n[d] * wq;
-        const double *T = &sFN[(it.le * C::NFACES + it.f) * C::NF];
         if (nb >= 0) {
 #pragma unroll
-          for (int eq = 0; eq < NEQ; eq++) jq[r][eq] = face_interp<C>(T + eq * C::FN_ITEMS, tab, it.idx);
+          for (int eq = 0; eq < NEQ; eq++)
+            jq[r][eq] = interp_stage2<C>(sFN + eq * C::FN_ITEMS, sW + eq * C::FW_ITEMS, tab, it.lf, it.idx);
         } else if (prm.use_bc_in_grad) {
           double u1[NEQ], u2[NEQ];
 #pragma unroll
-          for (int eq = 0; eq < NEQ; eq++) u1[eq] = face_interp<C>(T + eq * C::FN_ITEMS, tab, it.idx);
+          for (int eq = 0; eq < NEQ; eq++)
+            u1[eq] = interp_stage2<C>(sFN + eq * C::FN_ITEMS, sW + eq * C::FW_ITEMS, tab, it.lf, it.idx);
           PH::bc_grad_prim(prm, prm.bc[-nb - 1], u1, u2);
 #pragma unroll
           for (int eq = 0; eq < NEQ; eq++) jq[r][eq] = 0.5 * (u2[eq] - u1[eq]);
@@ -466,7 +530,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
       }
     }
   }
-  __syncthreads();
+  __syncthreads();  // sW, sFN dead
 #pragma unroll
   for (int d = 0; d < DIM; d++) {
 #pragma unroll
@@ -478,20 +542,19 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
       }
     }
     __syncthreads();
-    for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
-      const FaceItem it = face_item<C>(item, C::NF);
-      const double *R = &sQ[(it.le * C::NFACES + it.f) * C::NQ];
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) sL[eq * C::FN_ITEMS + item] = face_project<C>(R + eq * C::FQ_ITEMS, tab, it.idx);
-    }
+    project_stage1<C, NEQ>(sQ, sW, tab, tid);
+    if (DIM == 3) __syncthreads();
+    project_stage2<C, NEQ>(sQ, sW, sL, tab, tid);
     __syncthreads();
     if (node_on) {
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++)
         g[eq + d * NEQ] += inv_mass * face_lift<C>(&sL[eq * C::FN_ITEMS + le_n * C::NFACES * C::NF], tab, idx);
     }
-    __syncthreads();
+    // the next direction overwrites sQ (read by project_stage1/2 above, complete at the last
+    // barrier) and sW/sL (read before the barriers that precede their next writes)
   }
+  __syncthreads();  // all reads of sQ done before sG (same region) is written
 
   if (node_on) {
     const int64_t n = static_cast<int64_t>(e0 + le_n) * C::NPE + nd;
@@ -500,23 +563,44 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) {
         gradUp[n + eq * m.ndofs + d * NEQ * m.ndofs] = g[eq + d * NEQ];
-        sG[eq + d * NEQ][tid] = g[eq + d * NEQ];
+        sG[(eq + d * NEQ) * C::NODES + tid] = g[eq + d * NEQ];
       }
   }
   __syncthreads();
 
-  // ---- viscous normal-flux traces: face-node traces of U and gradUp, then quadrature points
-  for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
-    const FaceItem it = face_item<C>(item, C::NF);
-    if (e0 + it.le >= m.ne) continue;
+  // ---- viscous normal-flux traces: U and gradUp at the face quadrature points, NEQ fields at a time
+  double uq[C::FQ_ROUNDS][NEQ], gq[C::FQ_ROUNDS][NEQ * DIM];
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) sT[eq * C::FN_ITEMS + item] = face_trace<C>(&sU[eq][it.le * C::NPE], tab, it.f, it.idx);
+  for (int c = 0; c < 1 + DIM; c++) {
+    const double *src = (c == 0) ? sU : sG + (c - 1) * NEQ * C::NODES;
+    for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
+      const FaceItem it = face_item<C>(item, C::NF);
+      if (e0 + it.le >= m.ne) continue;
 #pragma unroll
-    for (int k = 0; k < NEQ * DIM; k++)
-      sT[(NEQ + k) * C::FN_ITEMS + item] = face_trace<C>(&sG[k][it.le * C::NPE], tab, it.f, it.idx);
+      for (int k = 0; k < NEQ; k++)
+        sT[k * C::FN_ITEMS + item] = face_trace<C>(&src[k * C::NODES + it.le * C::NPE], tab, it.f, it.idx);
+    }
+    __syncthreads();
+    interp_stage1<C, NEQ>(sT, sWc, tab, tid);
+    if (DIM == 3) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < C::FQ_ROUNDS; r++) {
+      const int item = tid + r * C::BLOCK;
+      if (item < C::FQ_ITEMS) {
+        const int lf = item / C::NQ, q = item - lf * C::NQ;
+#pragma unroll
+        for (int k = 0; k < NEQ; k++) {
+          const double v = interp_stage2<C>(sT + k * C::FN_ITEMS, sWc + k * C::FW_ITEMS, tab, lf, q);
+          if (c == 0)
+            uq[r][k] = v;
+          else
+            gq[r][k + (c - 1) * NEQ] = v;
+        }
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-#pragma unroll 1
+#pragma unroll
   for (int r = 0; r < C::FQ_ROUNDS; r++) {
     const int item = tid + r * C::BLOCK;
     if (item >= C::FQ_ITEMS) continue;
@@ -525,19 +609,14 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
     if (e >= m.ne) continue;
     const int slot = e * C::NFACES + it.f;
     const int nb = m.face_nbr[slot];
-    const double *T = &sT[(it.le * C::NFACES + it.f) * C::NF];
-    double uq[NEQ], gq[NEQ * DIM], fn[NEQ];
-#pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) uq[eq] = face_interp<C>(T + eq * C::FN_ITEMS, tab, it.idx);
-    PH::clamp_species(uq);
-#pragma unroll
-    for (int k = 0; k < NEQ * DIM; k++) gq[k] = face_interp<C>(T + (NEQ + k) * C::FN_ITEMS, tab, it.idx);
+    double fn[NEQ];
+    PH::clamp_species(uq[r]);
     double n[DIM], wq, X[DIM];
-    face_geometry<C>(sV[it.le], tab, it.f, it.idx, n, wq, X);
+    face_geometry<C>(&sV[it.le * C::NV * DIM], tab, it.f, it.idx, n, wq, X);
     if (nb >= 0) {
-      PH::visc_flux_n(prm, uq, gq, n, fn);
+      PH::visc_flux_n(prm, uq[r], gq[r], n, fn);
     } else {
-      PH::bc_visc_term(prm, prm.bc[-nb - 1], uq, gq, n, fn);
+      PH::bc_visc_term(prm, prm.bc[-nb - 1], uq[r], gq[r], n, fn);
     }
     double *out = TB + static_cast<int64_t>(slot) * (NEQ * C::NQ) + it.idx;
 #pragma unroll
@@ -549,27 +628,37 @@ __global__ __launch_bounds__(C::BLOCK) void k_gradient(MeshDev m, typename PH::P
 // sweep 2: y = M^-1 [ (grad phi, F_c - F_v)  -  <phi, F^ . n> ]  (+ point sources)
 // =============================================================================================
 template <class C, class PH>
+struct FluxLds {
+  static constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  // region A: sU + sGf, later W / W2 + sL ; region B: sT1 + sT2, later sQ
+  static constexpr int A_W = NEQ * C::FW_ITEMS;
+  static constexpr int RA = cmax(NEQ * C::NODES + NEQ * DIM * C::NODES, A_W + NEQ * C::FN_ITEMS);
+  static constexpr int RB = cmax(2 * NEQ * C::FN_ITEMS, NEQ * C::FQ_ITEMS);
+  static constexpr int TOTAL = RA + RB;
+};
+
+template <class C, class PH>
 __global__ __launch_bounds__(C::BLOCK) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
                                                    const double *__restrict__ gradUp, const double *__restrict__ TA,
                                                    const double *__restrict__ TB, double *__restrict__ Y,
                                                    unsigned long long *__restrict__ max_speed_bits) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-  __shared__ Tables1D tab;
-  __shared__ double sV[C::EPB][C::NV * DIM];
-  __shared__ double sU[NEQ][C::NODES];
-  __shared__ double sGf[NEQ * DIM][C::NODES];  // contravariant nodal flux, [eq + m*NEQ]
-  __shared__ double sT1[NEQ][C::FN_ITEMS];     // own face-node traces of U
-  __shared__ double sT2[NEQ][C::FN_ITEMS];     // neighbour traces, permuted into my frame
-  __shared__ double sQ[NEQ][C::FQ_ITEMS];      // weighted numerical flux at the quadrature points
-  double(*sL)[C::FN_ITEMS] = sT1;              // projected flux (reuses sT1 after the qpt loop)
+  typedef FluxLds<C, PH> L;
+  __shared__ Tab<C> tab;
+  __shared__ double sV[C::EPB * C::NV * DIM];
+  __shared__ double pool[L::TOTAL];
+  double *sU = pool;                                // [NEQ][NODES]
+  double *sGf = pool + NEQ * C::NODES;              // [NEQ*DIM][NODES] contravariant nodal flux
+  double *sW = pool;                                // [NEQ][FW_ITEMS]   (after z)
+  double *sL = pool + L::A_W;                       // [NEQ][FN_ITEMS]
+  double *sT1 = pool + L::RA;                       // [NEQ][FN_ITEMS] own traces of U
+  double *sT2 = pool + L::RA + NEQ * C::FN_ITEMS;   // [NEQ][FN_ITEMS] neighbour traces in my frame
+  double *sQ = pool + L::RA;                        // [NEQ][FQ_ITEMS]   (after the interpolation)
 
   load_tables<C>(tab, m.tables);
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * C::EPB;
-  for (int i = tid; i < C::EPB * C::NV * DIM; i += C::BLOCK) {
-    const int le = i / (C::NV * DIM);
-    if (e0 + le < m.ne) sV[le][i - le * (C::NV * DIM)] = m.verts[static_cast<int64_t>(e0) * C::NV * DIM + i];
-  }
+  load_vertices<C>(sV, m, e0);
   const bool node_on = tid < C::NODES && (e0 + tid / C::NPE) < m.ne;
   const int le_n = tid / C::NPE, nd = tid - le_n * C::NPE;
   int idx[3] = {nd % C::N1, (nd / C::N1) % C::N1, nd / (C::N1 * C::N1)};
@@ -579,7 +668,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_flux(MeshDev m, typename PH::Param
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) {
       u[eq] = U[n + eq * m.ndofs];
-      sU[eq][tid] = u[eq];
+      sU[eq * C::NODES + tid] = u[eq];
     }
 #pragma unroll
     for (int d = 0; d < DIM; d++)
@@ -601,7 +690,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_flux(MeshDev m, typename PH::Param
       xi[d] = tab.x[idx[d]];
       wn *= tab.w[idx[d]];
     }
-    jacobian<DIM>(sV[le_n], xi, J);
+    jacobian<DIM>(&sV[le_n * C::NV * DIM], xi, J);
     const double det = adjugate<DIM>(J, A);
     inv_mass = 1.0 / (wn * det);
     double uc[NEQ];
@@ -624,10 +713,10 @@ __global__ __launch_bounds__(C::BLOCK) void k_flux(MeshDev m, typename PH::Param
         double s = 0.0;
 #pragma unroll
         for (int d = 0; d < DIM; d++) s += A[mm + d * DIM] * (F[eq + d * NEQ] - Fv[eq + d * NEQ]);
-        sGf[eq + mm * NEQ][tid] = wn * s;
+        sGf[(eq + mm * NEQ) * C::NODES + tid] = wn * s;
       }
   }
-  // max |u|+c over the block -> global (positive doubles order like their bit patterns)
+  // max |u|+c over the wave -> global (positive doubles order like their bit patterns)
   {
     double v = speed;
 #pragma unroll
@@ -643,16 +732,17 @@ __global__ __launch_bounds__(C::BLOCK) void k_flux(MeshDev m, typename PH::Param
     const int slot = e * C::NFACES + it.f;
     const int nb = m.face_nbr[slot];
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) sT1[eq][item] = face_trace<C>(&sU[eq][it.le * C::NPE], tab, it.f, it.idx);
+    for (int eq = 0; eq < NEQ; eq++)
+      sT1[eq * C::FN_ITEMS + item] = face_trace<C>(&sU[eq * C::NODES + it.le * C::NPE], tab, it.f, it.idx);
     if (nb >= 0) {
       const int o = m.face_orient[slot];
       const int pn = permute<DIM>(o, C::N1, it.idx % C::N1, it.idx / C::N1);
       const double *s2 = TA + static_cast<int64_t>(nb) * (2 * NEQ * C::NF) + pn;
 #pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) sT2[eq][item] = s2[eq * C::NF];
+      for (int eq = 0; eq < NEQ; eq++) sT2[eq * C::FN_ITEMS + item] = s2[eq * C::NF];
     }
   }
-  __syncthreads();
+  __syncthreads();  // sGf, sT1, sT2 complete
 
   // ---- volume term: z_j = sum_m sum_a D[a][j_m] Ghat_m(a)   (src/domain_integrator.cpp:45-99)
   double z[NEQ];
@@ -663,16 +753,42 @@ __global__ __launch_bounds__(C::BLOCK) void k_flux(MeshDev m, typename PH::Param
 #pragma unroll
       for (int mm = 0; mm < DIM; mm++) {
         const int sd = stride_of<C>(mm);
-        const double *F = &sGf[eq + mm * NEQ][le_n * C::NPE + nd - idx[mm] * sd];
+        const double *F = &sGf[(eq + mm * NEQ) * C::NODES + le_n * C::NPE + nd - idx[mm] * sd];
 #pragma unroll
         for (int a = 0; a < C::N1; a++) acc += tab.D[a * C::N1 + idx[mm]] * F[a * sd];
       }
       z[eq] = acc;
     }
   }
+  if (DIM == 3) __syncthreads();  // sU/sGf dead: region A becomes W
 
-  // ---- numerical flux at the face quadrature points
-#pragma unroll 1
+  // ---- U at the face quadrature points, both sides
+  double u1[C::FQ_ROUNDS][NEQ], u2[C::FQ_ROUNDS][NEQ];
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const double *T = side ? sT2 : sT1;
+    interp_stage1<C, NEQ>(T, sW, tab, tid);
+    if (DIM == 3) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < C::FQ_ROUNDS; r++) {
+      const int item = tid + r * C::BLOCK;
+      if (item < C::FQ_ITEMS) {
+        const int lf = item / C::NQ, q = item - lf * C::NQ;
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) {
+          const double v = interp_stage2<C>(T + eq * C::FN_ITEMS, sW + eq * C::FW_ITEMS, tab, lf, q);
+          if (side)
+            u2[r][eq] = v;
+          else
+            u1[r][eq] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- numerical flux at the face quadrature points (sT1/sT2 dead: region B becomes sQ)
+#pragma unroll
   for (int r = 0; r < C::FQ_ROUNDS; r++) {
     const int item = tid + r * C::BLOCK;
     if (item >= C::FQ_ITEMS) continue;
@@ -681,47 +797,39 @@ __global__ __launch_bounds__(C::BLOCK) void k_flux(MeshDev m, typename PH::Param
     if (e >= m.ne) continue;
     const int slot = e * C::NFACES + it.f;
     const int nb = m.face_nbr[slot];
-    const int fbase = (it.le * C::NFACES + it.f) * C::NF;
-    double u1[NEQ], u2[NEQ], fh[NEQ];
-#pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) u1[eq] = face_interp<C>(&sT1[eq][fbase], tab, it.idx);
-    PH::clamp_species(u1);
+    double fh[NEQ];
+    PH::clamp_species(u1[r]);
     double n[DIM], wq, X[DIM];
-    face_geometry<C>(sV[it.le], tab, it.f, it.idx, n, wq, X);
+    face_geometry<C>(&sV[it.le * C::NV * DIM], tab, it.f, it.idx, n, wq, X);
     const double *tb_own = TB + static_cast<int64_t>(slot) * (NEQ * C::NQ) + it.idx;
     if (nb >= 0) {
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) u2[eq] = face_interp<C>(&sT2[eq][fbase], tab, it.idx);
-      PH::clamp_species(u2);
-      PH::lax_friedrichs(prm, u1, u2, n, fh);
+      PH::clamp_species(u2[r]);
+      PH::lax_friedrichs(prm, u1[r], u2[r], n, fh);
       const int o = m.face_orient[slot];
       const int pq = permute<DIM>(o, C::Q1, it.idx % C::Q1, it.idx / C::Q1);
       const double *tb_nb = TB + static_cast<int64_t>(nb) * (NEQ * C::NQ) + pq;
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fh[eq] -= 0.5 * (tb_own[eq * C::NQ] - tb_nb[eq * C::NQ]);
     } else {
-      PH::bc_ghost(prm, prm.bc[-nb - 1], u1, n, u2);
-      PH::lax_friedrichs(prm, u1, u2, n, fh);
+      double ug[NEQ];
+      PH::bc_ghost(prm, prm.bc[-nb - 1], u1[r], n, ug);
+      PH::lax_friedrichs(prm, u1[r], ug, n, fh);
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fh[eq] += tb_own[eq * C::NQ];
     }
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) sQ[eq][item] = fh[eq] * wq;
+    for (int eq = 0; eq < NEQ; eq++) sQ[eq * C::FQ_ITEMS + item] = fh[eq] * wq;
   }
   __syncthreads();
-  for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
-    const FaceItem it = face_item<C>(item, C::NF);
-    if (e0 + it.le >= m.ne) continue;
-    const int qbase = (it.le * C::NFACES + it.f) * C::NQ;
-#pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) sL[eq][item] = face_project<C>(&sQ[eq][qbase], tab, it.idx);
-  }
+  project_stage1<C, NEQ>(sQ, sW, tab, tid);
+  if (DIM == 3) __syncthreads();
+  project_stage2<C, NEQ>(sQ, sW, sL, tab, tid);
   __syncthreads();
   if (node_on) {
     const int64_t n = static_cast<int64_t>(e0 + le_n) * C::NPE + nd;
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) {
-      const double lift = face_lift<C>(&sL[eq][le_n * C::NFACES * C::NF], tab, idx);
+      const double lift = face_lift<C>(&sL[eq * C::FN_ITEMS + le_n * C::NFACES * C::NF], tab, idx);
       Y[n + eq * m.ndofs] = inv_mass * (z[eq] - lift) + src[eq];
     }
   }
