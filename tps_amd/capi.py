@@ -163,7 +163,7 @@ class MeshArgs:
 
 # ------------------------------------------------------------------------------------------
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtpsrhs.so")
+LIB_PATH = os.environ.get("TPSRHS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtpsrhs.so")
 
 
 class LibraryMissing(RuntimeError):

@@ -24,7 +24,7 @@ struct BcDev {
 constexpr int MAXBC = 16;
 
 struct DryAirParams {
-  double gamma, Rg, visc_mult, bulk_mult, C1, S0, cp_div_pr;
+  double gamma, Rg, inv_Rg, visc_mult, bulk_mult, C1, S0, cp_div_pr;
   int eq_system;  // tpsrhs_equations
   int use_bc_in_grad;
   int num_bcs;
@@ -40,89 +40,96 @@ struct DryAirPhys {
   static constexpr bool HAS_SOURCE = false;
   typedef DryAirParams Params;
 
-  __device__ static inline double pressure(const Params &p, const double *U) {
-    double k = 0.0;
+  // One reciprocal of the density per state; everything else multiplies by it (the reference
+  // divides by state[0] in every routine; the results differ in the last bit only).
+  struct State {
+    double ir;         // 1/rho
+    double k;          // |rho u|^2 / rho
+    double p;          // pressure
+    double vel[NVEL];  // u
+  };
+  __device__ static inline State make_state(const Params &p, const double *U) {
+    State s;
+    s.ir = 1.0 / U[0];
+    double m2 = 0.0;
 #pragma unroll
-    for (int d = 0; d < NVEL; d++) k += U[1 + d] * U[1 + d];
-    k /= U[0];
-    return (p.gamma - 1.0) * (U[1 + NVEL] - 0.5 * k);
+    for (int d = 0; d < NVEL; d++) {
+      m2 += U[1 + d] * U[1 + d];
+      s.vel[d] = U[1 + d] * s.ir;
+    }
+    s.k = m2 * s.ir;
+    s.p = (p.gamma - 1.0) * (U[1 + NVEL] - 0.5 * s.k);
+    return s;
   }
+
+  __device__ static inline double pressure(const Params &p, const double *U) { return make_state(p, U).p; }
 
   // GetPrimitivesFromConservatives, src/equation_of_state.cpp:321-335
   __device__ static inline void prim(const Params &p, const double *U, double *Up) {
-    double k = 0.0;
-#pragma unroll
-    for (int d = 0; d < NVEL; d++) k += U[1 + d] * U[1 + d];
-    k /= U[0];
-    const double T = (p.gamma - 1.0) / p.Rg * (U[1 + NVEL] - 0.5 * k) / U[0];
+    const State s = make_state(p, U);
     Up[0] = U[0];
 #pragma unroll
-    for (int d = 0; d < NVEL; d++) Up[1 + d] = U[1 + d] / U[0];
-    Up[1 + NVEL] = T;
+    for (int d = 0; d < NVEL; d++) Up[1 + d] = s.vel[d];
+    Up[1 + NVEL] = s.p * p.inv_Rg * s.ir;
   }
 
   __device__ static inline void clamp_species(double *) {}
 
   // ComputeMaxCharSpeed, src/equation_of_state.cpp:278-292
+  __device__ static inline double max_char_speed(const Params &p, const double *U, const State &s) {
+    return sqrt(s.k * s.ir) + sqrt(p.gamma * s.p * s.ir);
+  }
   __device__ static inline double max_char_speed(const Params &p, const double *U) {
-    double k = 0.0;
-#pragma unroll
-    for (int d = 0; d < NVEL; d++) k += U[1 + d] * U[1 + d];
-    k /= U[0];
-    const double pres = (p.gamma - 1.0) * (U[1 + NVEL] - 0.5 * k);
-    return sqrt(k / U[0]) + sqrt(p.gamma * pres / U[0]);
+    return max_char_speed(p, U, make_state(p, U));
   }
 
   // F(U).n, src/fluxes.cpp:135-170 contracted with n as in RiemannSolverTPS::ComputeFluxDotN
-  __device__ static inline void conv_flux_n(const Params &p, const double *U, const double *n, double *Fn) {
-    const double pres = pressure(p, U);
-    double mn = 0.0;  // rho u . n
+  __device__ static inline void conv_flux_n(const Params &p, const double *U, const State &s, const double *n,
+                                            double *Fn) {
+    double un = 0.0;
 #pragma unroll
-    for (int d = 0; d < DIM; d++) mn += U[1 + d] * n[d];
-    const double un = mn / U[0];
-    Fn[0] = mn;
+    for (int d = 0; d < DIM; d++) un += s.vel[d] * n[d];
+    Fn[0] = U[0] * un;
 #pragma unroll
-    for (int i = 0; i < NVEL; i++) Fn[1 + i] = U[1 + i] * un + (i < DIM ? pres * n[i] : 0.0);
-    Fn[1 + NVEL] = un * (U[1 + NVEL] + pres);
+    for (int i = 0; i < NVEL; i++) Fn[1 + i] = U[1 + i] * un + (i < DIM ? s.p * n[i] : 0.0);
+    Fn[1 + NVEL] = un * (U[1 + NVEL] + s.p);
   }
 
   // full convective flux tensor F[eq + d*NEQ]
-  __device__ static inline void conv_flux(const Params &p, const double *U, double *F) {
-    const double pres = pressure(p, U);
-    const double H = (U[1 + NVEL] + pres) / U[0];
+  __device__ static inline void conv_flux(const Params &p, const double *U, const State &s, double *F) {
+    const double H = U[1 + NVEL] + s.p;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
       F[0 + d * NEQ] = U[1 + d];
 #pragma unroll
-      for (int i = 0; i < NVEL; i++) F[1 + i + d * NEQ] = U[1 + i] * U[1 + d] / U[0];
-      F[1 + d + d * NEQ] += pres;
-      F[1 + NVEL + d * NEQ] = U[1 + d] * H;
+      for (int i = 0; i < NVEL; i++) F[1 + i + d * NEQ] = U[1 + i] * s.vel[d];
+      F[1 + d + d * NEQ] += s.p;
+      F[1 + NVEL + d * NEQ] = s.vel[d] * H;
     }
   }
 
   // Lax-Friedrichs flux with the area-weighted normal, src/riemann_solver.cpp:89-115
   __device__ static inline void lax_friedrichs(const Params &p, const double *U1, const double *U2, const double *n,
                                                double *F) {
-    const double l1 = max_char_speed(p, U1), l2 = max_char_speed(p, U2);
-    const double lam = fmax(l1, l2);
+    const State s1 = make_state(p, U1), s2 = make_state(p, U2);
+    const double lam = fmax(max_char_speed(p, U1, s1), max_char_speed(p, U2, s2));
     double f1[NEQ], f2[NEQ];
-    conv_flux_n(p, U1, n, f1);
-    conv_flux_n(p, U2, n, f2);
+    conv_flux_n(p, U1, s1, n, f1);
+    conv_flux_n(p, U2, s2, n, f2);
     double nm = 0.0;
 #pragma unroll
     for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
-    nm = sqrt(nm);
+    const double hl = 0.5 * lam * sqrt(nm);
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) F[eq] = 0.5 * (f1[eq] + f2[eq]) - 0.5 * lam * (U2[eq] - U1[eq]) * nm;
+    for (int eq = 0; eq < NEQ; eq++) F[eq] = 0.5 * (f1[eq] + f2[eq]) - hl * (U2[eq] - U1[eq]);
   }
 
   struct Transport {
     double visc, bulk, k;  // bulk already has -2/3 visc applied
   };
   // DryAirTransport::ComputeFluxMolecularTransport, src/transport_properties.cpp:224-266
-  __device__ static inline Transport transport(const Params &p, const double *U) {
-    const double pres = pressure(p, U);
-    const double T = pres / p.Rg / U[0];
+  __device__ static inline Transport transport(const Params &p, const State &s) {
+    const double T = s.p * p.inv_Rg * s.ir;
     Transport t;
     t.visc = p.C1 * p.visc_mult * (T * sqrt(T)) / (T + p.S0);
     t.bulk = p.bulk_mult * t.visc - 2.0 / 3.0 * t.visc;
@@ -131,11 +138,12 @@ struct DryAirPhys {
   }
 
   // ComputeViscousFluxes, src/fluxes.cpp:178-335; g[eq + d*NEQ] = d(Up_eq)/dx_d; F[eq + d*NEQ]
-  __device__ static inline void visc_flux(const Params &p, const double *U, const double *g, double *F) {
+  __device__ static inline void visc_flux(const Params &p, const double *U, const State &s, const double *g,
+                                          double *F) {
 #pragma unroll
     for (int i = 0; i < NEQ * DIM; i++) F[i] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
-    const Transport t = transport(p, U);
+    const Transport t = transport(p, s);
     double divV = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
@@ -150,30 +158,72 @@ struct DryAirPhys {
     for (int i = 0; i < DIM; i++)
 #pragma unroll
       for (int j = 0; j < DIM; j++) F[(1 + i) + j * NEQ] = stress[i + j * DIM];
-    double vel[DIM];
-#pragma unroll
-    for (int d = 0; d < DIM; d++) vel[d] = U[1 + d] / U[0];
 #pragma unroll
     for (int i = 0; i < DIM; i++) {
       double vt = 0.0;
 #pragma unroll
-      for (int j = 0; j < DIM; j++) vt += stress[i + j * DIM] * vel[j];
+      for (int j = 0; j < DIM; j++) vt += stress[i + j * DIM] * s.vel[j];
       F[(1 + NVEL) + i * NEQ] = vt + t.k * g[(1 + NVEL) + i * NEQ];
     }
   }
+  __device__ static inline void visc_flux(const Params &p, const double *U, const double *g, double *F) {
+    visc_flux(p, U, make_state(p, U), g, F);
+  }
 
-  // F_v(U, g) . n
+  // (F_c - F_v)(U, g) . a for an arbitrary vector a (a row of the metric adjugate at a node, or a
+  // normal): the register-lean form of ComputeConvectiveFluxes minus ComputeViscousFluxes
+  // (src/rhs_operator.cpp:532-541) -- no flux tensor is materialised.
+  __device__ static inline void total_flux_dot(const Params &p, const double *U, const State &s, const Transport &t,
+                                               double divV, const double *g, const double *a, double *Fa) {
+    double ua = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) ua += s.vel[d] * a[d];
+    Fa[0] = U[0] * ua;
+    double e = ua * (U[1 + NVEL] + s.p);
+    if (p.eq_system == TPSRHS_EULER) {
+#pragma unroll
+      for (int i = 0; i < NVEL; i++) Fa[1 + i] = U[1 + i] * ua + (i < DIM ? s.p * a[i] : 0.0);
+      Fa[1 + NVEL] = e;
+      return;
+    }
+    double qa = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) {
+      double sa = 0.0;  // sum_d a_d (d_d u_i + d_i u_d)
+#pragma unroll
+      for (int d = 0; d < DIM; d++) sa += (g[(1 + i) + d * NEQ] + g[(1 + d) + i * NEQ]) * a[d];
+      sa = t.visc * sa + t.bulk * divV * a[i];
+      Fa[1 + i] = U[1 + i] * ua + s.p * a[i] - sa;
+      e -= sa * s.vel[i];
+      qa += g[(1 + NVEL) + i * NEQ] * a[i];
+    }
+    Fa[1 + NVEL] = e - t.k * qa;
+  }
+  static constexpr bool HAS_FLUX_DOT = true;
+
+  // F_v(U, g) . n without forming the tensor
   __device__ static inline void visc_flux_n(const Params &p, const double *U, const double *g, const double *n,
                                             double *Fn) {
-    double F[NEQ * DIM];
-    visc_flux(p, U, g, F);
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) {
-      double s = 0.0;
+    for (int eq = 0; eq < NEQ; eq++) Fn[eq] = 0.0;
+    if (p.eq_system == TPSRHS_EULER) return;
+    const State s = make_state(p, U);
+    const Transport t = transport(p, s);
+    double divV = 0.0;
 #pragma unroll
-      for (int d = 0; d < DIM; d++) s += F[eq + d * NEQ] * n[d];
-      Fn[eq] = s;
+    for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
+    double e = 0.0, qn = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) {
+      double sn = 0.0;  // (stress . n)_i
+#pragma unroll
+      for (int j = 0; j < DIM; j++) sn += (g[(1 + j) + i * NEQ] + g[(1 + i) + j * NEQ]) * n[j];
+      sn = t.visc * sn + t.bulk * divV * n[i];
+      Fn[1 + i] = sn;
+      e += sn * s.vel[i];
+      qn += g[(1 + NVEL) + i * NEQ] * n[i];
     }
+    Fn[1 + NVEL] = e + t.k * qn;
   }
 
   // ComputeBdrViscousFluxes with zero prescribed species flux and, when `adiabatic`, zero heat
@@ -183,7 +233,8 @@ struct DryAirPhys {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) Fn[eq] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
-    const Transport t = transport(p, Uw);
+    const State sw = make_state(p, Uw);
+    const Transport t = transport(p, sw);
     double divV = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
@@ -208,7 +259,7 @@ struct DryAirPhys {
 #pragma unroll
     for (int d = 0; d < NVEL; d++) {
       Fn[1 + d] = sn[d];
-      e += sn[d] * (Uw[1 + d] / Uw[0]);
+      e += sn[d] * sw.vel[d];
     }
     Fn[1 + NVEL] = e;
   }

@@ -227,6 +227,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   std::memset(&d, 0, sizeof(d));
   d.gamma = phys->dry_air.specific_heat_ratio;
   d.Rg = phys->dry_air.gas_constant;
+  d.inv_Rg = 1.0 / d.Rg;
   d.visc_mult = phys->dry_air.visc_mult;
   d.bulk_mult = phys->dry_air.bulk_visc_mult;
   d.C1 = phys->dry_air.sutherland_C1;
