@@ -1,0 +1,114 @@
+"""Pins of the CPU oracle (no GPU): the reference's own known answers and the structural invariants
+of the discretisation.  The oracle is test infrastructure; nothing here touches the
+product path."""
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle
+from tps_amd import capi, cases, meshgen
+
+
+def test_gradient_test_error_windows():
+    """reference test/gradient.test:30-46 + test/test_gradient.cpp:61-87,228-238: sine field on the
+    160x160 periodic 5x5 quad mesh, p=2, GLL basis, GLL rule; relative L2 error of d(rho)/dx must lie
+    in [2.295e-4, 2.305e-4] (kx=2) and of d(rho)/dy in [5.74e-5, 5.75e-5] (ky=1)."""
+    m = meshgen.box_quad(160, 160, lengths=(5.0, 5.0))
+    o = Oracle(m, capi.Disc(2, 1, 1, 0, 0), capi.dry_air_physics(capi.NS))
+    X = o.node_coords()
+    rng = np.random.default_rng(2024)
+    L, kx = np.array([5.0, 5.0]), np.array([2, 1])
+    Up = np.zeros((o.neq, o.ndofs))
+    ex = np.zeros((2, o.neq, o.ndofs))
+    for eq in range(o.neq):
+        up0 = 1.0 + rng.random()
+        Up[eq] = up0
+        for d in range(2):
+            dup, off = 0.1 * up0 / 2 * rng.random(), rng.random()
+            Up[eq] += dup * np.sin(2 * np.pi * kx[d] * (X[d] / L[d] - off))
+            ex[d, eq] = dup * 2 * np.pi * kx[d] / L[d] * np.cos(2 * np.pi * kx[d] * (X[d] / L[d] - off))
+    g = o.compute_gradients(Up)
+    e0 = o.l2_norm(g[0, 0], ex[0, 0]) / o.l2_norm(g[0, 0])
+    e1 = o.l2_norm(g[1, 0], ex[1, 0]) / o.l2_norm(g[1, 0])
+    assert 2.295e-4 < e0 < 2.305e-4, e0  # "empirically observed error 2.2988e-4"
+    assert 5.74e-5 < e1 < 5.75e-5, e1  # "empirically observed error 5.7471e-5"
+    assert abs(e0 - 2.2988e-4) < 1e-8 and abs(e1 - 5.7471e-5) < 1e-9
+
+
+@pytest.mark.parametrize("basis,rule", [(0, 0), (1, 1), (0, 1)])
+def test_gradient_exact_for_polynomials(basis, rule):
+    m = meshgen.scramble_orientations(meshgen.box_hex(3, 3, 3, periodic=(False, False, False)), 3)
+    bcs = [capi.make_bc(a, capi.WALL, capi.INV) for a in range(1, 7)]
+    o = Oracle(m, capi.Disc(2, basis, rule, 0, 0), capi.dry_air_physics(capi.NS), bcs)
+    X = o.node_coords()
+    Up = np.zeros((5, o.ndofs))
+    Up[0] = 1 + X[0] ** 2 + X[1] * X[2]
+    Up[1] = X[0] * X[1]
+    Up[2] = X[2] ** 2
+    Up[3] = 1.0
+    Up[4] = X[0] + 2 * X[1] + 3 * X[2]
+    g = o.compute_gradients(Up)
+    assert np.abs(g[0, 0] - 2 * X[0]).max() < 1e-12
+    assert np.abs(g[1, 0] - X[2]).max() < 1e-12
+    assert np.abs(g[2, 0] - X[1]).max() < 1e-12
+    assert np.abs(g[:, 3]).max() < 1e-12
+    assert np.abs(g[2, 4] - 3).max() < 1e-12
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_free_stream_preservation_and_conservation(dim):
+    """uniform state => Mult = 0; smooth state on a periodic mesh => sum_e 1^T M_e y_e = 0."""
+    if dim == 3:
+        m = meshgen.scramble_orientations(meshgen.box_hex(3, 4, 3, lengths=(1, 1.3, 0.9), warp=0.15), 7)
+    else:
+        m = meshgen.scramble_orientations(meshgen.box_quad(5, 4, lengths=(1, 1.3), warp=0.15), 7)
+    o = Oracle(m, capi.Disc(2, 0, 0, 0, 0), capi.dry_air_physics(capi.NS, visc_mult=1000.0))
+    N = o.ndofs
+    rho, vel, p = 1.2, np.array([20.0, 5.0, -3.0])[:dim], 101300.0
+    U = np.zeros((dim + 2, N))
+    U[0] = rho
+    for d in range(dim):
+        U[1 + d] = rho * vel[d]
+    U[dim + 1] = p / 0.4 + 0.5 * rho * (vel**2).sum()
+    y = o.mult(U)
+    h = 0.25
+    flux_scale = np.array([rho * 20] + [rho * 400 + p] * dim + [20 * (U[dim + 1, 0] + p)]) / h
+    assert np.all(np.abs(y).max(axis=1) < 1e-11 * flux_scale)
+    assert abs(o.max_char_speed - (np.linalg.norm(vel) + np.sqrt(1.4 * p / rho))) < 1e-10
+    U = cases.dry_air_state(o.node_coords(), seed=4)
+    y = o.mult(U)
+    for eq in range(dim + 2):
+        assert abs(o.integral(y[eq])) < 1e-10 * np.abs(y[eq]).max()
+
+
+def test_boundary_viscous_flux_identity():
+    """reference test/test_boundary_flux.cpp:88-166: with nothing prescribed,
+    ComputeBdrViscousFluxes == ComputeViscousFluxes . n to rel 5e-13 on random states."""
+    m = meshgen.box_hex(3, 3, 3)
+    o = Oracle(m, capi.Disc(1, 0, 0, 0, 0), capi.dry_air_physics(capi.NS, visc_mult=3.0, bulk_visc_mult=0.7))
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        prim = np.array([1.0 + rng.random(), *(50 * (rng.random(3) - 0.5)), 250 + 100 * rng.random()])
+        U = o.cons(prim)
+        assert np.abs(o.prim(U) - prim).max() < 1e-13 * np.abs(prim).max()
+        g = rng.standard_normal((3, 5))
+        n = rng.standard_normal(3)
+        n /= np.linalg.norm(n)
+        fv = o.viscous_flux(U, g)
+        ref = (fv * n[:, None]).sum(axis=0)
+        got = o.bdr_viscous_flux(U, g, n)
+        assert np.abs(got - ref).max() < 5e-13 * np.abs(ref).max()
+
+
+def test_lax_friedrichs_consistency_and_wall_ghosts():
+    c = cases.cyl3d(3, 8, 3, 1, capi.NS, capi.VISC_ISOTH)
+    o = Oracle(c.mesh, c.disc, c.physics, c.bcs)
+    U = o.cons(np.array([1.1, 30.0, -4.0, 2.0, 310.0]))
+    n = np.array([0.3, -0.2, 0.5])
+    # F^(U, U, n) = F(U).n
+    assert np.abs(o.lf(U, U, n) - (o.convective_flux(U) * n[:, None]).sum(axis=0)).max() < 1e-9
+    # isothermal wall, zero gradients: mass flux through the wall = Rusanov dissipation only
+    f = o.bdr_flux(3, n, U, np.zeros((3, 5)))
+    assert np.all(np.isfinite(f))
+    # subsonic outlet keeps density and momentum of the interior state in the ghost
+    fo = o.bdr_flux(2, n, U, np.zeros((3, 5)))
+    assert np.all(np.isfinite(fo))
