@@ -8,14 +8,18 @@
 //   k_flux     U + gradUp + neighbour traces -> y                   (src/face_integrator.cpp:194-352, src/BCintegrator.cpp:295-441,
 //                                                                     src/rhs_operator.cpp:493-559, src/domain_integrator.cpp:45-99,
 //                                                                     src/rhs_operator.cpp:432-461)
-// A workgroup owns EPB whole elements (one lane per node; one 64-lane wave per hex at p=3), keeps
-// their nodal fields in LDS, and applies the element-independent 1-D operators (differentiation
-// matrix, end-point values, node -> face-quadrature interpolation) by sum factorisation out of a
-// 0.5 KB LDS table; two-dimensional face operators are factorised in two lane-parallel stages
-// through LDS.  Geometry (Jacobians, area-weighted normals) is recomputed from the 2^dim vertex
-// coordinates of the element: 192 B per hex instead of 10 doubles per node.
-// LDS is one hand-allocated pool whose regions are re-used as fields die, so that 7-8 single-wave
-// workgroups fit a CU at p=3.
+//
+// Mapping to the hardware.  A workgroup owns EPB whole elements, one lane per node: one 64-lane wave
+// per hex at p=3.  Nodal fields live in LDS.  The element-independent 1-D operators (differentiation
+// matrix, end-point values, node -> face-quadrature interpolation) are applied by sum factorisation.
+// Face work is done one reference direction at a time (the two opposite faces xi_d = 0, 1), in
+// "line" stages: a lane takes one line of N1 (or Q1) values out of LDS, produces all Q1 (or N1)
+// outputs of that line in registers and writes them back -- every table coefficient is a compile
+// time index into __constant__ memory, i.e. a scalar operand, and each LDS value is read once per
+// line instead of once per output.  Geometry (Jacobians, area-weighted normals) is recomputed from
+// the 2^dim vertex coordinates of the element: 192 B per hex instead of 10 doubles per node.
+// LDS is one hand-allocated pool whose regions are re-used as fields die (10-18 KB per hex at p=3),
+// so that 8-14 single-wave workgroups are resident per CU and hide each other's latencies.
 #ifndef TPSRHS_KERNELS_HPP_
 #define TPSRHS_KERNELS_HPP_
 
@@ -25,19 +29,30 @@
 
 namespace tpsrhs {
 
-#ifndef TPSRHS_MINW
-#define TPSRHS_MINW 1
+#ifndef TPSRHS_MINW_GRAD
+#define TPSRHS_MINW_GRAD 1
+#endif
+#ifndef TPSRHS_MINW_FLUX
+#define TPSRHS_MINW_FLUX 1
 #endif
 #ifndef TPSRHS_ABLATE
-#define TPSRHS_ABLATE 0  // timing experiments only (wrong results): 1 no trace reads, 2 no nodal physics, 4 no face physics
+#define TPSRHS_ABLATE 0  // timing experiments only (wrong results)
 #endif
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// 1-D operator tables of every (dim, order), filled by tpsrhs_create.  Identical for all operators of
+// a process (they depend on (dim, p) only).  Indexed with compile-time constants they are scalar loads.
+__constant__ Tables1D c_tab[2][TPSRHS_MAXORDER + 1];
 
 // LDS read of one double.  hipcc fuses neighbouring 8-byte LDS loads into ds_read2_b64, which the
 // LDS serves at half to a quarter of the ds_read_b64 rate on gfx950 (MI355X_MICROARCH.md, LDS
 // table: 8-16 cycles per wave-instruction against 2).  A volatile access is never fused.
 typedef const volatile __attribute__((address_space(3))) double *lds_cvptr;
+#ifdef TPSRHS_PLAIN_LDS
+__device__ inline double ldsr(const double *p) { return *p; }
+#else
 __device__ inline double ldsr(const double *p) { return *(lds_cvptr)(p); }
+#endif
 
 // Nodal field access fld[k*stride + n]: the field base is wave-uniform (SGPR pair) and the lane offset
 // 32-bit, so that every load/store uses the scalar-base addressing form and no 64-bit per-lane
@@ -49,30 +64,25 @@ template <int DIM_, int P_>
 struct Cfg {
   static constexpr int DIM = DIM_, P = P_, N1 = P_ + 1;
   static constexpr int NPE = (DIM_ == 3) ? N1 * N1 * N1 : N1 * N1;
-  static constexpr int NF = (DIM_ == 3) ? N1 * N1 : N1;
+  static constexpr int NF = (DIM_ == 3) ? N1 * N1 : N1;  // nodes of a face = lines through the element
   static constexpr int Q1 = ((DIM_ - 1) + 2 * P_) / 2 + 1;
   static constexpr int NQ = (DIM_ == 3) ? Q1 * Q1 : Q1;
   static constexpr int NW = (DIM_ == 3) ? Q1 * N1 : 1;  // half-interpolated face values (3-D only)
   static constexpr int NFACES = 2 * DIM_;
   static constexpr int NV = 1 << DIM_;
-  // Elements per block and block size: enough lanes that the face-quadrature loop of a block is a
-  // single round (no per-round register arrays) while several waves share one LDS pool -> more
-  // resident waves per CU to hide the HBM latency of the trace reads.
-  static constexpr int EPB = (DIM_ == 3) ? (P_ == 1 ? 4 : (P_ == 2 ? 2 : 1)) : cmax(1, 64 / NPE);
-  static constexpr int FQ_RAW = EPB * 2 * DIM_ * NQ;
-  static constexpr int BLOCK = cmax(64, ((cmax(FQ_RAW, EPB * NPE) + 63) / 64) * 64) > 256
-                                   ? 256
-                                   : cmax(64, ((cmax(FQ_RAW, EPB * NPE) + 63) / 64) * 64);
-  static constexpr int MINW = TPSRHS_MINW;  // launch-bounds waves per SIMD (register cap)
-  static constexpr int NODES = EPB * NPE;  // active lanes in node loops
-  static constexpr int LF = EPB * NFACES;  // local faces per block
-  static constexpr int FN_ITEMS = LF * NF;
-  static constexpr int FQ_ITEMS = LF * NQ;
-  static constexpr int FW_ITEMS = LF * NW;
-  static constexpr int FQ_ROUNDS = (FQ_ITEMS + BLOCK - 1) / BLOCK;
+  static constexpr int BLOCK = (NPE <= 64) ? 64 : ((NPE <= 128) ? 128 : 256);
+  static constexpr int EPB = (DIM_ == 3 && P_ == 1) ? 4 : BLOCK / NPE;  // elements per block
+  static constexpr int NODES = EPB * NPE;
+  // one direction pair (faces 2d, 2d+1) of a block
+  static constexpr int PF = 2 * EPB;
+  static constexpr int TN = PF * NF;
+  static constexpr int TW = PF * NW;
+  static constexpr int TQ = PF * NQ;
+  static constexpr int LN = EPB * NF;
+  static constexpr int Q_ROUNDS = (TQ + BLOCK - 1) / BLOCK;
 };
 
-// compact LDS copy of the 1-D tables of one order
+// LDS copy of the tables that are indexed per lane
 template <class C>
 struct Tab {
   double x[C::N1], w[C::N1], iw[C::N1], D[C::N1 * C::N1], b0[C::N1], b1[C::N1];
@@ -85,24 +95,20 @@ struct MeshDev {
   const double *verts;         // [ne][NV][DIM] lexicographic corners
   const int32_t *face_nbr;     // [ne*NFACES]
   const uint8_t *face_orient;  // [ne*NFACES]
-  const Tables1D *tables;      // device copy
 };
 
 // ---------------------------------------------------------------------------------------------
-// index helpers
 template <class C>
-__device__ inline int stride_of(int d) {
+__device__ constexpr int stride_of(int d) {
   return d == 0 ? 1 : (d == 1 ? C::N1 : C::N1 * C::N1);
 }
 template <class C>
-__device__ inline void tangential(int d, int &a, int &b) {
-  if (C::DIM == 2) {
-    a = 1 - d;
-    b = -1;
-  } else {
-    a = (d == 0) ? 1 : 0;
-    b = (d == 2) ? 1 : 2;
-  }
+__device__ constexpr int tan_a(int d) {
+  return (C::DIM == 2) ? 1 - d : ((d == 0) ? 1 : 0);
+}
+template <class C>
+__device__ constexpr int tan_b(int d) {
+  return (d == 2) ? 1 : 2;
 }
 // permutation of a tangential index pair under an orientation code (n symmetric points per
 // direction): my (ia, ib) -> neighbour's flat index
@@ -168,33 +174,18 @@ __device__ inline double adjugate(const double *J, double *A) {
   }
 }
 
-// a face item decoded from a flat id: local face lf = le*NFACES + f and index inside the face
-struct FaceItem {
-  int le, f, lf, idx;
-};
-template <class C>
-__device__ inline FaceItem face_item(int item, int per) {
-  FaceItem r;
-  r.lf = item / per;
-  r.idx = item - r.lf * per;
-  r.le = r.lf / C::NFACES;
-  r.f = r.lf - r.le * C::NFACES;
-  return r;
-}
-
-// Area-weighted outward normal at face quadrature point q of local face f, from the face's own
-// corner coordinates: on a multilinear element the two tangents of a face are linear in the other
+// Area-weighted outward normal at face quadrature point q of face (D, s), from the face's own corner
+// coordinates: on a multilinear element the two tangents of a face are linear in the other
 // tangential coordinate, so n = +-(dx/dta x dx/dtb) costs two lerps and a cross product
 // (CalcOrtho of the face Jacobian, src/face_integrator.cpp:323).  X = position (2-D only).
-template <class C>
-__device__ inline void face_geometry(const double *V, const Tab<C> &tab, int f, int q, double *n, double &wq,
+template <class C, int D>
+__device__ inline void face_geometry(const double *V, const Tab<C> &tab, int s, int q, double *n, double &wq,
                                      double *X) {
-  const int d = f >> 1, s = f & 1;
   if (C::DIM == 2) {
-    const int a = 1 - d;
-    const int c0 = (s << d), c1 = (s << d) | (1 << a);
+    constexpr int a = 1 - D;
+    const int c0 = (s << D), c1 = (s << D) | (1 << a);
     const double tx = V[c1 * 2 + 0] - V[c0 * 2 + 0], ty = V[c1 * 2 + 1] - V[c0 * 2 + 1];
-    const double sg = (s ? 1.0 : -1.0) * (d == 0 ? 1.0 : -1.0);
+    const double sg = (s ? 1.0 : -1.0) * (D == 0 ? 1.0 : -1.0);
     n[0] = sg * ty;
     n[1] = -sg * tx;
     wq = tab.wq[q];
@@ -202,11 +193,11 @@ __device__ inline void face_geometry(const double *V, const Tab<C> &tab, int f, 
     X[0] = V[c0 * 2 + 0] + t * tx;
     X[1] = V[c0 * 2 + 1] + t * ty;
   } else {
-    const int a = (d == 0) ? 1 : 0, b = (d == 2) ? 1 : 2;
+    constexpr int a = tan_a<C>(D), b = tan_b<C>(D);
     const int qa = q % C::Q1, qb = q / C::Q1;
     const double ta = tab.xq[qa], tb = tab.xq[qb];
     wq = tab.wq[qa] * tab.wq[qb];
-    const int c00 = (s << d), c10 = c00 | (1 << a), c01 = c00 | (1 << b), c11 = c10 | (1 << b);
+    const int c00 = (s << D), c10 = c00 | (1 << a), c01 = c00 | (1 << b), c11 = c10 | (1 << b);
     double va[3], vb[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -215,139 +206,159 @@ __device__ inline void face_geometry(const double *V, const Tab<C> &tab, int f, 
       va[i] = ea0 + tb * (ea1 - ea0);
       vb[i] = eb0 + ta * (eb1 - eb0);
     }
-    const double sg = (s ? 1.0 : -1.0) * (d == 1 ? -1.0 : 1.0);
+    const double sg = (s ? 1.0 : -1.0) * (D == 1 ? -1.0 : 1.0);
     n[0] = sg * (va[1] * vb[2] - va[2] * vb[1]);
     n[1] = sg * (va[2] * vb[0] - va[0] * vb[2]);
     n[2] = sg * (va[0] * vb[1] - va[1] * vb[0]);
   }
 }
 
-// trace at face node (f, fn) of nodal field F (LDS, NPE values of one element): sum_i b_s(i) F[...]
-template <class C>
-__device__ inline double face_trace(const double *F, const Tab<C> &tab, int f, int fn) {
-  const int d = f >> 1, s = f & 1;
-  int a, b;
-  tangential<C>(d, a, b);
-  int base;
-  if (C::DIM == 2) {
-    base = fn * stride_of<C>(a);
-  } else {
-    base = (fn % C::N1) * stride_of<C>(a) + (fn / C::N1) * stride_of<C>(b);
-  }
-  const int sd = stride_of<C>(d);
-  const double *bs = s ? tab.b1 : tab.b0;
-  double acc = 0.0;
+// ---------------------------------------------------------------------------------------------
+// Line stages.  Field-major LDS arrays: T[fld][TN] face nodes, W[fld][TW] half-interpolated,
+// R[fld][TQ] quadrature values, L[fld][TN] projected values; pf = 2*le + s indexes the faces of the
+// direction pair.  `ct` is the __constant__ table: all its indices below are compile-time.
+
+// traces on both faces of direction D of NFLD nodal fields F[fld][NODES]: one lane per line
+template <class C, int D, int NFLD>
+__device__ inline void trace_lines(const double *F, double *T, const Tables1D &ct, int tid) {
+  constexpr int sd = stride_of<C>(D);
+  constexpr int sa = stride_of<C>(tan_a<C>(D));
+  constexpr int sb = (C::DIM == 3) ? stride_of<C>(tan_b<C>(D)) : 0;
+  for (int item = tid; item < NFLD * C::LN; item += C::BLOCK) {
+    const int fld = item / C::LN, r = item - fld * C::LN;
+    const int le = r / C::NF, ln = r - le * C::NF;
+    const int base = le * C::NPE + ((C::DIM == 2) ? ln * sa : (ln % C::N1) * sa + (ln / C::N1) * sb);
+    const double *f = F + fld * C::NODES + base;
+    double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-  for (int i = 0; i < C::N1; i++) acc += bs[i] * ldsr(&F[base + i * sd]);
-  return acc;
+    for (int i = 0; i < C::N1; i++) {
+      const double v = ldsr(&f[i * sd]);
+      t0 += ct.b0[i] * v;
+      t1 += ct.b1[i] * v;
+    }
+    T[fld * C::TN + (2 * le) * C::NF + ln] = t0;
+    T[fld * C::TN + (2 * le + 1) * C::NF + ln] = t1;
+  }
 }
 
-// ---- two-stage face interpolation: T[fld][FN_ITEMS] -> W[fld][FW_ITEMS] -> value at a quadrature point
-// stage 1 (3-D): W[lf][qa + Q1*jb] = sum_ja B[qa][ja] T[lf][ja + N1*jb]
+// 3-D: W[fld][pf][qa*N1 + jb] = sum_ja B[qa][ja] T[fld][pf][ja + N1*jb]; one lane per (fld, pf, jb)
 template <class C, int NFLD>
-__device__ inline void interp_stage1(const double *T, double *W, const Tab<C> &tab, int tid) {
+__device__ inline void interp1_lines(const double *T, double *W, const Tables1D &ct, int tid) {
   if (C::DIM == 2) return;
-  for (int item = tid; item < C::FW_ITEMS; item += C::BLOCK) {
-    const int lf = item / C::NW, r = item - lf * C::NW;
-    const int jb = r / C::Q1, qa = r - jb * C::Q1;
-    const double *Bq = &tab.B[qa * C::N1];
-    const double *t = T + lf * C::NF + C::N1 * jb;
+  for (int item = tid; item < NFLD * C::PF * C::N1; item += C::BLOCK) {
+    const int fld = item / (C::PF * C::N1), r = item - fld * (C::PF * C::N1);
+    const int pf = r / C::N1, jb = r - pf * C::N1;
+    const double *t = T + fld * C::TN + pf * C::NF + C::N1 * jb;
+    double v[C::N1];
 #pragma unroll
-    for (int fld = 0; fld < NFLD; fld++) {
+    for (int ja = 0; ja < C::N1; ja++) v[ja] = ldsr(&t[ja]);
+    double *w = W + fld * C::TW + pf * C::NW + jb;
+#pragma unroll
+    for (int qa = 0; qa < C::Q1; qa++) {
       double acc = 0.0;
 #pragma unroll
-      for (int ja = 0; ja < C::N1; ja++) acc += Bq[ja] * ldsr(&t[fld * C::FN_ITEMS + ja]);
-      W[fld * C::FW_ITEMS + item] = acc;
+      for (int ja = 0; ja < C::N1; ja++) acc += ct.B[qa * C::N1 + ja] * v[ja];
+      w[qa * C::N1] = acc;
     }
   }
 }
-// stage 2: value of field `fld` at quadrature point (lf, q).  3-D reads W, 2-D reads T directly.
+// value of one field at quadrature point (pf, q); bq = B[qb][.] (3-D) or B[q][.] (2-D) of this lane
 template <class C>
-__device__ inline double interp_stage2(const double *T, const double *W, const Tab<C> &tab, int lf, int q) {
+__device__ inline double interp2_point(const double *T, const double *W, const double *bq, int pf, int q) {
   double acc = 0.0;
   if (C::DIM == 2) {
 #pragma unroll
-    for (int a = 0; a < C::N1; a++) acc += tab.B[q * C::N1 + a] * ldsr(&T[lf * C::NF + a]);
+    for (int a = 0; a < C::N1; a++) acc += bq[a] * ldsr(&T[pf * C::NF + a]);
   } else {
-    const int qa = q % C::Q1, qb = q / C::Q1;
+    const int qa = q % C::Q1;
+    const double *w = W + pf * C::NW + qa * C::N1;
 #pragma unroll
-    for (int jb = 0; jb < C::N1; jb++) acc += tab.B[qb * C::N1 + jb] * ldsr(&W[lf * C::NW + qa + C::Q1 * jb]);
+    for (int jb = 0; jb < C::N1; jb++) acc += bq[jb] * ldsr(&w[jb]);
   }
   return acc;
 }
-// ---- two-stage projection (transpose): R[fld][FQ_ITEMS] -> W2[fld][FW_ITEMS] -> L[fld][FN_ITEMS]
-// stage 1 (3-D): W2[lf][ja + N1*qb] = sum_qa B[qa][ja] R[lf][qa + Q1*qb]
+// 3-D: W2[fld][pf][ja*Q1 + qb] = sum_qa B[qa][ja] R[fld][pf][qa + Q1*qb]; one lane per (fld, pf, qb)
 template <class C, int NFLD>
-__device__ inline void project_stage1(const double *R, double *W2, const Tab<C> &tab, int tid) {
+__device__ inline void project1_lines(const double *R, double *W2, const Tables1D &ct, int tid) {
   if (C::DIM == 2) return;
-  for (int item = tid; item < C::FW_ITEMS; item += C::BLOCK) {
-    const int lf = item / C::NW, r = item - lf * C::NW;
-    const int qb = r / C::N1, ja = r - qb * C::N1;
-    const double *rr = R + lf * C::NQ + C::Q1 * qb;
+  for (int item = tid; item < NFLD * C::PF * C::Q1; item += C::BLOCK) {
+    const int fld = item / (C::PF * C::Q1), r = item - fld * (C::PF * C::Q1);
+    const int pf = r / C::Q1, qb = r - pf * C::Q1;
+    const double *rr = R + fld * C::TQ + pf * C::NQ + C::Q1 * qb;
+    double v[C::Q1];
 #pragma unroll
-    for (int fld = 0; fld < NFLD; fld++) {
+    for (int qa = 0; qa < C::Q1; qa++) v[qa] = ldsr(&rr[qa]);
+    double *w = W2 + fld * C::TW + pf * C::NW + qb;
+#pragma unroll
+    for (int ja = 0; ja < C::N1; ja++) {
       double acc = 0.0;
 #pragma unroll
-      for (int qa = 0; qa < C::Q1; qa++) acc += tab.B[qa * C::N1 + ja] * ldsr(&rr[fld * C::FQ_ITEMS + qa]);
-      W2[fld * C::FW_ITEMS + item] = acc;
+      for (int qa = 0; qa < C::Q1; qa++) acc += ct.B[qa * C::N1 + ja] * v[qa];
+      w[ja * C::Q1] = acc;
     }
   }
 }
+// L[fld][pf][ja + N1*jb] = sum_qb B[qb][jb] W2[fld][pf][ja*Q1 + qb] (3-D, one lane per (fld, pf, ja));
+// 2-D: L[fld][pf][ja] = sum_q B[q][ja] R[fld][pf][q] (one lane per (fld, pf))
 template <class C, int NFLD>
-__device__ inline void project_stage2(const double *R, const double *W2, double *L, const Tab<C> &tab, int tid) {
-  for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
-    const int lf = item / C::NF, fn = item - lf * C::NF;
-    if (C::DIM == 2) {
+__device__ inline void project2_lines(const double *RW, double *L, const Tables1D &ct, int tid) {
+  if (C::DIM == 2) {
+    for (int item = tid; item < NFLD * C::PF; item += C::BLOCK) {
+      const int fld = item / C::PF, pf = item - fld * C::PF;
+      const double *rr = RW + fld * C::TQ + pf * C::NQ;
+      double v[C::Q1];
 #pragma unroll
-      for (int fld = 0; fld < NFLD; fld++) {
+      for (int q = 0; q < C::Q1; q++) v[q] = ldsr(&rr[q]);
+#pragma unroll
+      for (int ja = 0; ja < C::N1; ja++) {
         double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < C::Q1; q++) acc += tab.B[q * C::N1 + fn] * ldsr(&R[fld * C::FQ_ITEMS + lf * C::NQ + q]);
-        L[fld * C::FN_ITEMS + item] = acc;
+        for (int q = 0; q < C::Q1; q++) acc += ct.B[q * C::N1 + ja] * v[q];
+        L[fld * C::TN + pf * C::NF + ja] = acc;
       }
-    } else {
-      const int ja = fn % C::N1, jb = fn / C::N1;
+    }
+  } else {
+    for (int item = tid; item < NFLD * C::PF * C::N1; item += C::BLOCK) {
+      const int fld = item / (C::PF * C::N1), r = item - fld * (C::PF * C::N1);
+      const int pf = r / C::N1, ja = r - pf * C::N1;
+      const double *w = RW + fld * C::TW + pf * C::NW + ja * C::Q1;
+      double v[C::Q1];
 #pragma unroll
-      for (int fld = 0; fld < NFLD; fld++) {
+      for (int qb = 0; qb < C::Q1; qb++) v[qb] = ldsr(&w[qb]);
+      double *l = L + fld * C::TN + pf * C::NF + ja;
+#pragma unroll
+      for (int jb = 0; jb < C::N1; jb++) {
         double acc = 0.0;
 #pragma unroll
-        for (int qb = 0; qb < C::Q1; qb++)
-          acc += tab.B[qb * C::N1 + jb] * ldsr(&W2[fld * C::FW_ITEMS + lf * C::NW + ja + C::N1 * qb]);
-        L[fld * C::FN_ITEMS + item] = acc;
+        for (int qb = 0; qb < C::Q1; qb++) acc += ct.B[qb * C::N1 + jb] * v[qb];
+        l[jb * C::N1] = acc;
       }
     }
   }
 }
-// lifting to a volume node: sum over the element's faces of b_s(idx_d) L[f][fn(node)]
-template <class C>
-__device__ inline double face_lift(const double *L, const Tab<C> &tab, const int *idx) {
-  double acc = 0.0;
-#pragma unroll
-  for (int d = 0; d < C::DIM; d++) {
-    int a, b;
-    tangential<C>(d, a, b);
-    const int fn = (C::DIM == 2) ? idx[a] : idx[a] + C::N1 * idx[b];
-    acc += tab.b0[idx[d]] * ldsr(&L[(2 * d) * C::NF + fn]) + tab.b1[idx[d]] * ldsr(&L[(2 * d + 1) * C::NF + fn]);
-  }
-  return acc;
+// lifting of the pair's two faces to a volume node: b0(idx_D) L[pf=2le] + b1(idx_D) L[pf=2le+1]
+template <class C, int D>
+__device__ inline double lift_pair(const double *Lf, const Tab<C> &tab, int le, const int *idx) {
+  const int fn = (C::DIM == 2) ? idx[tan_a<C>(D)] : idx[tan_a<C>(D)] + C::N1 * idx[tan_b<C>(D)];
+  return tab.b0[idx[D]] * ldsr(&Lf[(2 * le) * C::NF + fn]) + tab.b1[idx[D]] * ldsr(&Lf[(2 * le + 1) * C::NF + fn]);
 }
 
 template <class C>
-__device__ inline void load_tables(Tab<C> &t, const Tables1D *src) {
+__device__ inline void load_tables(Tab<C> &t, const Tables1D &src) {
   const int tid = threadIdx.x;
   if (tid < C::N1) {
-    t.x[tid] = src->x[tid];
-    t.w[tid] = src->w[tid];
-    t.iw[tid] = 1.0 / src->w[tid];
-    t.b0[tid] = src->b0[tid];
-    t.b1[tid] = src->b1[tid];
+    t.x[tid] = src.x[tid];
+    t.w[tid] = src.w[tid];
+    t.iw[tid] = 1.0 / src.w[tid];
+    t.b0[tid] = src.b0[tid];
+    t.b1[tid] = src.b1[tid];
   }
   if (tid < C::Q1) {
-    t.xq[tid] = src->xq[tid];
-    t.wq[tid] = src->wq[tid];
+    t.xq[tid] = src.xq[tid];
+    t.wq[tid] = src.wq[tid];
   }
-  for (int i = tid; i < C::N1 * C::N1; i += C::BLOCK) t.D[i] = src->D[i];
-  for (int i = tid; i < C::Q1 * C::N1; i += C::BLOCK) t.B[i] = src->B[i];
+  for (int i = tid; i < C::N1 * C::N1; i += C::BLOCK) t.D[i] = src.D[i];
+  for (int i = tid; i < C::Q1 * C::N1; i += C::BLOCK) t.B[i] = src.B[i];
 }
 template <class C>
 __device__ inline void load_vertices(double *sV, const MeshDev &m, int e0) {
@@ -357,18 +368,58 @@ __device__ inline void load_vertices(double *sV, const MeshDev &m, int e0) {
     if (e0 + le < m.ne) sV[i] = m.verts[static_cast<int64_t>(e0) * PER + i];
   }
 }
+// neighbour face-node traces of fields [f0, f0+NFLD) of the TA record -> Tnb[fld][TN], permuted into
+// my frame; boundary faces copy my own trace (already in Town[fld][TN])
+template <class C, int D, int NFLD>
+__device__ inline void load_neighbour_traces(const MeshDev &m, int e0, const double *__restrict__ TA, int rec, int f0,
+                                             const double *Town, double *Tnb, int tid) {
+  for (int item = tid; item < C::TN; item += C::BLOCK) {
+    const int pf = item / C::NF, fn = item - pf * C::NF;
+    const int le = pf >> 1, s = pf & 1;
+    const int e = e0 + le;
+    if (e >= m.ne) continue;
+    const int slot = e * C::NFACES + 2 * D + s;
+    const int nb = m.face_nbr[slot];
+    if (nb >= 0) {
+      const int pn = permute<C::DIM>(m.face_orient[slot], C::N1, fn % C::N1, fn / C::N1);
+      const double *src = TA + static_cast<int64_t>(nb) * rec + f0 * C::NF + pn;
+#pragma unroll
+      for (int k = 0; k < NFLD; k++) Tnb[k * C::TN + item] = (TPSRHS_ABLATE & 1) ? 1.0 : src[k * C::NF];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NFLD; k++) Tnb[k * C::TN + item] = ldsr(&Town[k * C::TN + item]);
+    }
+  }
+}
 
 // =============================================================================================
 // sweep 0: traces of U and Up at the face nodes.  TA[slot][2*NEQ][NF], slot = e*NFACES + f;
 // fields 0..NEQ-1 = U, NEQ..2NEQ-1 = Up
 // =============================================================================================
+template <class C, class PH, int D>
+__device__ inline void traces_dir(const MeshDev &m, int e0, const double *sF, double *sT, double *__restrict__ TA,
+                                  const Tables1D &ct, int tid) {
+  constexpr int NEQ = PH::NEQ;
+  trace_lines<C, D, 2 * NEQ>(sF, sT, ct, tid);
+  __syncthreads();
+  for (int item = tid; item < C::TN; item += C::BLOCK) {
+    const int pf = item / C::NF, fn = item - pf * C::NF;
+    const int e = e0 + (pf >> 1);
+    if (e >= m.ne) continue;
+    double *out = TA + (static_cast<int64_t>(e) * C::NFACES + 2 * D + (pf & 1)) * (2 * NEQ * C::NF) + fn;
+#pragma unroll
+    for (int fld = 0; fld < 2 * NEQ; fld++) out[fld * C::NF] = ldsr(&sT[fld * C::TN + item]);
+  }
+  __syncthreads();
+}
+
 template <class C, class PH>
 __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
                                                      double *__restrict__ Upout, double *__restrict__ TA) {
   constexpr int NEQ = PH::NEQ;
-  __shared__ Tab<C> tab;
-  __shared__ double sF[2 * NEQ][C::NODES];
-  load_tables<C>(tab, m.tables);
+  const Tables1D &ct = c_tab[C::DIM - 2][C::P];
+  __shared__ double sF[2 * NEQ * C::NODES];
+  __shared__ double sT[2 * NEQ * C::TN];
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * C::EPB;
   if (tid < C::NODES) {
@@ -382,21 +433,16 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Par
       PH::prim(prm, u, up);
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) {
-        sF[eq][tid] = u[eq];
-        sF[NEQ + eq][tid] = up[eq];
+        sF[eq * C::NODES + tid] = u[eq];
+        sF[(NEQ + eq) * C::NODES + tid] = up[eq];
         field_ptr(Upout, eq, m.ndofs)[n] = up[eq];
       }
     }
   }
   __syncthreads();
-  for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
-    const FaceItem it = face_item<C>(item, C::NF);
-    const int e = e0 + it.le;
-    if (e >= m.ne) continue;
-    double *out = TA + (static_cast<int64_t>(e) * C::NFACES + it.f) * (2 * NEQ * C::NF) + it.idx;
-#pragma unroll
-    for (int fld = 0; fld < 2 * NEQ; fld++) out[fld * C::NF] = face_trace<C>(&sF[fld][it.le * C::NPE], tab, it.f, it.idx);
-  }
+  traces_dir<C, PH, 0>(m, e0, sF, sT, TA, ct, tid);
+  traces_dir<C, PH, 1>(m, e0, sF, sT, TA, ct, tid);
+  if (C::DIM == 3) traces_dir<C, PH, (C::DIM == 3 ? 2 : 0)>(m, e0, sF, sT, TA, ct, tid);
 }
 
 // =============================================================================================
@@ -408,36 +454,166 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Par
 template <class C, class PH>
 struct GradLds {
   static constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-  // chunk of fields interpolated together in the viscous phase
-  static constexpr int CH = NEQ;
-  static constexpr int R0 = NEQ * C::NODES;                                           // sU
-  static constexpr int R1 = cmax(NEQ * DIM * C::NODES, NEQ * C::FQ_ITEMS);            // sG | sQ
-  static constexpr int R2 = cmax(cmax(NEQ * C::NODES, NEQ * C::FW_ITEMS), CH * C::FN_ITEMS);  // sUp | W | T chunk
-  static constexpr int R3 = cmax(NEQ * C::FN_ITEMS, CH * C::FW_ITEMS);                // sFN | sL | W chunk
-  static constexpr int O0 = 0, O1 = R0, O2 = R0 + R1, O3 = R0 + R1 + R2;
-  static constexpr int TOTAL = R0 + R1 + R2 + R3;
+  static constexpr int NVF = NEQ * (1 + DIM);  // fields interpolated for the viscous traces: U, gradUp
+  static constexpr int CH = 2 * NEQ;           // ... CH at a time
+  // X: T (2 NEQ fields) | R (NEQ*DIM fields) | L (NEQ*DIM fields); Y: W (2 NEQ) | W2 (NEQ*DIM) | R in 2-D
+  static constexpr int X_JUMP = cmax(cmax(2 * NEQ * C::TN, NEQ * DIM * C::TQ), NEQ * DIM * C::TN);
+  static constexpr int Y = cmax(cmax(2 * NEQ * C::TW, NEQ * DIM * C::TW), (DIM == 2) ? NEQ * DIM * C::TQ : 0);
+  static constexpr int SG = cmax(NEQ * DIM * C::NODES, X_JUMP);  // sG, hosting X during the jump phase
+  static constexpr int SUP = cmax(NEQ * C::NODES, CH * C::TN);   // sUp, hosting T during the viscous phase
+  static constexpr int O_U = 0, O_UP = NEQ * C::NODES, O_G = O_UP + SUP, O_Y = O_G + SG;
+  static constexpr int TOTAL = O_Y + Y;
 };
 
+// gradient jump of one direction pair: g += M^-1 sum_faces <phi, (u^ - u) n>
+template <class C, class PH, int D>
+__device__ inline void grad_jump_dir(const MeshDev &m, const typename PH::Params &prm, int e0, const double *sUp,
+                                     double *X, double *Yb, const double *sV, const Tab<C> &tab, const Tables1D &ct,
+                                     const double *__restrict__ TA, bool node_on, int le_n, const int *idx,
+                                     double inv_mass, double *g, int tid) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  trace_lines<C, D, NEQ>(sUp, X, ct, tid);  // own traces -> X[0..NEQ)
+  __syncthreads();
+  load_neighbour_traces<C, D, NEQ>(m, e0, TA, 2 * NEQ * C::NF, NEQ, X, X + NEQ * C::TN, tid);
+  __syncthreads();
+  interp1_lines<C, 2 * NEQ>(X, Yb, ct, tid);
+  if (DIM == 3) __syncthreads();
+  // quadrature points: half jump times weighted normal, all gradient directions at once
+  double r[C::Q_ROUNDS][NEQ * DIM];
+#pragma unroll
+  for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
+    const int item = tid + rd * C::BLOCK;
+#pragma unroll
+    for (int k = 0; k < NEQ * DIM; k++) r[rd][k] = 0.0;
+    if (item < C::TQ) {
+      const int pf = item / C::NQ, q = item - pf * C::NQ;
+      const int le = pf >> 1, s = pf & 1;
+      const int e = e0 + le;
+      if (e < m.ne) {
+        const int nb = m.face_nbr[e * C::NFACES + 2 * D + s];
+        double bq[C::N1];
+        const int qrow = (DIM == 2) ? q : q / C::Q1;
+#pragma unroll
+        for (int a = 0; a < C::N1; a++) bq[a] = tab.B[qrow * C::N1 + a];
+        double u1[NEQ], u2[NEQ];
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) {
+          u1[eq] = interp2_point<C>(X + eq * C::TN, Yb + eq * C::TW, bq, pf, q);
+          u2[eq] = interp2_point<C>(X + (NEQ + eq) * C::TN, Yb + (NEQ + eq) * C::TW, bq, pf, q);
+        }
+        if (nb < 0 && prm.use_bc_in_grad) PH::bc_grad_prim(prm, prm.bc[-nb - 1], u1, u2);
+        double n[DIM], wq, Xq[DIM];
+        face_geometry<C, D>(&sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
+#pragma unroll
+        for (int dd = 0; dd < DIM; dd++) {
+          const double nw = n[dd] * wq;
+#pragma unroll
+          for (int eq = 0; eq < NEQ; eq++) r[rd][eq + dd * NEQ] = 0.5 * (u2[eq] - u1[eq]) * nw;
+        }
+      }
+    }
+  }
+  __syncthreads();  // X (T) and Y (W) are dead
+  double *R = (DIM == 2) ? Yb : X;
+#pragma unroll
+  for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
+    const int item = tid + rd * C::BLOCK;
+    if (item < C::TQ) {
+#pragma unroll
+      for (int k = 0; k < NEQ * DIM; k++) R[k * C::TQ + item] = r[rd][k];
+    }
+  }
+  __syncthreads();
+  project1_lines<C, NEQ * DIM>(X, Yb, ct, tid);
+  if (DIM == 3) __syncthreads();
+  project2_lines<C, NEQ * DIM>(Yb, X, ct, tid);  // 3-D: W2 (Y) -> L (X); 2-D: R (Y) -> L (X)
+  __syncthreads();
+  if (node_on) {
+#pragma unroll
+    for (int k = 0; k < NEQ * DIM; k++) g[k] += inv_mass * lift_pair<C, D>(X + k * C::TN, tab, le_n, idx);
+  }
+  __syncthreads();
+}
+
+// viscous normal-flux traces of one direction pair
+template <class C, class PH, int D>
+__device__ inline void visc_traces_dir(const MeshDev &m, const typename PH::Params &prm, int e0, const double *sU,
+                                       const double *sG, double *Tb, double *Wb, const double *sV, const Tab<C> &tab,
+                                       const Tables1D &ct, double *__restrict__ TB, int tid) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  typedef GradLds<C, PH> L;
+  double v[C::Q_ROUNDS][L::NVF];
+#pragma unroll
+  for (int c0 = 0; c0 < L::NVF; c0 += L::CH) {
+    // fields c0 .. c0+CH of [U | gradUp]
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int f0 = c0 + half * NEQ;
+      if (f0 < L::NVF) {
+        const double *src = (f0 < NEQ) ? sU : sG + (f0 - NEQ) * C::NODES;
+        trace_lines<C, D, NEQ>(src, Tb + half * NEQ * C::TN, ct, tid);
+      }
+    }
+    __syncthreads();
+    interp1_lines<C, L::CH>(Tb, Wb, ct, tid);
+    if (DIM == 3) __syncthreads();
+#pragma unroll
+    for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
+      const int item = tid + rd * C::BLOCK;
+      if (item < C::TQ) {
+        const int pf = item / C::NQ, q = item - pf * C::NQ;
+        double bq[C::N1];
+        const int qrow = (DIM == 2) ? q : q / C::Q1;
+#pragma unroll
+        for (int a = 0; a < C::N1; a++) bq[a] = tab.B[qrow * C::N1 + a];
+#pragma unroll
+        for (int k = 0; k < L::CH; k++)
+          if (c0 + k < L::NVF) v[rd][c0 + k] = interp2_point<C>(Tb + k * C::TN, Wb + k * C::TW, bq, pf, q);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
+    const int item = tid + rd * C::BLOCK;
+    if (item >= C::TQ) continue;
+    const int pf = item / C::NQ, q = item - pf * C::NQ;
+    const int le = pf >> 1, s = pf & 1;
+    const int e = e0 + le;
+    if (e >= m.ne) continue;
+    const int slot = e * C::NFACES + 2 * D + s;
+    const int nb = m.face_nbr[slot];
+    double fn[NEQ];
+    PH::clamp_species(v[rd]);
+    double n[DIM], wq, Xq[DIM];
+    face_geometry<C, D>(&sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
+    if (nb >= 0) {
+      PH::visc_flux_n(prm, v[rd], v[rd] + NEQ, n, fn);
+    } else {
+      PH::bc_visc_term(prm, prm.bc[-nb - 1], v[rd], v[rd] + NEQ, n, fn);
+    }
+    double *out = TB + static_cast<int64_t>(slot) * (NEQ * C::NQ) + q;
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) out[eq * C::NQ] = fn[eq];
+  }
+}
+
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK, C::MINW) void k_gradient(MeshDev m, typename PH::Params prm,
+__global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_GRAD) void k_gradient(MeshDev m, typename PH::Params prm,
                                                        const double *__restrict__ U, const double *__restrict__ TA,
                                                        double *__restrict__ gradUp, double *__restrict__ TB) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   typedef GradLds<C, PH> L;
+  const Tables1D &ct = c_tab[DIM - 2][C::P];
   __shared__ Tab<C> tab;
   __shared__ double sV[C::EPB * C::NV * DIM];
   __shared__ double pool[L::TOTAL];
-  double *sU = pool + L::O0;   // [NEQ][NODES]
-  double *sG = pool + L::O1;   // [NEQ*DIM][NODES]      (after the jump phase)
-  double *sQ = pool + L::O1;   // [NEQ][FQ_ITEMS]       (jump phase)
-  double *sUp = pool + L::O2;  // [NEQ][NODES]
-  double *sW = pool + L::O2;   // [NEQ][FW_ITEMS]       (after sUp is dead)
-  double *sT = pool + L::O2;   // [CH][FN_ITEMS]        (viscous phase)
-  double *sFN = pool + L::O3;  // [NEQ][FN_ITEMS]
-  double *sL = pool + L::O3;   // [NEQ][FN_ITEMS]
-  double *sWc = pool + L::O3;  // [CH][FW_ITEMS]        (viscous phase)
+  double *sU = pool + L::O_U;    // [NEQ][NODES]
+  double *sUp = pool + L::O_UP;  // [NEQ][NODES]; viscous phase: T chunk
+  double *sG = pool + L::O_G;    // [NEQ*DIM][NODES]; jump phase: X
+  double *sY = pool + L::O_Y;
 
-  load_tables<C>(tab, m.tables);
+  load_tables<C>(tab, ct);
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * C::EPB;
   load_vertices<C>(sV, m, e0);
@@ -460,6 +636,8 @@ __global__ __launch_bounds__(C::BLOCK, C::MINW) void k_gradient(MeshDev m, typen
 
   // ---- volume part: collocation derivative (Ke then M^-1 of the reference collapse to it)
   double g[NEQ * DIM];  // g[eq + d*NEQ]
+#pragma unroll
+  for (int k = 0; k < NEQ * DIM; k++) g[k] = 0.0;
   double inv_mass = 0.0;
   if (node_on) {
     double xi[DIM], J[DIM * DIM], A[DIM * DIM];
@@ -473,6 +651,11 @@ __global__ __launch_bounds__(C::BLOCK, C::MINW) void k_gradient(MeshDev m, typen
     const double det = adjugate<DIM>(J, A);
     const double idet = 1.0 / det;
     inv_mass = iwn * idet;
+    double Dr[DIM][C::N1];
+#pragma unroll
+    for (int mm = 0; mm < DIM; mm++)
+#pragma unroll
+      for (int a = 0; a < C::N1; a++) Dr[mm][a] = tab.D[idx[mm] * C::N1 + a];
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) {
       double dr[DIM];
@@ -482,7 +665,7 @@ __global__ __launch_bounds__(C::BLOCK, C::MINW) void k_gradient(MeshDev m, typen
         const double *F = &sUp[eq * C::NODES + le_n * C::NPE + nd - idx[mm] * sd];
         double acc = 0.0;
 #pragma unroll
-        for (int a = 0; a < C::N1; a++) acc += tab.D[idx[mm] * C::N1 + a] * ldsr(&F[a * sd]);
+        for (int a = 0; a < C::N1; a++) acc += Dr[mm][a] * ldsr(&F[a * sd]);
         dr[mm] = acc;
       }
 #pragma unroll
@@ -495,159 +678,30 @@ __global__ __launch_bounds__(C::BLOCK, C::MINW) void k_gradient(MeshDev m, typen
     }
   }
 
-  // ---- face part: half jump of the primitives at the face nodes (own trace on boundary faces)
-  for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
-    const FaceItem it = face_item<C>(item, C::NF);
-    const int e = e0 + it.le;
-    if (e >= m.ne) continue;
-    const int slot = e * C::NFACES + it.f;
-    const int nb = m.face_nbr[slot];
-    double u1[NEQ];
-#pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) u1[eq] = face_trace<C>(&sUp[eq * C::NODES + it.le * C::NPE], tab, it.f, it.idx);
-    if (nb >= 0) {
-      const int o = m.face_orient[slot];
-      const int pn = permute<DIM>(o, C::N1, it.idx % C::N1, it.idx / C::N1);
-      const double *src = TA + static_cast<int64_t>(nb) * (2 * NEQ * C::NF) + NEQ * C::NF + pn;
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) sFN[eq * C::FN_ITEMS + item] = 0.5 * (src[eq * C::NF] - u1[eq]);
-    } else {
-      // boundary: u2 = u1 (src/faceGradientIntegration.cpp:113-115); the wall ghost of useBCinGrad
-      // is not polynomial in the face nodes and is applied at the quadrature points below
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) sFN[eq * C::FN_ITEMS + item] = u1[eq];
-    }
+  // ---- face part, one direction pair at a time (X lives in the sG region, not yet in use)
+  if (!(TPSRHS_ABLATE & 8)) {
+    grad_jump_dir<C, PH, 0>(m, prm, e0, sUp, sG, sY, sV, tab, ct, TA, node_on, le_n, idx, inv_mass, g, tid);
+    grad_jump_dir<C, PH, 1>(m, prm, e0, sUp, sG, sY, sV, tab, ct, TA, node_on, le_n, idx, inv_mass, g, tid);
+    if (DIM == 3)
+      grad_jump_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, prm, e0, sUp, sG, sY, sV, tab, ct, TA, node_on, le_n, idx, inv_mass,
+                                                g, tid);
   }
-  __syncthreads();  // sFN complete, sUp dead
-  interp_stage1<C, NEQ>(sFN, sW, tab, tid);
-  __syncthreads();
-
-  // quadrature-point values of the half jump and the weighted normals, in registers per round
-  double jq[C::FQ_ROUNDS][NEQ];
-  double nw[C::FQ_ROUNDS][DIM];
-#pragma unroll
-  for (int r = 0; r < C::FQ_ROUNDS; r++) {
-    const int item = tid + r * C::BLOCK;
-#pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) jq[r][eq] = 0.0;
-#pragma unroll
-    for (int d = 0; d < DIM; d++) nw[r][d] = 0.0;
-    if (item < C::FQ_ITEMS) {
-      const FaceItem it = face_item<C>(item, C::NQ);
-      const int e = e0 + it.le;
-      if (e < m.ne) {
-        const int nb = m.face_nbr[e * C::NFACES + it.f];
-        double n[DIM], wq, X[DIM];
-        face_geometry<C>(&sV[it.le * C::NV * DIM], tab, it.f, it.idx, n, wq, X);
-#pragma unroll
-        for (int d = 0; d < DIM; d++) nw[r][d] = n[d] * wq;
-        if (nb >= 0) {
-#pragma unroll
-          for (int eq = 0; eq < NEQ; eq++)
-            jq[r][eq] = interp_stage2<C>(sFN + eq * C::FN_ITEMS, sW + eq * C::FW_ITEMS, tab, it.lf, it.idx);
-        } else if (prm.use_bc_in_grad) {
-          double u1[NEQ], u2[NEQ];
-#pragma unroll
-          for (int eq = 0; eq < NEQ; eq++)
-            u1[eq] = interp_stage2<C>(sFN + eq * C::FN_ITEMS, sW + eq * C::FW_ITEMS, tab, it.lf, it.idx);
-          PH::bc_grad_prim(prm, prm.bc[-nb - 1], u1, u2);
-#pragma unroll
-          for (int eq = 0; eq < NEQ; eq++) jq[r][eq] = 0.5 * (u2[eq] - u1[eq]);
-        }
-      }
-    }
-  }
-  __syncthreads();  // sW, sFN dead
-#pragma unroll
-  for (int d = 0; d < DIM; d++) {
-#pragma unroll
-    for (int r = 0; r < C::FQ_ROUNDS; r++) {
-      const int item = tid + r * C::BLOCK;
-      if (item < C::FQ_ITEMS) {
-#pragma unroll
-        for (int eq = 0; eq < NEQ; eq++) sQ[eq * C::FQ_ITEMS + item] = jq[r][eq] * nw[r][d];
-      }
-    }
-    __syncthreads();
-    project_stage1<C, NEQ>(sQ, sW, tab, tid);
-    if (DIM == 3) __syncthreads();
-    project_stage2<C, NEQ>(sQ, sW, sL, tab, tid);
-    __syncthreads();
-    if (node_on) {
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++)
-        g[eq + d * NEQ] += inv_mass * face_lift<C>(&sL[eq * C::FN_ITEMS + le_n * C::NFACES * C::NF], tab, idx);
-    }
-    // the next direction overwrites sQ (read by project_stage1/2 above, complete at the last
-    // barrier) and sW/sL (read before the barriers that precede their next writes)
-  }
-  __syncthreads();  // all reads of sQ done before sG (same region) is written
 
   if (node_on) {
     const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
 #pragma unroll
-    for (int d = 0; d < DIM; d++)
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) {
-        field_ptr(gradUp, eq + d * NEQ, m.ndofs)[n] = g[eq + d * NEQ];
-        sG[(eq + d * NEQ) * C::NODES + tid] = g[eq + d * NEQ];
-      }
+    for (int k = 0; k < NEQ * DIM; k++) {
+      field_ptr(gradUp, k, m.ndofs)[n] = g[k];
+      sG[k * C::NODES + tid] = g[k];
+    }
   }
   __syncthreads();
 
-  // ---- viscous normal-flux traces: U and gradUp at the face quadrature points, NEQ fields at a time
-  double uq[C::FQ_ROUNDS][NEQ], gq[C::FQ_ROUNDS][NEQ * DIM];
-#pragma unroll
-  for (int c = 0; c < 1 + DIM; c++) {
-    const double *src = (c == 0) ? sU : sG + (c - 1) * NEQ * C::NODES;
-    for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
-      const FaceItem it = face_item<C>(item, C::NF);
-      if (e0 + it.le >= m.ne) continue;
-#pragma unroll
-      for (int k = 0; k < NEQ; k++)
-        sT[k * C::FN_ITEMS + item] = face_trace<C>(&src[k * C::NODES + it.le * C::NPE], tab, it.f, it.idx);
-    }
-    __syncthreads();
-    interp_stage1<C, NEQ>(sT, sWc, tab, tid);
-    if (DIM == 3) __syncthreads();
-#pragma unroll
-    for (int r = 0; r < C::FQ_ROUNDS; r++) {
-      const int item = tid + r * C::BLOCK;
-      if (item < C::FQ_ITEMS) {
-        const int lf = item / C::NQ, q = item - lf * C::NQ;
-#pragma unroll
-        for (int k = 0; k < NEQ; k++) {
-          const double v = interp_stage2<C>(sT + k * C::FN_ITEMS, sWc + k * C::FW_ITEMS, tab, lf, q);
-          if (c == 0)
-            uq[r][k] = v;
-          else
-            gq[r][k + (c - 1) * NEQ] = v;
-        }
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int r = 0; r < C::FQ_ROUNDS; r++) {
-    const int item = tid + r * C::BLOCK;
-    if (item >= C::FQ_ITEMS) continue;
-    const FaceItem it = face_item<C>(item, C::NQ);
-    const int e = e0 + it.le;
-    if (e >= m.ne) continue;
-    const int slot = e * C::NFACES + it.f;
-    const int nb = m.face_nbr[slot];
-    double fn[NEQ];
-    PH::clamp_species(uq[r]);
-    double n[DIM], wq, X[DIM];
-    face_geometry<C>(&sV[it.le * C::NV * DIM], tab, it.f, it.idx, n, wq, X);
-    if (nb >= 0) {
-      PH::visc_flux_n(prm, uq[r], gq[r], n, fn);
-    } else {
-      PH::bc_visc_term(prm, prm.bc[-nb - 1], uq[r], gq[r], n, fn);
-    }
-    double *out = TB + static_cast<int64_t>(slot) * (NEQ * C::NQ) + it.idx;
-#pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) out[eq * C::NQ] = fn[eq];
+  // ---- viscous normal-flux traces (T chunk in the sUp region, W chunk in Y)
+  if (!(TPSRHS_ABLATE & 16)) {
+    visc_traces_dir<C, PH, 0>(m, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
+    visc_traces_dir<C, PH, 1>(m, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
+    if (DIM == 3) visc_traces_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
   }
 }
 
@@ -657,32 +711,111 @@ __global__ __launch_bounds__(C::BLOCK, C::MINW) void k_gradient(MeshDev m, typen
 template <class C, class PH>
 struct FluxLds {
   static constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-  // region A: sU + sGf, later W / W2 + sL ; region B: sT1 + sT2, later sQ
-  static constexpr int A_W = NEQ * C::FW_ITEMS;
-  static constexpr int RA = cmax(NEQ * C::NODES + NEQ * DIM * C::NODES, A_W + NEQ * C::FN_ITEMS);
-  static constexpr int RB = cmax(2 * NEQ * C::FN_ITEMS, NEQ * C::FQ_ITEMS);
-  static constexpr int TOTAL = RA + RB;
+  static constexpr int X = cmax(cmax(2 * NEQ * C::TN, NEQ * C::TQ), NEQ * C::TN);  // T | R (3-D) | L
+  static constexpr int Y = cmax(cmax(2 * NEQ * C::TW, NEQ * C::TW), (DIM == 2) ? NEQ * C::TQ : 0);
+  static constexpr int GF = cmax(NEQ * DIM * C::NODES, X + Y);  // sGf, then X and Y
+  static constexpr int TOTAL = NEQ * C::NODES + GF;
 };
 
+template <class C, class PH, int D>
+__device__ inline void face_flux_dir(const MeshDev &m, const typename PH::Params &prm, int e0, const double *sU,
+                                     double *X, double *Yb, const double *sV, const Tab<C> &tab, const Tables1D &ct,
+                                     const double *__restrict__ TA, const double *__restrict__ TB, bool node_on,
+                                     int le_n, const int *idx, double *z, int tid) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  trace_lines<C, D, NEQ>(sU, X, ct, tid);
+  __syncthreads();
+  load_neighbour_traces<C, D, NEQ>(m, e0, TA, 2 * NEQ * C::NF, 0, X, X + NEQ * C::TN, tid);
+  __syncthreads();
+  interp1_lines<C, 2 * NEQ>(X, Yb, ct, tid);
+  if (DIM == 3) __syncthreads();
+  double fh[C::Q_ROUNDS][NEQ];
+#pragma unroll
+  for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
+    const int item = tid + rd * C::BLOCK;
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] = 0.0;
+    if (item >= C::TQ) continue;
+    const int pf = item / C::NQ, q = item - pf * C::NQ;
+    const int le = pf >> 1, s = pf & 1;
+    const int e = e0 + le;
+    if (e >= m.ne) continue;
+    const int slot = e * C::NFACES + 2 * D + s;
+    const int nb = m.face_nbr[slot];
+    double bq[C::N1];
+    const int qrow = (DIM == 2) ? q : q / C::Q1;
+#pragma unroll
+    for (int a = 0; a < C::N1; a++) bq[a] = tab.B[qrow * C::N1 + a];
+    double u1[NEQ], u2[NEQ];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) {
+      u1[eq] = interp2_point<C>(X + eq * C::TN, Yb + eq * C::TW, bq, pf, q);
+      u2[eq] = interp2_point<C>(X + (NEQ + eq) * C::TN, Yb + (NEQ + eq) * C::TW, bq, pf, q);
+    }
+    PH::clamp_species(u1);
+    double n[DIM], wq, Xq[DIM];
+    face_geometry<C, D>(&sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
+    const double *tb_own = TB + static_cast<int64_t>(slot) * (NEQ * C::NQ) + q;
+    if (TPSRHS_ABLATE & 4) {
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] = u1[eq] + u2[eq] * n[0];
+    } else if (nb >= 0) {
+      PH::clamp_species(u2);
+      PH::lax_friedrichs(prm, u1, u2, n, fh[rd]);
+      const int pq = permute<DIM>(m.face_orient[slot], C::Q1, q % C::Q1, q / C::Q1);
+      const double *tb_nb = TB + static_cast<int64_t>(nb) * (NEQ * C::NQ) + pq;
+      if (!(TPSRHS_ABLATE & 1)) {
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] -= 0.5 * (tb_own[eq * C::NQ] - tb_nb[eq * C::NQ]);
+      }
+    } else {
+      double ug[NEQ];
+      PH::bc_ghost(prm, prm.bc[-nb - 1], u1, n, ug);
+      PH::lax_friedrichs(prm, u1, ug, n, fh[rd]);
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] += tb_own[eq * C::NQ];
+    }
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] *= wq;
+  }
+  __syncthreads();  // X (T) and Y (W) are dead
+  double *R = (DIM == 2) ? Yb : X;
+#pragma unroll
+  for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
+    const int item = tid + rd * C::BLOCK;
+    if (item < C::TQ) {
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) R[eq * C::TQ + item] = fh[rd][eq];
+    }
+  }
+  __syncthreads();
+  project1_lines<C, NEQ>(X, Yb, ct, tid);
+  if (DIM == 3) __syncthreads();
+  project2_lines<C, NEQ>(Yb, X, ct, tid);
+  __syncthreads();
+  if (node_on) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) z[eq] -= lift_pair<C, D>(X + eq * C::TN, tab, le_n, idx);
+  }
+  __syncthreads();
+}
+
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK, C::MINW) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
+__global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_FLUX) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
                                                    const double *__restrict__ gradUp, const double *__restrict__ TA,
                                                    const double *__restrict__ TB, double *__restrict__ Y,
-                                                   unsigned long long *__restrict__ max_speed_bits) {
+                                                   double *__restrict__ block_speed) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   typedef FluxLds<C, PH> L;
+  const Tables1D &ct = c_tab[DIM - 2][C::P];
   __shared__ Tab<C> tab;
   __shared__ double sV[C::EPB * C::NV * DIM];
   __shared__ double pool[L::TOTAL];
-  double *sU = pool;                                // [NEQ][NODES]
-  double *sGf = pool + NEQ * C::NODES;              // [NEQ*DIM][NODES] contravariant nodal flux
-  double *sW = pool;                                // [NEQ][FW_ITEMS]   (after z)
-  double *sL = pool + L::A_W;                       // [NEQ][FN_ITEMS]
-  double *sT1 = pool + L::RA;                       // [NEQ][FN_ITEMS] own traces of U
-  double *sT2 = pool + L::RA + NEQ * C::FN_ITEMS;   // [NEQ][FN_ITEMS] neighbour traces in my frame
-  double *sQ = pool + L::RA;                        // [NEQ][FQ_ITEMS]   (after the interpolation)
+  double *sU = pool;                    // [NEQ][NODES]
+  double *sGf = pool + NEQ * C::NODES;  // [NEQ*DIM][NODES] contravariant nodal flux; later X | Y
+  double *sX = sGf, *sY = sGf + L::X;
 
-  load_tables<C>(tab, m.tables);
+  load_tables<C>(tab, ct);
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * C::EPB;
   load_vertices<C>(sV, m, e0);
@@ -698,18 +831,39 @@ __global__ __launch_bounds__(C::BLOCK, C::MINW) void k_flux(MeshDev m, typename 
       sU[eq * C::NODES + tid] = u[eq];
     }
 #pragma unroll
-    for (int d = 0; d < DIM; d++)
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) gr[eq + d * NEQ] = field_ptr(gradUp, eq + d * NEQ, m.ndofs)[n];
+    for (int k = 0; k < NEQ * DIM; k++) gr[k] = field_ptr(gradUp, k, m.ndofs)[n];
   }
   __syncthreads();  // tables + vertices + sU
 
-  // ---- nodal flux F_c - F_v (src/rhs_operator.cpp:493-559), contravariant components
+  // ---- nodal flux F_c - F_v (src/rhs_operator.cpp:493-559), contravariant components.
+  // Ordered to keep the register peak low: physics first (U, gradUp -> 15 flux entries), then the
+  // geometry, then the contraction with the metric rows.
   double inv_mass = 0.0, speed = 0.0;
   double src[NEQ];
 #pragma unroll
   for (int eq = 0; eq < NEQ; eq++) src[eq] = 0.0;
   if (node_on) {
+    double F[NEQ * DIM];
+    {
+      double uc[NEQ];
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) uc[eq] = u[eq];
+      PH::clamp_species(uc);
+      const typename PH::State st = PH::make_state(prm, uc);
+      speed = PH::max_char_speed(prm, uc, st);
+      if (PH::HAS_SOURCE) {
+        double up[NEQ];
+        PH::prim(prm, u, up);
+        PH::source(prm, u, up, gr, src);
+      }
+      if (TPSRHS_ABLATE & 2) {
+#pragma unroll
+        for (int k = 0; k < NEQ * DIM; k++) F[k] = uc[k % NEQ] + gr[k];
+      } else {
+        PH::total_flux(prm, uc, st, gr, F);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     double xi[DIM], J[DIM * DIM], A[DIM * DIM];
     double wn = 1.0, iwn = 1.0;
 #pragma unroll
@@ -721,79 +875,50 @@ __global__ __launch_bounds__(C::BLOCK, C::MINW) void k_flux(MeshDev m, typename 
     jacobian<DIM>(&sV[le_n * C::NV * DIM], xi, J);
     const double det = adjugate<DIM>(J, A);
     inv_mass = iwn / det;
-    double uc[NEQ];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) uc[eq] = u[eq];
-    PH::clamp_species(uc);
-    const typename PH::State st = PH::make_state(prm, uc);
-    speed = PH::max_char_speed(prm, uc, st);
-    if (PH::HAS_SOURCE) {
-      double up[NEQ];
-      PH::prim(prm, u, up);
-      PH::source(prm, u, up, gr, src);
-    }
-    if (PH::HAS_FLUX_DOT) {
-      // contravariant flux, one metric row at a time (keeps ~35 doubles live instead of ~70)
-      const typename PH::Transport tr = PH::transport(prm, st);
-      double divV = 0.0;
-#pragma unroll
-      for (int i = 0; i < DIM; i++) divV += gr[(1 + i) + i * NEQ];
+    for (int eq = 0; eq < NEQ; eq++)
 #pragma unroll
       for (int mm = 0; mm < DIM; mm++) {
-        double a[DIM], Fa[NEQ];
+        double s = 0.0;
 #pragma unroll
-        for (int d = 0; d < DIM; d++) a[d] = wn * A[mm + d * DIM];
-        PH::total_flux_dot(prm, uc, st, tr, divV, gr, a, Fa);
-#pragma unroll
-        for (int eq = 0; eq < NEQ; eq++) sGf[(eq + mm * NEQ) * C::NODES + tid] = Fa[eq];
-        __builtin_amdgcn_sched_barrier(0);  // one metric row at a time: keeps the register peak low
+        for (int d = 0; d < DIM; d++) s += A[mm + d * DIM] * F[eq + d * NEQ];
+        sGf[(eq + mm * NEQ) * C::NODES + tid] = wn * s;
       }
-    } else {
-      double F[NEQ * DIM], Fv[NEQ * DIM];
-      PH::conv_flux(prm, uc, st, F);
-      PH::visc_flux(prm, uc, st, gr, Fv);
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++)
-#pragma unroll
-        for (int mm = 0; mm < DIM; mm++) {
-          double s = 0.0;
-#pragma unroll
-          for (int d = 0; d < DIM; d++) s += A[mm + d * DIM] * (F[eq + d * NEQ] - Fv[eq + d * NEQ]);
-          sGf[(eq + mm * NEQ) * C::NODES + tid] = wn * s;
-        }
-    }
   }
-  // max |u|+c over the wave -> global (positive doubles order like their bit patterns)
+  // max |u|+c of the block -> one slot per block.  (A single global atomicMax per wave serialises
+  // at the L2: ~12 ns each, 0.6 ms for 50k waves -- measured; per-block stores cost nothing and a
+  // tiny reduction kernel runs only when the caller asks for the value.)
   {
     double v = speed;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    if ((tid & 63) == 0 && v > 0.0) atomicMax(max_speed_bits, static_cast<unsigned long long>(__double_as_longlong(v)));
-  }
-
-  // ---- face traces of U: own and neighbour
-  for (int item = tid; item < C::FN_ITEMS; item += C::BLOCK) {
-    const FaceItem it = face_item<C>(item, C::NF);
-    const int e = e0 + it.le;
-    if (e >= m.ne) continue;
-    const int slot = e * C::NFACES + it.f;
-    const int nb = m.face_nbr[slot];
+    if (C::BLOCK == 64) {
+      if (tid == 0) block_speed[blockIdx.x] = v;
+    } else {
+      __shared__ double swave[C::BLOCK / 64];
+      if ((tid & 63) == 0) swave[tid >> 6] = v;
+      __syncthreads();
+      if (tid == 0) {
+        double b = swave[0];
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++)
-      sT1[eq * C::FN_ITEMS + item] = face_trace<C>(&sU[eq * C::NODES + it.le * C::NPE], tab, it.f, it.idx);
-    if (nb >= 0) {
-      const int o = m.face_orient[slot];
-      const int pn = permute<DIM>(o, C::N1, it.idx % C::N1, it.idx / C::N1);
-      const double *s2 = TA + static_cast<int64_t>(nb) * (2 * NEQ * C::NF) + pn;
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) sT2[eq * C::FN_ITEMS + item] = (TPSRHS_ABLATE & 1) ? 1.0 : s2[eq * C::NF];
+        for (int w = 1; w < C::BLOCK / 64; w++) b = fmax(b, swave[w]);
+        block_speed[blockIdx.x] = b;
+      }
     }
   }
-  __syncthreads();  // sGf, sT1, sT2 complete
+  __syncthreads();  // sGf complete
 
   // ---- volume term: z_j = sum_m sum_a D[a][j_m] Ghat_m(a)   (src/domain_integrator.cpp:45-99)
   double z[NEQ];
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) z[eq] = 0.0;
   if (node_on) {
+    double Dc[DIM][C::N1];
+#pragma unroll
+    for (int mm = 0; mm < DIM; mm++)
+#pragma unroll
+      for (int a = 0; a < C::N1; a++) Dc[mm][a] = tab.D[a * C::N1 + idx[mm]];
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) {
       double acc = 0.0;
@@ -802,89 +927,40 @@ __global__ __launch_bounds__(C::BLOCK, C::MINW) void k_flux(MeshDev m, typename 
         const int sd = stride_of<C>(mm);
         const double *F = &sGf[(eq + mm * NEQ) * C::NODES + le_n * C::NPE + nd - idx[mm] * sd];
 #pragma unroll
-        for (int a = 0; a < C::N1; a++) acc += tab.D[a * C::N1 + idx[mm]] * ldsr(&F[a * sd]);
+        for (int a = 0; a < C::N1; a++) acc += Dc[mm][a] * ldsr(&F[a * sd]);
       }
       z[eq] = acc;
     }
   }
-  if (DIM == 3) __syncthreads();  // sU/sGf dead: region A becomes W
+  __syncthreads();  // sGf dead: its region becomes X | Y
 
-  // ---- U at the face quadrature points, both sides
-  double u1[C::FQ_ROUNDS][NEQ], u2[C::FQ_ROUNDS][NEQ];
-#pragma unroll
-  for (int side = 0; side < 2; side++) {
-    const double *T = side ? sT2 : sT1;
-    interp_stage1<C, NEQ>(T, sW, tab, tid);
-    if (DIM == 3) __syncthreads();
-#pragma unroll
-    for (int r = 0; r < C::FQ_ROUNDS; r++) {
-      const int item = tid + r * C::BLOCK;
-      if (item < C::FQ_ITEMS) {
-        const int lf = item / C::NQ, q = item - lf * C::NQ;
-#pragma unroll
-        for (int eq = 0; eq < NEQ; eq++) {
-          const double v = interp_stage2<C>(T + eq * C::FN_ITEMS, sW + eq * C::FW_ITEMS, tab, lf, q);
-          if (side)
-            u2[r][eq] = v;
-          else
-            u1[r][eq] = v;
-        }
-      }
-    }
-    __syncthreads();
+  // ---- face term, one direction pair at a time
+  if (!(TPSRHS_ABLATE & 8)) {
+    face_flux_dir<C, PH, 0>(m, prm, e0, sU, sX, sY, sV, tab, ct, TA, TB, node_on, le_n, idx, z, tid);
+    face_flux_dir<C, PH, 1>(m, prm, e0, sU, sX, sY, sV, tab, ct, TA, TB, node_on, le_n, idx, z, tid);
+    if (DIM == 3)
+      face_flux_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, prm, e0, sU, sX, sY, sV, tab, ct, TA, TB, node_on, le_n, idx, z, tid);
   }
 
-  // ---- numerical flux at the face quadrature points (sT1/sT2 dead: region B becomes sQ)
-#pragma unroll
-  for (int r = 0; r < C::FQ_ROUNDS; r++) {
-    const int item = tid + r * C::BLOCK;
-    if (item >= C::FQ_ITEMS) continue;
-    const FaceItem it = face_item<C>(item, C::NQ);
-    const int e = e0 + it.le;
-    if (e >= m.ne) continue;
-    const int slot = e * C::NFACES + it.f;
-    const int nb = m.face_nbr[slot];
-    double fh[NEQ];
-    PH::clamp_species(u1[r]);
-    double n[DIM], wq, X[DIM];
-    face_geometry<C>(&sV[it.le * C::NV * DIM], tab, it.f, it.idx, n, wq, X);
-    const double *tb_own = TB + static_cast<int64_t>(slot) * (NEQ * C::NQ) + it.idx;
-    if (TPSRHS_ABLATE & 4) {
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) fh[eq] = u1[r][eq] + u2[r][eq] * n[0];
-    } else if (nb >= 0) {
-      PH::clamp_species(u2[r]);
-      PH::lax_friedrichs(prm, u1[r], u2[r], n, fh);
-      const int o = m.face_orient[slot];
-      const int pq = permute<DIM>(o, C::Q1, it.idx % C::Q1, it.idx / C::Q1);
-      const double *tb_nb = TB + static_cast<int64_t>(nb) * (NEQ * C::NQ) + pq;
-      if (!(TPSRHS_ABLATE & 1)) {
-#pragma unroll
-        for (int eq = 0; eq < NEQ; eq++) fh[eq] -= 0.5 * (tb_own[eq * C::NQ] - tb_nb[eq * C::NQ]);
-      }
-    } else {
-      double ug[NEQ];
-      PH::bc_ghost(prm, prm.bc[-nb - 1], u1[r], n, ug);
-      PH::lax_friedrichs(prm, u1[r], ug, n, fh);
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) fh[eq] += tb_own[eq * C::NQ];
-    }
-#pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) sQ[eq * C::FQ_ITEMS + item] = fh[eq] * wq;
-  }
-  __syncthreads();
-  project_stage1<C, NEQ>(sQ, sW, tab, tid);
-  if (DIM == 3) __syncthreads();
-  project_stage2<C, NEQ>(sQ, sW, sL, tab, tid);
-  __syncthreads();
   if (node_on) {
     const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) {
-      const double lift = face_lift<C>(&sL[eq * C::FN_ITEMS + le_n * C::NFACES * C::NF], tab, idx);
-      field_ptr(Y, eq, m.ndofs)[n] = inv_mass * (z[eq] - lift) + src[eq];
-    }
+    for (int eq = 0; eq < NEQ; eq++) field_ptr(Y, eq, m.ndofs)[n] = inv_mass * z[eq] + src[eq];
   }
+}
+
+// max over the per-block maxima written by k_flux (one block)
+__global__ void k_reduce_max(int n, const double *__restrict__ v, double *__restrict__ out) {
+  __shared__ double s[256];
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, v[i]);
+  s[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = s[0];
 }
 
 // =============================================================================================

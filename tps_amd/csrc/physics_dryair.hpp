@@ -201,6 +201,37 @@ struct DryAirPhys {
   }
   static constexpr bool HAS_FLUX_DOT = true;
 
+  // F_c - F_v as one tensor F[eq + d*NEQ] (src/rhs_operator.cpp:532-541)
+  __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const double *g,
+                                           double *F) {
+    const double H = U[1 + NVEL] + s.p;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      F[0 + d * NEQ] = U[1 + d];
+#pragma unroll
+      for (int i = 0; i < NVEL; i++) F[1 + i + d * NEQ] = U[1 + i] * s.vel[d];
+      F[1 + d + d * NEQ] += s.p;
+      F[1 + NVEL + d * NEQ] = s.vel[d] * H;
+    }
+    if (p.eq_system == TPSRHS_EULER) return;
+    const Transport t = transport(p, s);
+    double divV = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
+#pragma unroll
+    for (int i = 0; i < DIM; i++) {
+      double vt = 0.0;
+#pragma unroll
+      for (int j = 0; j < DIM; j++) {
+        double st = t.visc * (g[(1 + j) + i * NEQ] + g[(1 + i) + j * NEQ]);
+        if (i == j) st += t.bulk * divV;
+        F[(1 + j) + i * NEQ] -= st;  // stress is symmetric: tau_ij enters F[1+j][i]
+        vt += st * s.vel[j];
+      }
+      F[(1 + NVEL) + i * NEQ] -= vt + t.k * g[(1 + NVEL) + i * NEQ];
+    }
+  }
+
   // F_v(U, g) . n without forming the tensor
   __device__ static inline void visc_flux_n(const Params &p, const double *U, const double *g, const double *n,
                                             double *Fn) {

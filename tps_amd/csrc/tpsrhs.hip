@@ -69,9 +69,9 @@ struct tpsrhs_operator {
   double *d_verts = nullptr;
   int32_t *d_face_nbr = nullptr;
   uint8_t *d_face_orient = nullptr;
-  Tables1D *d_tables = nullptr;
   double *d_Up = nullptr, *d_gradUp = nullptr, *d_TA = nullptr, *d_TB = nullptr;
-  unsigned long long *d_speed = nullptr;
+  double *d_speed = nullptr, *d_block_speed = nullptr;
+  int flux_grid = 0;
   double *d_xh = nullptr, *d_yh = nullptr;  // staging for tpsrhs_mult_host
   // halo
   tpsrhs_halo_fn halo = nullptr;
@@ -97,14 +97,13 @@ struct tpsrhs_operator {
     m.verts = d_verts;
     m.face_nbr = d_face_nbr;
     m.face_orient = d_face_orient;
-    m.tables = d_tables;
     return m;
   }
   ~tpsrhs_operator() {
     (void)hipSetDevice(device);
     for (void *p : {static_cast<void *>(d_verts), static_cast<void *>(d_face_nbr), static_cast<void *>(d_face_orient),
-                    static_cast<void *>(d_tables), static_cast<void *>(d_Up), static_cast<void *>(d_gradUp),
-                    static_cast<void *>(d_TA), static_cast<void *>(d_TB), static_cast<void *>(d_speed),
+                    static_cast<void *>(d_Up), static_cast<void *>(d_gradUp),
+                    static_cast<void *>(d_TA), static_cast<void *>(d_TB), static_cast<void *>(d_speed), static_cast<void *>(d_block_speed),
                     static_cast<void *>(d_xh), static_cast<void *>(d_yh), static_cast<void *>(d_shared_slot),
                     static_cast<void *>(d_shared_orient), static_cast<void *>(d_send)})
       if (p) (void)hipFree(p);
@@ -155,9 +154,12 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
   if (op->timing) HIP_CHECK(hipEventRecord(op->ev[2], s));
   if (gradients_only) return;
   exchange(op, 1, op->d_TB, PH::NEQ, C::NQ);
-  HIP_CHECK(hipMemsetAsync(op->d_speed, 0, sizeof(unsigned long long), s));
+  if (!op->d_block_speed) {
+    op->d_block_speed = dev_alloc<double>(grid);
+    op->flux_grid = grid;
+  }
   hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_gradUp, op->d_TA, op->d_TB, y,
-                     op->d_speed);
+                     op->d_block_speed);
   HIP_CHECK(hipGetLastError());
   if (op->timing) {
     HIP_CHECK(hipEventRecord(op->ev[3], s));
@@ -250,8 +252,13 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   op->d_verts = dev_upload(tp.verts);
   op->d_face_nbr = dev_upload(tp.face_nbr);
   op->d_face_orient = dev_upload(tp.face_orient);
-  std::vector<Tables1D> tabs(1, make_tables(op->order, op->dim));
-  op->d_tables = dev_upload(tabs);
+  {
+    // 1-D operator tables -> __constant__ memory; a function of (dim, order) only
+    const Tables1D tabs = make_tables(op->order, op->dim);
+    const size_t off = (static_cast<size_t>(op->dim - 2) * (TPSRHS_MAXORDER + 1) + op->order) * sizeof(Tables1D);
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &tabs, sizeof(Tables1D), off, hipMemcpyHostToDevice));
+  }
+  if (op->ndofs >= (int64_t(1) << 31)) throw Unsupported("more than 2^31 nodes per rank");
   const int64_t nslots = static_cast<int64_t>(op->ne) * op->nfaces + tp.num_shared;
   op->d_Up = dev_alloc<double>(op->neq * op->ndofs);
   op->d_gradUp = dev_alloc<double>(op->dim * op->neq * op->ndofs);
@@ -259,8 +266,8 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   op->d_TB = dev_alloc<double>(nslots * op->neq * op->nq);
   HIP_CHECK(hipMemset(op->d_TA, 0, nslots * 2 * op->neq * op->nf * sizeof(double)));
   HIP_CHECK(hipMemset(op->d_TB, 0, nslots * op->neq * op->nq * sizeof(double)));
-  op->d_speed = dev_alloc<unsigned long long>(1);
-  HIP_CHECK(hipMemset(op->d_speed, 0, sizeof(unsigned long long)));
+  op->d_speed = dev_alloc<double>(1);
+  HIP_CHECK(hipMemset(op->d_speed, 0, sizeof(double)));
   if (tp.num_shared > 0) {
     op->d_shared_slot = dev_upload(tp.shared_slot);
     op->d_shared_orient = dev_upload(tp.shared_orient);
@@ -329,10 +336,10 @@ int tpsrhs_mult(tpsrhs_handle h, const double *x, double *y, double /*time*/, do
     HIP_CHECK(hipSetDevice(h->device));
     h->launch(h, x, y, false);
     if (max_char_speed) {
-      unsigned long long bits = 0;
-      HIP_CHECK(hipMemcpyAsync(&bits, h->d_speed, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
+      hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_speed);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(max_char_speed, h->d_speed, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIP_CHECK(hipStreamSynchronize(h->stream));
-      std::memcpy(max_char_speed, &bits, sizeof(double));
     }
   });
 }
