@@ -60,6 +60,22 @@ __device__ inline double ldsr(const double *p) { return *(lds_cvptr)(p); }
 __device__ inline const double *field_ptr(const double *base, int k, int64_t stride) { return base + k * stride; }
 __device__ inline double *field_ptr(double *base, int k, int64_t stride) { return base + k * stride; }
 
+// Synchronisation between the LDS stages of a block.  A single-wave workgroup needs no hardware
+// barrier and no wait: the LDS executes the DS instructions of one wave in issue order, so a ds_read
+// that follows a ds_write in program order sees it.  __syncthreads() would also drain the VMEM
+// counter (vmcnt(0)) at every stage and expose the latency of every prefetched global load; the
+// wave barrier only stops the compiler from reordering across it.
+template <int BLOCK>
+__device__ inline void block_sync() {
+  if (BLOCK == 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 template <int DIM_, int P_>
 struct Cfg {
   static constexpr int DIM = DIM_, P = P_, N1 = P_ + 1;
@@ -93,9 +109,18 @@ struct MeshDev {
   int ne;
   int64_t ndofs;
   const double *verts;         // [ne][NV][DIM] lexicographic corners
-  const int32_t *face_nbr;     // [ne*NFACES]
-  const uint8_t *face_orient;  // [ne*NFACES]
+  const int2 *face_info;       // [ne*NFACES] {neighbour slot | -(bc+1), orientation code}
 };
+
+// Face records of the block's elements -> LDS, once, so that no later stage has a global load on the
+// path to a neighbour address (nb = INT32_MIN marks the faces of elements past the end of the mesh).
+template <class C>
+__device__ inline void load_face_info(int2 *sFI, const MeshDev &m, int e0) {
+  for (int i = threadIdx.x; i < C::EPB * C::NFACES; i += C::BLOCK) {
+    const int e = e0 + i / C::NFACES;
+    sFI[i] = (e < m.ne) ? m.face_info[static_cast<int64_t>(e0) * C::NFACES + i] : make_int2(INT32_MIN, 0);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 template <class C>
@@ -368,26 +393,83 @@ __device__ inline void load_vertices(double *sV, const MeshDev &m, int e0) {
     if (e0 + le < m.ne) sV[i] = m.verts[static_cast<int64_t>(e0) * PER + i];
   }
 }
-// neighbour face-node traces of fields [f0, f0+NFLD) of the TA record -> Tnb[fld][TN], permuted into
-// my frame; boundary faces copy my own trace (already in Town[fld][TN])
+// Neighbour face-node traces of fields [f0, f0+NFLD) of the TA records of one direction pair, held in
+// registers: issued early (the global latency overlaps other work), stored to LDS when the pass runs.
+template <class C, int NFLD>
+struct NbTraces {
+  static constexpr int ROUNDS = (C::TN + C::BLOCK - 1) / C::BLOCK;
+  double v[ROUNDS][NFLD];
+  int nb[ROUNDS];  // INT32_MIN: no item; < 0: boundary face; >= 0: neighbour slot (values loaded)
+};
 template <class C, int D, int NFLD>
-__device__ inline void load_neighbour_traces(const MeshDev &m, int e0, const double *__restrict__ TA, int rec, int f0,
-                                             const double *Town, double *Tnb, int tid) {
-  for (int item = tid; item < C::TN; item += C::BLOCK) {
-    const int pf = item / C::NF, fn = item - pf * C::NF;
-    const int le = pf >> 1, s = pf & 1;
-    const int e = e0 + le;
-    if (e >= m.ne) continue;
-    const int slot = e * C::NFACES + 2 * D + s;
-    const int nb = m.face_nbr[slot];
-    if (nb >= 0) {
-      const int pn = permute<C::DIM>(m.face_orient[slot], C::N1, fn % C::N1, fn / C::N1);
-      const double *src = TA + static_cast<int64_t>(nb) * rec + f0 * C::NF + pn;
+__device__ inline void issue_neighbour_traces(const int2 *sFI, const double *__restrict__ TA, int rec, int f0,
+                                              NbTraces<C, NFLD> &t, int tid) {
 #pragma unroll
-      for (int k = 0; k < NFLD; k++) Tnb[k * C::TN + item] = (TPSRHS_ABLATE & 1) ? 1.0 : src[k * C::NF];
+  for (int r = 0; r < NbTraces<C, NFLD>::ROUNDS; r++) {
+    const int item = tid + r * C::BLOCK;
+    t.nb[r] = INT32_MIN;
+#pragma unroll
+    for (int k = 0; k < NFLD; k++) t.v[r][k] = 0.0;
+    if (item < C::TN) {
+      const int pf = item / C::NF, fn = item - pf * C::NF;
+      const int2 fi = sFI[(pf >> 1) * C::NFACES + 2 * D + (pf & 1)];
+      t.nb[r] = fi.x;
+      if (fi.x >= 0 && !(TPSRHS_ABLATE & 1)) {
+        const int pn = permute<C::DIM>(fi.y, C::N1, fn % C::N1, fn / C::N1);
+        const double *src = TA + static_cast<int64_t>(fi.x) * rec + f0 * C::NF + pn;
+#pragma unroll
+        for (int k = 0; k < NFLD; k++) t.v[r][k] = src[k * C::NF];
+      }
+    }
+  }
+}
+// -> Tnb[fld][TN]; boundary faces copy my own trace (already in Town[fld][TN])
+template <class C, int NFLD>
+__device__ inline void store_neighbour_traces(const NbTraces<C, NFLD> &t, const double *Town, double *Tnb, int tid) {
+#pragma unroll
+  for (int r = 0; r < NbTraces<C, NFLD>::ROUNDS; r++) {
+    const int item = tid + r * C::BLOCK;
+    if (t.nb[r] == INT32_MIN) continue;
+    if (t.nb[r] >= 0) {
+#pragma unroll
+      for (int k = 0; k < NFLD; k++) Tnb[k * C::TN + item] = t.v[r][k];
     } else {
 #pragma unroll
       for (int k = 0; k < NFLD; k++) Tnb[k * C::TN + item] = ldsr(&Town[k * C::TN + item]);
+    }
+  }
+}
+// Viscous normal-flux traces (own and neighbour) at this lane's quadrature points of one direction pair
+template <class C, int NEQ>
+struct NbFlux {
+  double own[C::Q_ROUNDS][NEQ], nbv[C::Q_ROUNDS][NEQ];
+  int nb[C::Q_ROUNDS];
+};
+template <class C, int D, int NEQ>
+__device__ inline void issue_visc_traces(const int2 *sFI, int e0, const double *__restrict__ TB, NbFlux<C, NEQ> &t,
+                                         int tid) {
+#pragma unroll
+  for (int r = 0; r < C::Q_ROUNDS; r++) {
+    const int item = tid + r * C::BLOCK;
+    t.nb[r] = INT32_MIN;
+#pragma unroll
+    for (int k = 0; k < NEQ; k++) t.own[r][k] = t.nbv[r][k] = 0.0;
+    if (item < C::TQ) {
+      const int pf = item / C::NQ, q = item - pf * C::NQ;
+      const int lslot = (pf >> 1) * C::NFACES + 2 * D + (pf & 1);
+      const int2 fi = sFI[lslot];
+      t.nb[r] = fi.x;
+      if (fi.x != INT32_MIN && !(TPSRHS_ABLATE & 1)) {
+        const double *o = TB + (static_cast<int64_t>(e0) * C::NFACES + lslot) * (NEQ * C::NQ) + q;
+#pragma unroll
+        for (int k = 0; k < NEQ; k++) t.own[r][k] = o[k * C::NQ];
+        if (fi.x >= 0) {
+          const int pq = permute<C::DIM>(fi.y, C::Q1, q % C::Q1, q / C::Q1);
+          const double *b2 = TB + static_cast<int64_t>(fi.x) * (NEQ * C::NQ) + pq;
+#pragma unroll
+          for (int k = 0; k < NEQ; k++) t.nbv[r][k] = b2[k * C::NQ];
+        }
+      }
     }
   }
 }
@@ -401,7 +483,7 @@ __device__ inline void traces_dir(const MeshDev &m, int e0, const double *sF, do
                                   const Tables1D &ct, int tid) {
   constexpr int NEQ = PH::NEQ;
   trace_lines<C, D, 2 * NEQ>(sF, sT, ct, tid);
-  __syncthreads();
+  block_sync<C::BLOCK>();
   for (int item = tid; item < C::TN; item += C::BLOCK) {
     const int pf = item / C::NF, fn = item - pf * C::NF;
     const int e = e0 + (pf >> 1);
@@ -410,7 +492,7 @@ __device__ inline void traces_dir(const MeshDev &m, int e0, const double *sF, do
 #pragma unroll
     for (int fld = 0; fld < 2 * NEQ; fld++) out[fld * C::NF] = ldsr(&sT[fld * C::TN + item]);
   }
-  __syncthreads();
+  block_sync<C::BLOCK>();
 }
 
 template <class C, class PH>
@@ -439,7 +521,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Par
       }
     }
   }
-  __syncthreads();
+  block_sync<C::BLOCK>();
   traces_dir<C, PH, 0>(m, e0, sF, sT, TA, ct, tid);
   traces_dir<C, PH, 1>(m, e0, sF, sT, TA, ct, tid);
   if (C::DIM == 3) traces_dir<C, PH, (C::DIM == 3 ? 2 : 0)>(m, e0, sF, sT, TA, ct, tid);
@@ -467,17 +549,18 @@ struct GradLds {
 
 // gradient jump of one direction pair: g += M^-1 sum_faces <phi, (u^ - u) n>
 template <class C, class PH, int D>
-__device__ inline void grad_jump_dir(const MeshDev &m, const typename PH::Params &prm, int e0, const double *sUp,
+__device__ inline void grad_jump_dir(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
+                                     const double *sUp,
                                      double *X, double *Yb, const double *sV, const Tab<C> &tab, const Tables1D &ct,
-                                     const double *__restrict__ TA, bool node_on, int le_n, const int *idx,
+                                     const NbTraces<C, PH::NEQ> &ta, bool node_on, int le_n, const int *idx,
                                      double inv_mass, double *g, int tid) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   trace_lines<C, D, NEQ>(sUp, X, ct, tid);  // own traces -> X[0..NEQ)
-  __syncthreads();
-  load_neighbour_traces<C, D, NEQ>(m, e0, TA, 2 * NEQ * C::NF, NEQ, X, X + NEQ * C::TN, tid);
-  __syncthreads();
+  block_sync<C::BLOCK>();
+  store_neighbour_traces<C, NEQ>(ta, X, X + NEQ * C::TN, tid);
+  block_sync<C::BLOCK>();
   interp1_lines<C, 2 * NEQ>(X, Yb, ct, tid);
-  if (DIM == 3) __syncthreads();
+  if (DIM == 3) block_sync<C::BLOCK>();
   // quadrature points: half jump times weighted normal, all gradient directions at once
   double r[C::Q_ROUNDS][NEQ * DIM];
 #pragma unroll
@@ -490,7 +573,7 @@ __device__ inline void grad_jump_dir(const MeshDev &m, const typename PH::Params
       const int le = pf >> 1, s = pf & 1;
       const int e = e0 + le;
       if (e < m.ne) {
-        const int nb = m.face_nbr[e * C::NFACES + 2 * D + s];
+        const int nb = sFI[le * C::NFACES + 2 * D + s].x;
         double bq[C::N1];
         const int qrow = (DIM == 2) ? q : q / C::Q1;
 #pragma unroll
@@ -513,7 +596,7 @@ __device__ inline void grad_jump_dir(const MeshDev &m, const typename PH::Params
       }
     }
   }
-  __syncthreads();  // X (T) and Y (W) are dead
+  block_sync<C::BLOCK>();  // X (T) and Y (W) are dead
   double *R = (DIM == 2) ? Yb : X;
 #pragma unroll
   for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
@@ -523,21 +606,22 @@ __device__ inline void grad_jump_dir(const MeshDev &m, const typename PH::Params
       for (int k = 0; k < NEQ * DIM; k++) R[k * C::TQ + item] = r[rd][k];
     }
   }
-  __syncthreads();
+  block_sync<C::BLOCK>();
   project1_lines<C, NEQ * DIM>(X, Yb, ct, tid);
-  if (DIM == 3) __syncthreads();
+  if (DIM == 3) block_sync<C::BLOCK>();
   project2_lines<C, NEQ * DIM>(Yb, X, ct, tid);  // 3-D: W2 (Y) -> L (X); 2-D: R (Y) -> L (X)
-  __syncthreads();
+  block_sync<C::BLOCK>();
   if (node_on) {
 #pragma unroll
     for (int k = 0; k < NEQ * DIM; k++) g[k] += inv_mass * lift_pair<C, D>(X + k * C::TN, tab, le_n, idx);
   }
-  __syncthreads();
+  block_sync<C::BLOCK>();
 }
 
 // viscous normal-flux traces of one direction pair
 template <class C, class PH, int D>
-__device__ inline void visc_traces_dir(const MeshDev &m, const typename PH::Params &prm, int e0, const double *sU,
+__device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
+                                       const double *sU,
                                        const double *sG, double *Tb, double *Wb, const double *sV, const Tab<C> &tab,
                                        const Tables1D &ct, double *__restrict__ TB, int tid) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
@@ -554,9 +638,9 @@ __device__ inline void visc_traces_dir(const MeshDev &m, const typename PH::Para
         trace_lines<C, D, NEQ>(src, Tb + half * NEQ * C::TN, ct, tid);
       }
     }
-    __syncthreads();
+    block_sync<C::BLOCK>();
     interp1_lines<C, L::CH>(Tb, Wb, ct, tid);
-    if (DIM == 3) __syncthreads();
+    if (DIM == 3) block_sync<C::BLOCK>();
 #pragma unroll
     for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
       const int item = tid + rd * C::BLOCK;
@@ -571,7 +655,7 @@ __device__ inline void visc_traces_dir(const MeshDev &m, const typename PH::Para
           if (c0 + k < L::NVF) v[rd][c0 + k] = interp2_point<C>(Tb + k * C::TN, Wb + k * C::TW, bq, pf, q);
       }
     }
-    __syncthreads();
+    block_sync<C::BLOCK>();
   }
 #pragma unroll
   for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
@@ -582,7 +666,7 @@ __device__ inline void visc_traces_dir(const MeshDev &m, const typename PH::Para
     const int e = e0 + le;
     if (e >= m.ne) continue;
     const int slot = e * C::NFACES + 2 * D + s;
-    const int nb = m.face_nbr[slot];
+    const int nb = sFI[le * C::NFACES + 2 * D + s].x;
     double fn[NEQ];
     PH::clamp_species(v[rd]);
     double n[DIM], wq, Xq[DIM];
@@ -613,10 +697,18 @@ __global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_GRAD) void k_gradient(MeshDev
   double *sG = pool + L::O_G;    // [NEQ*DIM][NODES]; jump phase: X
   double *sY = pool + L::O_Y;
 
-  load_tables<C>(tab, ct);
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * C::EPB;
+  __shared__ int2 sFI[C::EPB * C::NFACES];
+  load_face_info<C>(sFI, m, e0);
+  load_tables<C>(tab, ct);
   load_vertices<C>(sV, m, e0);
+  block_sync<C::BLOCK>();
+  // neighbour Up traces of all direction pairs: issued first, consumed by the jump passes
+  NbTraces<C, NEQ> ta0, ta1, ta2;
+  issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta0, tid);
+  issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta1, tid);
+  if (DIM == 3) issue_neighbour_traces<C, (DIM == 3 ? 2 : 0), NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta2, tid);
   const bool node_on = tid < C::NODES && (e0 + tid / C::NPE) < m.ne;
   const int le_n = tid / C::NPE, nd = tid - le_n * C::NPE;
   int idx[3] = {nd % C::N1, (nd / C::N1) % C::N1, nd / (C::N1 * C::N1)};
@@ -632,7 +724,7 @@ __global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_GRAD) void k_gradient(MeshDev
       sUp[eq * C::NODES + tid] = up[eq];
     }
   }
-  __syncthreads();
+  block_sync<C::BLOCK>();
 
   // ---- volume part: collocation derivative (Ke then M^-1 of the reference collapse to it)
   double g[NEQ * DIM];  // g[eq + d*NEQ]
@@ -680,10 +772,10 @@ __global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_GRAD) void k_gradient(MeshDev
 
   // ---- face part, one direction pair at a time (X lives in the sG region, not yet in use)
   if (!(TPSRHS_ABLATE & 8)) {
-    grad_jump_dir<C, PH, 0>(m, prm, e0, sUp, sG, sY, sV, tab, ct, TA, node_on, le_n, idx, inv_mass, g, tid);
-    grad_jump_dir<C, PH, 1>(m, prm, e0, sUp, sG, sY, sV, tab, ct, TA, node_on, le_n, idx, inv_mass, g, tid);
+    grad_jump_dir<C, PH, 0>(m, sFI, prm, e0, sUp, sG, sY, sV, tab, ct, ta0, node_on, le_n, idx, inv_mass, g, tid);
+    grad_jump_dir<C, PH, 1>(m, sFI, prm, e0, sUp, sG, sY, sV, tab, ct, ta1, node_on, le_n, idx, inv_mass, g, tid);
     if (DIM == 3)
-      grad_jump_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, prm, e0, sUp, sG, sY, sV, tab, ct, TA, node_on, le_n, idx, inv_mass,
+      grad_jump_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, sFI, prm, e0, sUp, sG, sY, sV, tab, ct, ta2, node_on, le_n, idx, inv_mass,
                                                 g, tid);
   }
 
@@ -695,13 +787,13 @@ __global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_GRAD) void k_gradient(MeshDev
       sG[k * C::NODES + tid] = g[k];
     }
   }
-  __syncthreads();
+  block_sync<C::BLOCK>();
 
   // ---- viscous normal-flux traces (T chunk in the sUp region, W chunk in Y)
   if (!(TPSRHS_ABLATE & 16)) {
-    visc_traces_dir<C, PH, 0>(m, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
-    visc_traces_dir<C, PH, 1>(m, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
-    if (DIM == 3) visc_traces_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
+    visc_traces_dir<C, PH, 0>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
+    visc_traces_dir<C, PH, 1>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
+    if (DIM == 3) visc_traces_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
   }
 }
 
@@ -720,28 +812,25 @@ struct FluxLds {
 template <class C, class PH, int D>
 __device__ inline void face_flux_dir(const MeshDev &m, const typename PH::Params &prm, int e0, const double *sU,
                                      double *X, double *Yb, const double *sV, const Tab<C> &tab, const Tables1D &ct,
-                                     const double *__restrict__ TA, const double *__restrict__ TB, bool node_on,
+                                     const NbTraces<C, PH::NEQ> &ta, const NbFlux<C, PH::NEQ> &tb, bool node_on,
                                      int le_n, const int *idx, double *z, int tid) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   trace_lines<C, D, NEQ>(sU, X, ct, tid);
-  __syncthreads();
-  load_neighbour_traces<C, D, NEQ>(m, e0, TA, 2 * NEQ * C::NF, 0, X, X + NEQ * C::TN, tid);
-  __syncthreads();
+  block_sync<C::BLOCK>();
+  store_neighbour_traces<C, NEQ>(ta, X, X + NEQ * C::TN, tid);
+  block_sync<C::BLOCK>();
   interp1_lines<C, 2 * NEQ>(X, Yb, ct, tid);
-  if (DIM == 3) __syncthreads();
+  if (DIM == 3) block_sync<C::BLOCK>();
   double fh[C::Q_ROUNDS][NEQ];
 #pragma unroll
   for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
     const int item = tid + rd * C::BLOCK;
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] = 0.0;
-    if (item >= C::TQ) continue;
+    const int nb = tb.nb[rd];
+    if (nb == INT32_MIN) continue;
     const int pf = item / C::NQ, q = item - pf * C::NQ;
     const int le = pf >> 1, s = pf & 1;
-    const int e = e0 + le;
-    if (e >= m.ne) continue;
-    const int slot = e * C::NFACES + 2 * D + s;
-    const int nb = m.face_nbr[slot];
     double bq[C::N1];
     const int qrow = (DIM == 2) ? q : q / C::Q1;
 #pragma unroll
@@ -755,30 +844,25 @@ __device__ inline void face_flux_dir(const MeshDev &m, const typename PH::Params
     PH::clamp_species(u1);
     double n[DIM], wq, Xq[DIM];
     face_geometry<C, D>(&sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
-    const double *tb_own = TB + static_cast<int64_t>(slot) * (NEQ * C::NQ) + q;
     if (TPSRHS_ABLATE & 4) {
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] = u1[eq] + u2[eq] * n[0];
     } else if (nb >= 0) {
       PH::clamp_species(u2);
       PH::lax_friedrichs(prm, u1, u2, n, fh[rd]);
-      const int pq = permute<DIM>(m.face_orient[slot], C::Q1, q % C::Q1, q / C::Q1);
-      const double *tb_nb = TB + static_cast<int64_t>(nb) * (NEQ * C::NQ) + pq;
-      if (!(TPSRHS_ABLATE & 1)) {
 #pragma unroll
-        for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] -= 0.5 * (tb_own[eq * C::NQ] - tb_nb[eq * C::NQ]);
-      }
+      for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] -= 0.5 * (tb.own[rd][eq] - tb.nbv[rd][eq]);
     } else {
       double ug[NEQ];
       PH::bc_ghost(prm, prm.bc[-nb - 1], u1, n, ug);
       PH::lax_friedrichs(prm, u1, ug, n, fh[rd]);
 #pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] += tb_own[eq * C::NQ];
+      for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] += tb.own[rd][eq];
     }
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] *= wq;
   }
-  __syncthreads();  // X (T) and Y (W) are dead
+  block_sync<C::BLOCK>();  // X (T) and Y (W) are dead
   double *R = (DIM == 2) ? Yb : X;
 #pragma unroll
   for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
@@ -788,16 +872,16 @@ __device__ inline void face_flux_dir(const MeshDev &m, const typename PH::Params
       for (int eq = 0; eq < NEQ; eq++) R[eq * C::TQ + item] = fh[rd][eq];
     }
   }
-  __syncthreads();
+  block_sync<C::BLOCK>();
   project1_lines<C, NEQ>(X, Yb, ct, tid);
-  if (DIM == 3) __syncthreads();
+  if (DIM == 3) block_sync<C::BLOCK>();
   project2_lines<C, NEQ>(Yb, X, ct, tid);
-  __syncthreads();
+  block_sync<C::BLOCK>();
   if (node_on) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) z[eq] -= lift_pair<C, D>(X + eq * C::TN, tab, le_n, idx);
   }
-  __syncthreads();
+  block_sync<C::BLOCK>();
 }
 
 template <class C, class PH>
@@ -815,10 +899,17 @@ __global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_FLUX) void k_flux(MeshDev m, 
   double *sGf = pool + NEQ * C::NODES;  // [NEQ*DIM][NODES] contravariant nodal flux; later X | Y
   double *sX = sGf, *sY = sGf + L::X;
 
-  load_tables<C>(tab, ct);
   const int tid = threadIdx.x;
   const int e0 = blockIdx.x * C::EPB;
+  __shared__ int2 sFI[C::EPB * C::NFACES];
+  load_face_info<C>(sFI, m, e0);
+  load_tables<C>(tab, ct);
   load_vertices<C>(sV, m, e0);
+  block_sync<C::BLOCK>();
+  NbTraces<C, NEQ> ta0;
+  NbFlux<C, NEQ> tb0;
+  issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta0, tid);
+  issue_visc_traces<C, 0, NEQ>(sFI, e0, TB, tb0, tid);
   const bool node_on = tid < C::NODES && (e0 + tid / C::NPE) < m.ne;
   const int le_n = tid / C::NPE, nd = tid - le_n * C::NPE;
   int idx[3] = {nd % C::N1, (nd / C::N1) % C::N1, nd / (C::N1 * C::N1)};
@@ -833,7 +924,7 @@ __global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_FLUX) void k_flux(MeshDev m, 
 #pragma unroll
     for (int k = 0; k < NEQ * DIM; k++) gr[k] = field_ptr(gradUp, k, m.ndofs)[n];
   }
-  __syncthreads();  // tables + vertices + sU
+  block_sync<C::BLOCK>();  // tables + vertices + sU
 
   // ---- nodal flux F_c - F_v (src/rhs_operator.cpp:493-559), contravariant components.
   // Ordered to keep the register peak low: physics first (U, gradUp -> 15 flux entries), then the
@@ -898,7 +989,7 @@ __global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_FLUX) void k_flux(MeshDev m, 
     } else {
       __shared__ double swave[C::BLOCK / 64];
       if ((tid & 63) == 0) swave[tid >> 6] = v;
-      __syncthreads();
+      block_sync<C::BLOCK>();
       if (tid == 0) {
         double b = swave[0];
 #pragma unroll
@@ -907,7 +998,7 @@ __global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_FLUX) void k_flux(MeshDev m, 
       }
     }
   }
-  __syncthreads();  // sGf complete
+  block_sync<C::BLOCK>();  // sGf complete
 
   // ---- volume term: z_j = sum_m sum_a D[a][j_m] Ghat_m(a)   (src/domain_integrator.cpp:45-99)
   double z[NEQ];
@@ -932,14 +1023,24 @@ __global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_FLUX) void k_flux(MeshDev m, 
       z[eq] = acc;
     }
   }
-  __syncthreads();  // sGf dead: its region becomes X | Y
+  block_sync<C::BLOCK>();  // sGf dead: its region becomes X | Y
 
   // ---- face term, one direction pair at a time
   if (!(TPSRHS_ABLATE & 8)) {
-    face_flux_dir<C, PH, 0>(m, prm, e0, sU, sX, sY, sV, tab, ct, TA, TB, node_on, le_n, idx, z, tid);
-    face_flux_dir<C, PH, 1>(m, prm, e0, sU, sX, sY, sV, tab, ct, TA, TB, node_on, le_n, idx, z, tid);
+    // software pipeline over the direction pairs: the traces of pair d+1 are in flight while pair d runs
+    NbTraces<C, NEQ> ta1, ta2;
+    NbFlux<C, NEQ> tb1, tb2;
+    issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta1, tid);
+    issue_visc_traces<C, 1, NEQ>(sFI, e0, TB, tb1, tid);
+    face_flux_dir<C, PH, 0>(m, prm, e0, sU, sX, sY, sV, tab, ct, ta0, tb0, node_on, le_n, idx, z, tid);
+    if (DIM == 3) {
+      issue_neighbour_traces<C, (DIM == 3 ? 2 : 0), NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta2, tid);
+      issue_visc_traces<C, (DIM == 3 ? 2 : 0), NEQ>(sFI, e0, TB, tb2, tid);
+    }
+    face_flux_dir<C, PH, 1>(m, prm, e0, sU, sX, sY, sV, tab, ct, ta1, tb1, node_on, le_n, idx, z, tid);
     if (DIM == 3)
-      face_flux_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, prm, e0, sU, sX, sY, sV, tab, ct, TA, TB, node_on, le_n, idx, z, tid);
+      face_flux_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, prm, e0, sU, sX, sY, sV, tab, ct, ta2, tb2, node_on, le_n, idx, z,
+                                                tid);
   }
 
   if (node_on) {

@@ -67,8 +67,7 @@ struct tpsrhs_operator {
   DryAirParams dry;
   // device data
   double *d_verts = nullptr;
-  int32_t *d_face_nbr = nullptr;
-  uint8_t *d_face_orient = nullptr;
+  int2 *d_face_info = nullptr;
   double *d_Up = nullptr, *d_gradUp = nullptr, *d_TA = nullptr, *d_TB = nullptr;
   double *d_speed = nullptr, *d_block_speed = nullptr;
   int flux_grid = 0;
@@ -95,13 +94,12 @@ struct tpsrhs_operator {
     m.ne = ne;
     m.ndofs = ndofs;
     m.verts = d_verts;
-    m.face_nbr = d_face_nbr;
-    m.face_orient = d_face_orient;
+    m.face_info = d_face_info;
     return m;
   }
   ~tpsrhs_operator() {
     (void)hipSetDevice(device);
-    for (void *p : {static_cast<void *>(d_verts), static_cast<void *>(d_face_nbr), static_cast<void *>(d_face_orient),
+    for (void *p : {static_cast<void *>(d_verts), static_cast<void *>(d_face_info),
                     static_cast<void *>(d_Up), static_cast<void *>(d_gradUp),
                     static_cast<void *>(d_TA), static_cast<void *>(d_TB), static_cast<void *>(d_speed), static_cast<void *>(d_block_speed),
                     static_cast<void *>(d_xh), static_cast<void *>(d_yh), static_cast<void *>(d_shared_slot),
@@ -250,8 +248,11 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     pick_order<2, DryAirPhys<2>>(op);
 
   op->d_verts = dev_upload(tp.verts);
-  op->d_face_nbr = dev_upload(tp.face_nbr);
-  op->d_face_orient = dev_upload(tp.face_orient);
+  {
+    std::vector<int2> fi(tp.face_nbr.size());
+    for (size_t i = 0; i < fi.size(); i++) fi[i] = make_int2(tp.face_nbr[i], tp.face_orient[i]);
+    op->d_face_info = dev_upload(fi);
+  }
   {
     // 1-D operator tables -> __constant__ memory; a function of (dim, order) only
     const Tables1D tabs = make_tables(op->order, op->dim);
