@@ -653,6 +653,31 @@ int tpsoracle_point_flux_transport(void *h, const double *state, const double *g
   op->transport->ComputeFluxTransportProperties(state, gradUp, E, -1.0, 0.0, buffer4, diffVel);
   return 0;
 }
+// collision-integral fits by name id: 0 att11, 1 att12, 2 att13, 3 att14, 4 att15, 5 rep22, 6 rep23,
+// 7 rep24 (argument: nondimensional temperature); 8 ArAr22, 9 ArAr1P11, 10..14 eAr1r r=1..5 (argument: T in K)
+double tpsoracle_collision_integral(int id, double x) {
+  using namespace tpsoracle::collision;
+  switch (id) {
+    case 0: return charged::att11(x);
+    case 1: return charged::att12(x);
+    case 2: return charged::att13(x);
+    case 3: return charged::att14(x);
+    case 4: return charged::att15(x);
+    case 5: return charged::rep22(x);
+    case 6: return charged::rep23(x);
+    case 7: return charged::rep24(x);
+    case 8: return argon::ArAr22(x);
+    case 9: return argon::ArAr1P11(x);
+    default: return (id >= 10 && id <= 14) ? argon::eAr1r(id - 9, x) : 0.0;
+  }
+}
+int tpsoracle_point_source_transport(void *h, const double *state, const double *prim, const double *gradUp,
+                                     double *global1, double *species, double *diffVel, double *n_sp) {
+  Operator *op = static_cast<Operator *>(h);
+  double E[3] = {0, 0, 0};
+  op->transport->ComputeSourceTransportProperties(state, prim, gradUp, E, 0.0, global1, species, diffVel, n_sp);
+  return 0;
+}
 int tpsoracle_point_source(void *h, const double *state, const double *prim, const double *gradUp, double *src) {
   Operator *op = static_cast<Operator *>(h);
   if (!op->source) return 1;

@@ -55,6 +55,9 @@ def lib():
         L.tpsoracle_point_bdr_flux.argtypes = [vp, C.c_int, _dp, _dp, _dp, C.c_double, _dp]
         L.tpsoracle_point_flux_transport.argtypes = [vp, _dp, _dp, _dp, _dp]
         L.tpsoracle_point_source.argtypes = [vp, _dp, _dp, _dp, _dp]
+        L.tpsoracle_point_source_transport.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.tpsoracle_collision_integral.restype = C.c_double
+        L.tpsoracle_collision_integral.argtypes = [C.c_int, C.c_double]
         _lib = L
     return _lib
 
@@ -197,3 +200,35 @@ class Oracle:
         if st != 0:
             raise RuntimeError("oracle: " + lib().tpsoracle_last_error().decode())
         return out
+
+    def flux_transport(self, state, grad):
+        """(viscosity, bulk, k_heavy, k_electron), diffusion velocities [sp + d*nsp]"""
+        buf = np.zeros(4)
+        V = np.zeros(3 * 8)
+        lib().tpsoracle_point_flux_transport(self.h, _p(np.ascontiguousarray(state, dtype=np.float64)),
+                                             _p(np.ascontiguousarray(grad, dtype=np.float64)), _p(buf), _p(V))
+        return buf, V
+
+    def source_transport(self, state, prim, grad):
+        """electric conductivity, momentum-transfer frequencies, diffusion velocities, number densities"""
+        g, sp, V, n = np.zeros(8), np.zeros(8), np.zeros(24), np.zeros(8)
+        lib().tpsoracle_point_source_transport(self.h, _p(np.ascontiguousarray(state, dtype=np.float64)),
+                                               _p(np.ascontiguousarray(prim, dtype=np.float64)),
+                                               _p(np.ascontiguousarray(grad, dtype=np.float64)), _p(g), _p(sp), _p(V), _p(n))
+        return g[0], sp, V, n
+
+    def source(self, state, prim, grad):
+        out = np.zeros(self.neq)
+        st = lib().tpsoracle_point_source(self.h, _p(np.ascontiguousarray(state, dtype=np.float64)),
+                                          _p(np.ascontiguousarray(prim, dtype=np.float64)),
+                                          _p(np.ascontiguousarray(grad, dtype=np.float64)), _p(out))
+        if st != 0:
+            raise RuntimeError("oracle: no source term for this physics")
+        return out
+
+
+def collision_integral(name, x):
+    ids = {"att11": 0, "att12": 1, "att13": 2, "att14": 3, "att15": 4, "rep22": 5, "rep23": 6, "rep24": 7,
+           "ArAr22": 8, "ArAr1P11": 9, "eAr11": 10, "eAr12": 11, "eAr13": 12, "eAr14": 13, "eAr15": 14}
+    return lib().tpsoracle_collision_integral(ids[name], float(x))
+

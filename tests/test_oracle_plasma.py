@@ -1,0 +1,166 @@
+"""CPU checks of the oracle's plasma closures (PerfectMixture, argon transport, chemistry, sources).
+
+The reference's own regression data for these paths are git-LFS pointers, so the
+restatement is pinned by (i) the two collision-integral known answers SURVEY.md records from the
+reference's collision_integrals.cpp, (ii) identities the reference's own tests assert
+(test/test_perfect_mixture.cpp style round trips, mole/mass fraction sums, zero net diffusive mass
+flux, zero ambipolar current) and (iii) independent numpy restatements of closed-form formulas.
+"""
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, collision_integral
+from tps_amd import capi, cases, meshgen
+
+R = capi.UNIVERSALGASCONSTANT
+
+
+def tiny_oracle(two_t=False, transport=capi.ARGON_MINIMAL, reactions="arrhenius", dim=3, radiation=False):
+    mesh = (meshgen.box_hex(1, 1, 1, periodic=(False,) * 3) if dim == 3 else
+            meshgen.box_quad(1, 1, periodic=(False,) * 2))
+    ph = capi.argon_ternary_physics(capi.NS, two_t, transport, reactions, radiation=radiation)
+    nattr = 6 if dim == 3 else 4
+    bcs = [capi.make_bc(a + 1, capi.WALL, capi.INV) for a in range(nattr)]
+    return Oracle(mesh, capi.Disc(1, 0, 0, 0, 0), ph, bcs), ph
+
+
+def sample_states(ph, nvel, n=64, seed=3):
+    X = np.random.default_rng(seed).uniform(0, 1, size=(nvel if nvel < 3 else 3, n))
+    return cases.plasma_state(X, ph, nvel=nvel, seed=seed).T.copy()
+
+
+def test_collision_integral_known_answers():
+    # SURVEY.md section 7 ("What does compile"): values of the reference's collision_integrals.cpp
+    assert collision_integral("att11", 5.0) == pytest.approx(0.038997464294197495, rel=1e-14)
+    assert collision_integral("eAr11", 1.0e4) == pytest.approx(3.9634368412470003e-20, rel=1e-14)
+    # closed forms (src/collision_integrals.cpp:124-135)
+    assert collision_integral("ArAr22", 8000.0) == pytest.approx(1.7e-18 * 8000.0 ** -0.25, rel=1e-15)
+    assert collision_integral("ArAr1P11", 8000.0) == pytest.approx(4.574321e-18 * 8000.0 ** -0.1805, rel=1e-15)
+    # the charged fits decay monotonically in the nondimensional temperature
+    for name in ("att11", "att12", "att13", "att14", "att15", "rep22", "rep23", "rep24"):
+        v = [collision_integral(name, t) for t in (0.5, 2.0, 8.0, 32.0)]
+        assert all(a > b > 0 for a, b in zip(v, v[1:])), name
+    # Devoto ordering of the e-Ar integrals at 1 eV
+    q = [collision_integral(f"eAr1{r}", 11604.0) for r in range(1, 6)]
+    assert all(x > 0 for x in q)
+
+
+@pytest.mark.parametrize("two_t", [False, True])
+def test_prim_cons_round_trip_and_pressure(two_t):
+    o, ph = tiny_oracle(two_t)
+    for U in sample_states(ph, 3):
+        Up = o.prim(U)
+        U2 = o.cons(Up)
+        assert np.allclose(U2, U, rtol=1e-13, atol=0)
+        # p = R (n_h T_h + n_e T_e) with n_e = n_i (ambipolar), independent restatement
+        mw = [ph.mixture.gas_params[sp] for sp in range(3)]
+        ni = Up[5]
+        nB = (U[0] - ni * mw[0] - ni * mw[1]) / mw[2]
+        Te = Up[6] if two_t else Up[4]
+        assert o.pressure(U) == pytest.approx(R * ((ni + nB) * Up[4] + ni * Te), rel=1e-13)
+        # speed of sound uses the heavies' heat ratio 5/3 (all cv = 1.5 R)
+        c = o.max_char_speed_point(U) - np.linalg.norm(U[1:4]) / U[0]
+        assert c == pytest.approx(np.sqrt(5.0 / 3.0 * o.pressure(U) / U[0]), rel=1e-12)
+
+
+@pytest.mark.parametrize("transport", [capi.ARGON_MINIMAL, capi.CONSTANT])
+@pytest.mark.parametrize("two_t", [False, True])
+def test_diffusion_velocities_conserve_mass_and_charge(transport, two_t):
+    o, ph = tiny_oracle(two_t, transport)
+    rng = np.random.default_rng(5)
+    neq = o.neq
+    mw = np.array([ph.mixture.gas_params[sp] for sp in range(3)])
+    for U in sample_states(ph, 3, n=16):
+        Up = o.prim(U)
+        g = rng.normal(size=(3, neq)) * np.abs(Up)[None, :] * 2.0  # gradUp[eq + d*neq]
+        buf, V = o.flux_transport(U, g.ravel())
+        V = V[:9].reshape(3, 3)  # [d][sp]
+        ni = Up[5]
+        n = np.array([ni, ni, (U[0] - ni * (mw[0] + mw[1])) / mw[2]])
+        Y = n * mw / U[0]
+        assert np.abs(V @ Y).max() < 1e-12 * np.abs(V).max()           # sum_sp Y V = 0
+        q = np.array([1.0, -1.0, 0.0])
+        assert np.abs(V @ (q * n)).max() < 1e-9 * np.abs(V * n).max()  # ambipolar: no net current
+        assert buf[0] > 0 and buf[2] > 0 and buf[3] >= 0
+
+
+def test_argon_viscosity_formula():
+    """neutral-dominated limit: mu -> 5/16 sqrt(pi m kB T) / Q22(T) (src/gas_transport.cpp:261-262)."""
+    o, ph = tiny_oracle()
+    X = np.zeros((3, 1))
+    mw = [ph.mixture.gas_params[sp] for sp in range(3)]
+    T, p = 5000.0, 101300.0
+    alpha = 1e-12
+    nh = p / (R * T)
+    ni = alpha * nh
+    rho = ni * (mw[0] + mw[1]) + (nh - ni) * mw[2]
+    U = cases.plasma_conserved(ph, 3, np.array([rho]), [np.zeros(1)] * 3, np.array([T]), [np.array([ni])])[:, 0]
+    buf, _ = o.flux_transport(U, np.zeros(3 * o.neq))
+    kB = R / 6.0221409e23
+    mu = 5.0 / 16.0 * np.sqrt(np.pi * mw[2] / 6.0221409e23 * kB * T) / (1.7e-18 * T ** -0.25)
+    assert buf[0] == pytest.approx(mu, rel=1e-9)
+    assert buf[2] == pytest.approx(mu * 15.0 / 4.0 * kB / (mw[2] / 6.0221409e23), rel=1e-9)
+    assert buf[1] == 0.0
+
+
+def test_arrhenius_source_against_numpy():
+    o, ph = tiny_oracle(two_t=True)
+    ch = ph.chemistry
+    mw = [ph.mixture.gas_params[sp] for sp in range(3)]
+    for U in sample_states(ph, 3, n=16, seed=9):
+        Up = o.prim(U)
+        g = np.zeros(3 * o.neq)
+        src = o.source(U, Up, g)
+        Th, Te, ni = Up[4], Up[6], Up[5]
+        nB = (U[0] - ni * (mw[0] + mw[1])) / mw[2]
+        n = np.array([ni, ni, nB])
+        w = []
+        for r in range(2):
+            re_ = np.array([ch.reactant_stoich[sp + 3 * r] for sp in range(3)])
+            A, b, E = (ch.rate_params[k + 3 * r] for k in range(3))
+            T = max(Te, 2000.0)  # both reactions involve electrons
+            w.append(A * T ** b * np.exp(-E / R / T) * np.prod(n ** re_))
+        assert src[5] == pytest.approx((w[0] - w[1]) * mw[0], rel=1e-11)
+        assert src[0] == 0 and np.all(src[1:4] == 0)
+        assert src[4] == 0  # no radiation
+        # electron energy: -sum dH_r w_r - elastic exchange (grad = 0)
+        _, mt, _, _ = o.source_transport(U, Up, g)
+        el = sum(1.5 * R * (Te - Th) * 2 * mw[1] * mw[sp] / (mw[sp] + mw[1]) ** 2 * ni * mt[sp] for sp in (0, 2))
+        expect = -(ch.reaction_energies[0] * w[0] + ch.reaction_energies[1] * w[1]) - el
+        assert src[6] == pytest.approx(expect, rel=1e-10)
+
+
+def test_reaction_model_variants():
+    oa, pa = tiny_oracle(reactions="arrhenius")
+    ot, pt = tiny_oracle(reactions="tabulated")
+    ob, pb = tiny_oracle(reactions="balance")
+    oh, _ = tiny_oracle(reactions="hoffertlien")
+    orad, _ = tiny_oracle(radiation=True)
+    for U in sample_states(pa, 3, n=8, seed=11):
+        Up = oa.prim(U)
+        g = np.zeros(3 * oa.neq)
+        sa, st = oa.source(U, Up, g), ot.source(U, Up, g)
+        # a 257-point log-log table of the same law differs by interpolation error only
+        assert st[5] == pytest.approx(sa[5], rel=2e-3, abs=1e-12 * abs(sa[5]))
+        sb = ob.source(U, Up, g)
+        assert np.isfinite(sb).all() and sb[5] != sa[5]
+        assert np.isfinite(oh.source(U, Up, g)).all()
+        sr = orad.source(U, Up, g)
+        T = Up[4]
+        Tt = np.linspace(300.0, 3.0e4, 512)
+        nec = np.interp(T, Tt, 1.0e9 * np.exp(-8.0e4 / Tt))
+        assert sr[4] == pytest.approx(-4.0 * np.pi * nec, rel=1e-12)
+        assert sr[5] == sa[5]
+
+
+def test_species_clamp_offset_is_the_references():
+    """SourceTerm clamps equation 3+2+sp (hard-coded nvel = 3, src/source_term.cpp:129): with nvel = 2
+    that index is past the active species of a ternary mixture, so a negative ion density is NOT
+    clamped there; with nvel = 3 it is."""
+    o3, ph = tiny_oracle()
+    U = sample_states(ph, 3, n=1)[0]
+    Up = o3.prim(U)
+    U[5] = -abs(U[5])
+    Up[5] = -abs(Up[5])
+    s = o3.source(U, Up, np.zeros(3 * o3.neq))
+    assert np.isfinite(s).all() and s[5] == 0.0  # n_i = n_e = 0 after the clamp: no reaction progress

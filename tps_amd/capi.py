@@ -125,6 +125,97 @@ def dry_air_physics(eq_system=NS, visc_mult=1.0, bulk_visc_mult=0.0, gamma=1.4, 
     return ph
 
 
+UNIVERSALGASCONSTANT = 8.3144598  # src/equation_of_state.hpp:55
+
+
+def make_table(x, f, x_log=False, f_log=False, keep=None) -> Table:
+    """TableInput over two float64 arrays; `keep` (a list) receives the arrays so they outlive the call."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    assert x.shape == f.shape and x.ndim == 1
+    if keep is not None:
+        keep += [x, f]
+    return Table(len(x), x.ctypes.data_as(_dp), f.ctypes.data_as(_dp), int(x_log), int(f_log))
+
+
+def argon_ternary_physics(eq_system=NS, two_temperature=False, transport=ARGON_MINIMAL, reactions="arrhenius",
+                          third_order_ke=True, radiation=False) -> Physics:
+    """[plasma_models] of the reference's argon inputs: species (Ar.+1, E, Ar) in mixture order -- active
+    species first, electron second to last, neutral background last (src/M2ulPhyS.cpp:3114-3236);
+    ambipolar; atoms/species values of test/inputs/argonMinimal.ini:70-97; the two Arrhenius reactions
+    (ionisation by electron impact, three-body recombination) of
+    test/inputs/lomach.torch.reacting.ini:185-212, stoichiometry permuted into mixture order."""
+    ph = Physics()
+    keep = []
+    ph.eq_system = eq_system
+    ph.working_fluid = USER_DEFINED
+    m_ar, m_e = 39.948e-3, 5.4858e-7
+    nsp = 3
+    mx = ph.mixture
+    mx.num_species, mx.is_electron_included, mx.ambipolar, mx.two_temperature = nsp, 1, 1, int(two_temperature)
+    mw = [m_ar - m_e, m_e, m_ar]
+    charge = [1.0, -1.0, 0.0]
+    eform = [1520.57e3, 0.0, 0.0]
+    degen = [4.0, 2.0, 1.0]
+    for sp in range(nsp):
+        mx.gas_params[sp + SPECIES_MW * nsp] = mw[sp]
+        mx.gas_params[sp + SPECIES_CHARGES * nsp] = charge[sp]
+        mx.gas_params[sp + FORMATION_ENERGY * nsp] = eform[sp]
+        mx.gas_params[sp + SPECIES_DEGENERACY * nsp] = degen[sp]
+        mx.molar_cv[sp] = 1.5  # in units of R (perfect_mixture/constant_molar_cv)
+    ph.transport_model = transport
+    ct = ph.constant_transport  # values in the spirit of test/inputs/*constant transport* inputs
+    ct.viscosity, ct.bulk_viscosity = 5.0e-5, 0.0
+    ct.thermal_conductivity, ct.electron_thermal_conductivity = 0.05, 0.2
+    for sp, (d, f) in enumerate([(3.0e-3, 1.0e9), (2.0e-1, 0.0), (2.5e-3, 4.0e8)]):
+        ct.diffusivity[sp], ct.mt_freq[sp] = d, f
+    ct.electron_index = 1
+    gt = ph.gas_transport
+    gt.neutral_index, gt.ion_index, gt.electron_index = 2, 0, 1
+    gt.third_order_k_electron = int(third_order_ke)
+    gt.multiply = 0
+    for k in range(4):
+        gt.flux_trns_multiplier[k] = 1.0
+    gt.spcs_trns_multiplier[0] = gt.diff_mult = gt.mobil_mult = 1.0
+    ch = ph.chemistry
+    ch.electron_index = 1
+    ch.minimum_temperature = 2000.0
+    if reactions:
+        ch.num_reactions = 2
+        rxn = [  # reactants, products in mixture order (Ar+, E, Ar); A, b, E; reaction energy
+            ((0, 1, 1), (1, 2, 0), (74072.331348, 1.511, 1176329.772504), 1520571.3883),
+            ((1, 2, 0), (0, 1, 1), (34126.47475259143, 0.368, -377725.908714), -1520571.3883)]
+        for r, (re_, pr, abe, en) in enumerate(rxn):
+            ch.reaction_energies[r] = en
+            ch.detailed_balance[r] = 0
+            ch.reaction_models[r] = ARRHENIUS
+            for sp in range(nsp):
+                ch.reactant_stoich[sp + r * nsp] = re_[sp]
+                ch.product_stoich[sp + r * nsp] = pr[sp]
+            for k in range(3):
+                ch.rate_params[k + r * MAXCHEMPARAMS] = abe[k]
+        if reactions == "tabulated":  # ionisation rate as a log-log table of the same Arrhenius law
+            T = np.geomspace(300.0, 5.0e4, 257)
+            A, b, E = rxn[0][2]
+            ch.reaction_models[0] = TABULATED_RXN
+            ch.rate_tables[0] = make_table(T, A * T ** b * np.exp(-E / UNIVERSALGASCONSTANT / T) + 1e-300, True, True, keep)
+        if reactions == "balance":  # recombination replaced by detailed balance of the ionisation
+            ch.num_reactions = 1
+            ch.detailed_balance[0] = 1
+            for k, v in enumerate((2.9e22 / 6.0221409e23, 1.5, 182850.0)):
+                ch.equilibrium_constant_params[k] = v
+        if reactions == "hoffertlien":
+            ch.reaction_models[0] = HOFFERTLIEN
+            for k, v in enumerate((1.0e-2, 0.5, 1.85e-18)):
+                ch.rate_params[k] = v
+    if radiation:  # smooth stand-in for the NEC table (the reference's nec_sample.0.h5 is an LFS pointer)
+        T = np.linspace(300.0, 3.0e4, 512)
+        ph.radiation.model = NET_EMISSION
+        ph.radiation.nec_table = make_table(T, 1.0e9 * np.exp(-8.0e4 / T), False, False, keep)
+    ph._keep = keep
+    return ph
+
+
 def make_bc(attribute, category, bc_type, data=()) -> BC:
     bc = BC()
     bc.attribute, bc.category, bc.type = attribute, category, bc_type

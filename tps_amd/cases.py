@@ -26,6 +26,8 @@ class Case:
 
     def state(self, seed=12345, amp=0.05, coords=None):
         X = node_coordinates(self.mesh, self.disc.order) if coords is None else coords
+        if self.physics.working_fluid == capi.USER_DEFINED:
+            return plasma_state(X, self.physics, nvel=3 if self.disc.axisymmetric else X.shape[0], seed=seed, amp=amp)
         return dry_air_state(X, seed=seed, amp=amp)
 
 
@@ -55,6 +57,119 @@ def dry_air_state(X, seed=12345, amp=0.05, rho0=1.2, vel0=(20.0, 0.0, 0.0), p0=1
     return U
 
 
+def _waves(X, seed):
+    rng = np.random.Generator(np.random.MT19937(seed))
+    dim = X.shape[0]
+    L = np.maximum(X.max(axis=1) - X.min(axis=1), 1e-12)
+
+    def wave():
+        k = rng.integers(1, 4, size=dim) * 2.0 * np.pi / L
+        ph = rng.uniform(0.0, 2.0 * np.pi)
+        return np.sin(np.tensordot(k, X, axes=(0, 0)) + ph)
+
+    return wave
+
+
+def plasma_conserved(physics, nvel, rho, vel, Th, n_active, Te=None):
+    """PerfectMixture::GetConservativesFromPrimitives (src/equation_of_state.cpp:744-783) on arrays, for
+    the ambipolar mixtures of this package: builds INPUT states only (the kernels and the oracle each
+    have their own closures)."""
+    mx = physics.mixture
+    nsp = mx.num_species
+    nact = nsp - 2 if mx.ambipolar else nsp - 1
+    R = capi.UNIVERSALGASCONSTANT
+    mw = [mx.gas_params[sp + capi.SPECIES_MW * nsp] for sp in range(nsp)]
+    q = [mx.gas_params[sp + capi.SPECIES_CHARGES * nsp] for sp in range(nsp)]
+    ef = [mx.gas_params[sp + capi.FORMATION_ENERGY * nsp] for sp in range(nsp)]
+    cv = [mx.molar_cv[sp] * R for sp in range(nsp)]
+    two_t = bool(mx.two_temperature)
+    neq = nvel + 2 + nact + (1 if two_t else 0)
+    U = np.zeros((neq,) + np.shape(rho))
+    U[0] = rho
+    ke = 0.0
+    for d in range(nvel):
+        U[1 + d] = rho * vel[d]
+        ke = ke + 0.5 * rho * vel[d] ** 2
+    rhoB = np.array(rho, dtype=float)
+    ne = 0.0
+    for sp in range(nact):
+        U[nvel + 2 + sp] = n_active[sp] * mw[sp]
+        rhoB = rhoB - n_active[sp] * mw[sp]
+        ne = ne + q[sp] * n_active[sp]
+    if mx.ambipolar:
+        rhoB = rhoB - ne * mw[nsp - 2]
+    else:
+        ne = n_active[nsp - 2]
+    nB = rhoB / mw[nsp - 1]
+    assert np.all(nB > 0)
+    ch = nB * cv[nsp - 1]
+    for sp in range(nact):
+        if sp != nsp - 2:
+            ch = ch + n_active[sp] * cv[sp]
+    e = ke + ch * Th
+    Te = Th if Te is None else Te
+    ee = ne * cv[nsp - 2] * Te
+    e = e + ee
+    if two_t:
+        U[neq - 1] = ee
+    for sp in range(nsp - 2):
+        e = e + n_active[sp] * ef[sp]
+    U[nvel + 1] = e
+    return U
+
+
+def plasma_state(X, physics, nvel, seed=12345, amp=0.05, p0=101300.0, vel0=(20.0, 0.0, 0.0)):
+    """Smooth argon-plasma state: T_h in [3000, 12000] K, ionisation degree in
+    [1e-6, 1e-2] (log-uniform waves), pressure p0(1 + amp wave), velocity free stream + amp waves,
+    T_e = T_h (1 + 0.3 + 0.2 wave) for two-temperature mixtures."""
+    wave = _waves(X, seed)
+    R = capi.UNIVERSALGASCONSTANT
+    mx = physics.mixture
+    nsp = mx.num_species
+    mw = [mx.gas_params[sp + capi.SPECIES_MW * nsp] for sp in range(nsp)]
+    scale = min(1.0, amp / 0.05)
+    Th = 7500.0 + 4500.0 * scale * wave()
+    alpha = 10.0 ** (-4.0 + 2.0 * scale * wave())
+    p = p0 * (1.0 + amp * wave())
+    Te = Th * (1.3 + 0.2 * wave()) if mx.two_temperature else None
+    vel = [vel0[d] + amp * 20.0 * wave() for d in range(nvel)]
+    # p = R (n_h T_h + n_e T_e), n_e = n_i = alpha n_h'  with n_h = n_i + n_B
+    TeE = Th if Te is None else Te
+    nh = p / (R * (Th + alpha * TeE))
+    ni = alpha * nh
+    nB = nh - ni
+    rho = ni * mw[0] + ni * mw[nsp - 2] + nB * mw[nsp - 1]
+    return plasma_conserved(physics, nvel, rho, vel, Th, [ni], Te)
+
+
+def argon_inlet_state(physics, nvel, T=6000.0, alpha=1.0e-4, p0=101300.0, vel0=(20.0, 0.0, 0.0)):
+    """rho, u, v, w, rho Y_active of a uniform argon free stream: the inlet data of SUB_DENS_VEL."""
+    R = capi.UNIVERSALGASCONSTANT
+    mx = physics.mixture
+    nsp = mx.num_species
+    mw = [mx.gas_params[sp + capi.SPECIES_MW * nsp] for sp in range(nsp)]
+    nh = p0 / (R * T * (1.0 + alpha))
+    ni = alpha * nh
+    rho = ni * mw[0] + ni * mw[nsp - 2] + (nh - ni) * mw[nsp - 1]
+    return [rho, vel0[0], vel0[1], vel0[2], ni * mw[0]]
+
+
+def plasma_cylinder_bcs(physics, wall_type=capi.VISC_ISOTH, t_wall=3000.0):
+    inlet = capi.make_bc(1, capi.INLET, capi.SUB_DENS_VEL, argon_inlet_state(physics, 3))
+    outlet = capi.make_bc(2, capi.OUTLET, capi.SUB_P, [101300.0])
+    wall = capi.make_bc(3, capi.WALL, wall_type, [t_wall])
+    return [inlet, outlet, wall]
+
+
+def argon_cyl3d(nr, ntheta, nz, order, two_temperature=False, transport=capi.ARGON_MINIMAL, reactions="arrhenius",
+                wall_type=capi.VISC_ISOTH, eq_system=capi.NS, radiation=False, name=None):
+    """O-grid cylinder in an argon plasma stream (ambipolar ternary mixture)."""
+    mesh = meshgen.ogrid_cylinder(nr, ntheta, nz)
+    ph = capi.argon_ternary_physics(eq_system, two_temperature, transport, reactions, radiation=radiation)
+    return Case(name or f"argon_cyl3d_{nr}x{ntheta}x{nz}_p{order}", mesh, capi.Disc(order, 0, 0, 0, 0), ph,
+                plasma_cylinder_bcs(ph, wall_type), "O-grid cylinder, argon ternary plasma")
+
+
 def cylinder_bcs(wall_type=capi.VISC_ISOTH, t_wall=300.0, dim=3):
     inlet = capi.make_bc(1, capi.INLET, capi.SUB_DENS_VEL, [1.2, 20.0, 0.0, 0.0])
     outlet = capi.make_bc(2, capi.OUTLET, capi.SUB_P, [101300.0])
@@ -77,6 +192,8 @@ def config(i: int) -> Case:
         return cyl3d(10, 24, 8, 1, capi.EULER, name="cfg1_cyl3d_euler_p1")
     if i == 2:
         return cyl3d(28, 112, 16, 3, capi.NS, name="cfg2_cyl3d_ns_p3")
+    if i == 3:
+        return argon_cyl3d(28, 112, 16, 2, name="cfg3_argon_minimal_p2")
     if i == 4:
         return cyl3d(56, 224, 32, 3, capi.NS, name="cfg4_cyl3d_ns_p3_8gpu")
     raise NotImplementedError(f"configuration {i} is not built yet")

@@ -43,7 +43,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // 1-D operator tables of every (dim, order), filled by tpsrhs_create.  Identical for all operators of
 // a process (they depend on (dim, p) only).  Indexed with compile-time constants they are scalar loads.
-__constant__ Tables1D c_tab[2][TPSRHS_MAXORDER + 1];
+static __constant__ Tables1D c_tab[2][TPSRHS_MAXORDER + 1];
 
 // LDS read of one double (a hook: a volatile-typed variant that stops hipcc from fusing neighbouring
 // 8-byte reads into ds_read2_b64 was measured and dropped -- volatile LDS accesses are followed by a
@@ -679,7 +679,7 @@ __device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const 
 }
 
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_GRAD) void k_gradient(MeshDev m, typename PH::Params prm,
+__global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m, typename PH::Params prm,
                                                        const double *__restrict__ U, const double *__restrict__ TA,
                                                        double *__restrict__ gradUp, double *__restrict__ TB) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
@@ -881,7 +881,7 @@ __device__ inline void face_flux_dir(const MeshDev &m, const typename PH::Params
 }
 
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_FLUX) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
+__global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
                                                    const double *__restrict__ gradUp, const double *__restrict__ TA,
                                                    const double *__restrict__ TB, double *__restrict__ Y,
                                                    double *__restrict__ block_speed) {
@@ -1047,13 +1047,14 @@ __global__ __launch_bounds__(C::BLOCK, TPSRHS_MINW_FLUX) void k_flux(MeshDev m, 
 }
 
 // max over the per-block maxima written by k_flux (one block)
+template <int BLOCK>
 __global__ void k_reduce_max(int n, const double *__restrict__ v, double *__restrict__ out) {
-  __shared__ double s[256];
+  __shared__ double s[BLOCK];
   double m = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, v[i]);
+  for (int i = threadIdx.x; i < n; i += BLOCK) m = fmax(m, v[i]);
   s[threadIdx.x] = m;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = BLOCK / 2; off > 0; off >>= 1) {
     if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
     __syncthreads();
   }

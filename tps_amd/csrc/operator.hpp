@@ -1,0 +1,192 @@
+// Shared by the translation units of libtpsrhs.so: the operator object behind tpsrhs_handle and the
+// templated launch sequence of one RHS evaluation.  Kernels are instantiated per physics family in
+// separate .hip files (compiled in parallel); each has its own copy of the __constant__ tables.
+#ifndef TPSRHS_OPERATOR_HPP_
+#define TPSRHS_OPERATOR_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tpsrhs.h"
+#include "basis.hpp"
+#include "kernels.hpp"
+#include "topology.hpp"
+
+using namespace tpsrhs;
+
+namespace {
+
+struct DeviceError : std::runtime_error {
+  explicit DeviceError(const std::string &s) : std::runtime_error(s) {}
+};
+struct Unsupported : std::runtime_error {
+  explicit Unsupported(const std::string &s) : std::runtime_error(s) {}
+};
+
+#define HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess)                                                                                 \
+      throw DeviceError(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+
+template <class T>
+T *dev_alloc(size_t n) {
+  T *p = nullptr;
+  HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)));
+  return p;
+}
+template <class T>
+T *dev_upload(const std::vector<T> &v) {
+  T *p = dev_alloc<T>(v.size());
+  if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return p;
+}
+
+constexpr int NKERN = 3;
+const char *kKernelNames[NKERN] = {"k_traces", "k_gradient", "k_flux"};
+
+}  // namespace
+
+struct tpsrhs_operator {
+  int dim = 0, order = 0, neq = 0, nvel = 0;
+  int ne = 0, nfaces = 0, nf = 0, nq = 0;
+  int64_t ndofs = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Topology topo;
+  tpsrhs_physics phys;
+  alignas(16) unsigned char params[4096];  // PH::Params of the selected physics, passed by value
+  void *d_chem = nullptr;                   // ChemDev block + table storage (plasma)
+  std::vector<void *> d_extra;
+  // device data
+  double *d_verts = nullptr;
+  int2 *d_face_info = nullptr;
+  double *d_Up = nullptr, *d_gradUp = nullptr, *d_TA = nullptr, *d_TB = nullptr;
+  double *d_speed = nullptr, *d_block_speed = nullptr;
+  int flux_grid = 0;
+  double *d_xh = nullptr, *d_yh = nullptr;  // staging for tpsrhs_mult_host
+  // halo
+  tpsrhs_halo_fn halo = nullptr;
+  void *halo_ctx = nullptr;
+  int32_t *d_shared_slot = nullptr;
+  uint8_t *d_shared_orient = nullptr;
+  double *d_send = nullptr;
+  std::vector<int64_t> send_off[2], recv_off[2];
+  // timing
+  // per-kernel timing: a ring of event sets so that a timed loop never synchronises
+  static constexpr int MAXSETS = 128;
+  bool timing = false;
+  hipEvent_t evs[MAXSETS][NKERN + 1] = {};
+  int64_t sets_recorded = 0;
+  hipEvent_t *ev = evs[0];
+
+  void (*launch)(tpsrhs_operator *, const double *, double *, bool) = nullptr;
+
+  MeshDev mesh_dev() const {
+    MeshDev m;
+    m.ne = ne;
+    m.ndofs = ndofs;
+    m.verts = d_verts;
+    m.face_info = d_face_info;
+    return m;
+  }
+  ~tpsrhs_operator() {
+    (void)hipSetDevice(device);
+    for (void *p : {static_cast<void *>(d_verts), static_cast<void *>(d_face_info),
+                    static_cast<void *>(d_Up), static_cast<void *>(d_gradUp),
+                    static_cast<void *>(d_TA), static_cast<void *>(d_TB), static_cast<void *>(d_speed), static_cast<void *>(d_block_speed),
+                    static_cast<void *>(d_xh), static_cast<void *>(d_yh), static_cast<void *>(d_shared_slot),
+                    static_cast<void *>(d_shared_orient), static_cast<void *>(d_send)})
+      if (p) (void)hipFree(p);
+    if (d_chem) (void)hipFree(d_chem);
+    for (void *p : d_extra) (void)hipFree(p);
+    for (auto &set : evs)
+      for (auto &e : set)
+        if (e) (void)hipEventDestroy(e);
+  }
+};
+
+namespace {
+
+inline void exchange(tpsrhs_operator *op, int phase, double *T, int nfld, int per) {
+  const Topology &tp = op->topo;
+  if (tp.num_shared == 0) return;
+  const int n1 = (phase == 0) ? op->order + 1 : ((op->dim - 1) + 2 * op->order) / 2 + 1;
+  const int64_t total = static_cast<int64_t>(tp.num_shared) * nfld * per;
+  const int grid = static_cast<int>(std::min<int64_t>((total + 255) / 256, 2048));
+  if (op->dim == 3)
+    hipLaunchKernelGGL(k_pack<3>, dim3(grid), dim3(256), 0, op->stream, tp.num_shared, nfld, n1, op->d_shared_slot,
+                       op->d_shared_orient, T, op->d_send);
+  else
+    hipLaunchKernelGGL(k_pack<2>, dim3(grid), dim3(256), 0, op->stream, tp.num_shared, nfld, n1, op->d_shared_slot,
+                       op->d_shared_orient, T, op->d_send);
+  HIP_CHECK(hipGetLastError());
+  double *recv = T + static_cast<int64_t>(op->ne) * op->nfaces * nfld * per;
+  const int st = op->halo(op->halo_ctx, phase, op->d_send, recv, static_cast<int>(tp.nbr_ranks.size()),
+                          tp.nbr_ranks.data(), op->send_off[phase].data(), op->recv_off[phase].data(), op->stream);
+  if (st != 0) throw std::runtime_error("halo callback failed in phase " + std::to_string(phase));
+}
+
+template <int DIM, int P, class PH>
+void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_only) {
+  typedef Cfg<DIM, P> C;
+  const MeshDev m = op->mesh_dev();
+  const int grid = (op->ne + C::EPB - 1) / C::EPB;
+  static_assert(sizeof(typename PH::Params) <= sizeof(op->params), "parameter block too large");
+  const typename PH::Params &prm = *reinterpret_cast<const typename PH::Params *>(op->params);
+  hipStream_t s = op->stream;
+  if (op->timing) {
+    op->ev = op->evs[op->sets_recorded % tpsrhs_operator::MAXSETS];
+    HIP_CHECK(hipEventRecord(op->ev[0], s));
+  }
+  hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_Up, op->d_TA);
+  HIP_CHECK(hipGetLastError());
+  if (op->timing) HIP_CHECK(hipEventRecord(op->ev[1], s));
+  exchange(op, 0, op->d_TA, 2 * PH::NEQ, C::NF);
+  hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_TA, op->d_gradUp, op->d_TB);
+  HIP_CHECK(hipGetLastError());
+  if (op->timing) HIP_CHECK(hipEventRecord(op->ev[2], s));
+  if (gradients_only) return;
+  exchange(op, 1, op->d_TB, PH::NEQ, C::NQ);
+  if (!op->d_block_speed) {
+    op->d_block_speed = dev_alloc<double>(grid);
+    op->flux_grid = grid;
+  }
+  hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_gradUp, op->d_TA, op->d_TB, y,
+                     op->d_block_speed);
+  HIP_CHECK(hipGetLastError());
+  if (op->timing) {
+    HIP_CHECK(hipEventRecord(op->ev[3], s));
+    op->sets_recorded++;
+  }
+}
+
+// 1-D operator tables -> this translation unit's __constant__ copy; a function of (dim, order) only
+inline void upload_tables(int dim, int order) {
+  const Tables1D tabs = make_tables(order, dim);
+  const size_t off = (static_cast<size_t>(dim - 2) * (TPSRHS_MAXORDER + 1) + order) * sizeof(Tables1D);
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &tabs, sizeof(Tables1D), off, hipMemcpyHostToDevice));
+}
+
+template <int DIM, class PH>
+void pick_order(tpsrhs_operator *op) {
+  upload_tables(DIM, op->order);
+  switch (op->order) {
+    case 1: op->launch = &launch_all<DIM, 1, PH>; break;
+    case 2: op->launch = &launch_all<DIM, 2, PH>; break;
+    case 3: op->launch = &launch_all<DIM, 3, PH>; break;
+    case 4: op->launch = &launch_all<DIM, 4, PH>; break;
+    default: throw Unsupported("polynomial order " + std::to_string(op->order) + " is not built (1..4)");
+  }
+}
+
+}  // namespace
+
+#endif

@@ -40,6 +40,13 @@ __device__ inline double fast_sqrt(double x) {
   return fma(fma(-g, g, x), h, g);
 }
 
+#ifndef TPSRHS_MINW_GRAD
+#define TPSRHS_MINW_GRAD 1
+#endif
+#ifndef TPSRHS_MINW_FLUX
+#define TPSRHS_MINW_FLUX 3  // <= 168 VGPRs: 3 waves per SIMD (the allocator otherwise lands on 170)
+#endif
+
 struct BcDev {
   int category, type;
   double data[4 + TPSRHS_MAXSPECIES];
@@ -61,6 +68,7 @@ struct DryAirPhys {
   static constexpr int NEQ = DIM_ + 2;
   static constexpr int NACTIVE = 0;
   static constexpr bool HAS_SOURCE = false;
+  static constexpr int MINW_GRAD = TPSRHS_MINW_GRAD, MINW_FLUX = TPSRHS_MINW_FLUX;  // launch-bound waves per SIMD
   typedef DryAirParams Params;
 
   // One reciprocal of the density per state; everything else multiplies by it (the reference

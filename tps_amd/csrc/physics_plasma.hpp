@@ -1,0 +1,835 @@
+// Device point-wise physics, multi-species plasma (WorkingFluid::USER_DEFINED, PerfectMixture).
+//
+// Flattened restatement of the reference's virtual hierarchy; compile-time policy = (NVEL, NSP,
+// ambipolar, two-temperature, transport model), so that every loop is unrolled and the species
+// arrays live in registers.  Number densities, temperatures and pressure of a state are computed
+// ONCE per point and shared by the Riemann solver, the fluxes, the transport and the sources (the
+// reference recomputes them in every call).
+//   PerfectMixture        src/equation_of_state.cpp:478-1942
+//   ConstantTransport     src/transport_properties.cpp:303-449
+//   GasMinimalTransport   src/gas_transport.cpp:43-830 (argon ternary), collision fits
+//                         src/collision_integrals.cpp:53-201
+//   Fluxes                src/fluxes.cpp:135-505 ; RiemannSolverTPS src/riemann_solver.cpp:53-115
+//   Chemistry / Reaction  src/chemistry.cpp:161-299, src/reaction.cpp:41-83, src/table.cpp:52-110
+//   SourceTerm            src/source_term.cpp:107-251 ; NetEmission src/radiation.hpp:68
+//   boundary ghosts       src/inletBC.cpp:729-757, src/outletBC.cpp:731-737, src/wallBC.cpp:277-510
+#ifndef TPSRHS_PHYSICS_PLASMA_HPP_
+#define TPSRHS_PHYSICS_PLASMA_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include "physics_dryair.hpp"
+
+namespace tpsrhs {
+
+constexpr double kRgas = 8.3144598;  // src/equation_of_state.hpp:55-67
+constexpr double kAvogadro = 6.0221409e+23;
+constexpr double kBoltz = kRgas / kAvogadro;
+constexpr double kEps0 = 8.8541878128e-12;
+constexpr double kQe = 1.60218e-19;
+constexpr double kMolarQe = kQe * kAvogadro;
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kXeps = 1.0e-30;
+
+struct TableDev {  // LinearTable with the interval coefficients precomputed on the host
+  int n, x_log, f_log, pad;
+  const double *x, *a, *b;
+};
+struct ChemDev {  // ChemistryInput, device image (lives in a device buffer; uniform reads)
+  int num_reactions, electron_index;
+  double min_temperature;
+  double energy[TPSRHS_MAXREACTIONS];
+  double rate[TPSRHS_MAXCHEMPARAMS * TPSRHS_MAXREACTIONS];
+  double keq[TPSRHS_MAXCHEMPARAMS * TPSRHS_MAXREACTIONS];
+  signed char reactant[TPSRHS_MAXSPECIES * TPSRHS_MAXREACTIONS];
+  signed char product[TPSRHS_MAXSPECIES * TPSRHS_MAXREACTIONS];
+  signed char model[TPSRHS_MAXREACTIONS];
+  signed char detailed_balance[TPSRHS_MAXREACTIONS];
+  TableDev table[TPSRHS_MAXREACTIONS];
+  int radiation;  // tpsrhs_radiation_model
+  TableDev nec;
+};
+
+constexpr int PLASMA_MAXBC = 8;
+template <int NSP>
+struct PlasmaParams {
+  double mw[NSP], charge[NSP], eform[NSP], cv[NSP], cp[NSP];
+  // constant transport
+  double c_visc, c_bulk, c_k, c_ke, c_diff[NSP], c_mtfreq[NSP];
+  int c_eidx;
+  // argon ternary
+  int third_order, multiply;
+  double mult_flux[4], mult_spcs, mult_diff, mult_mobil;
+  const ChemDev *chem;
+  int eq_system, use_bc_in_grad, num_bcs, axisymmetric;
+  BcDev bc[PLASMA_MAXBC];
+};
+
+__device__ inline double ipow(double x, int k) {  // pow(x, small non-negative integer), pow(0,0) = 1
+  double r = 1.0;
+  for (int i = 0; i < k; i++) r *= x;
+  return r;
+}
+__device__ inline double table_eval(const TableDev &t, double xe) {  // src/table.cpp:52-101
+  int count = t.n, first = 0;
+  while (count > 0) {
+    int it = first;
+    const int step = count / 2;
+    it += step;
+    if (xe > t.x[it]) {
+      first = ++it;
+      count -= step + 1;
+    } else {
+      count = step;
+    }
+  }
+  first = max(1, min(t.n - 1, first));
+  const int idx = first - 1;
+  const double xt = t.x_log ? log(xe) : xe;
+  double ft = t.a[idx] + t.b[idx] * xt;
+  if (t.f_log) ft = exp(ft);
+  return ft;
+}
+
+namespace coll {  // collision-integral fits, src/collision_integrals.cpp
+__device__ inline double cfit(double c0, double c1, double c2, double c3, double Tp) {
+  return c0 * pow(log(1.0 + c1 * pow(Tp, c2)), c3) / Tp / Tp;
+}
+__device__ inline double att11(double Tp) { return cfit(0.2150, 5.2194, 1.0472, 1.2435, Tp); }
+__device__ inline double att12(double Tp) { return cfit(0.0991, 7.4684, 1.0155, 1.1536, Tp); }
+__device__ inline double att13(double Tp) { return cfit(0.0616, 7.8271, 0.9452, 1.1105, Tp); }
+__device__ inline double att14(double Tp) { return cfit(0.0308, 13.9567, 0.9511, 1.1803, Tp); }
+__device__ inline double att15(double Tp) { return cfit(0.0232, 13.7888, 0.9148, 1.1532, Tp); }
+__device__ inline double rep22(double Tp) { return cfit(0.4128, 1.2436, 1.1830, 1.0123, Tp); }
+__device__ inline double rep23(double Tp) { return cfit(0.2203, 1.8832, 1.2059, 0.9851, Tp); }
+__device__ inline double rep24(double Tp) { return cfit(0.1323, 2.7248, 1.2129, 0.9847, Tp); }
+__device__ inline double ArAr22(double T) { return 1.7e-18 * pow(T, -0.25); }
+__device__ inline double ArAr1P11(double T) { return 4.574321e-18 * pow(T, -0.1805); }
+__device__ inline double eAr1r(int r, double logT) {
+  const double C[5][9] = {
+      {6.36254140e-18, 1.84835040e-18, -5.87727093e-18, 3.20023027e-18, -8.50509054e-19, 1.28163820e-19,
+       -1.11712910e-20, 5.25649382e-22, -1.03296658e-23},
+      {1.91338172e-17, 5.45418129e-18, -1.78361685e-17, 9.75657946e-18, -2.61115722e-18, 3.98310268e-19,
+       -3.53503678e-20, 1.70375066e-21, -3.45211955e-23},
+      {3.04685398e-17, 8.39750994e-18, -2.88132528e-17, 1.60147037e-17, -4.34837891e-18, 6.73136845e-19,
+       -6.06704580e-20, 2.97216168e-21, -6.12760944e-23},
+      {3.90777949e-17, 1.04696956e-17, -3.73774204e-17, 2.10610498e-17, -5.79029566e-18, 9.07573157e-19,
+       -8.28466766e-20, 4.11188110e-21, -8.59225098e-23},
+      {4.41333290e-17, 1.15696010e-17, -4.25651305e-17, 2.42442440e-17, -6.73359258e-18, 1.06641697e-18,
+       -9.83933863e-20, 4.93775812e-21, -1.04362372e-22}};
+  double fit = C[r - 1][0] / logT, pw = 1.0;
+#pragma unroll
+  for (int k = 1; k < 9; k++) {
+    fit += C[r - 1][k] * pw;
+    pw *= logT;
+  }
+  return fit;
+}
+}  // namespace coll
+
+enum { TRANSPORT_CONSTANT = 0, TRANSPORT_ARGON_MINIMAL = 1 };
+
+template <int DIM_, int NVEL_, int NSP_, bool AMBI, bool TWOT, int TRANSPORT>
+struct PlasmaPhys {
+  static constexpr int DIM = DIM_, NVEL = NVEL_, NSP = NSP_;
+  static constexpr int NACTIVE = AMBI ? NSP_ - 2 : NSP_ - 1;
+  static constexpr int NEQ = NVEL_ + 2 + NACTIVE + (TWOT ? 1 : 0);
+  static constexpr int IE = NSP_ - 2, IB = NSP_ - 1;  // electron, background
+  static constexpr int ITH = NVEL_ + 1, ITE = NEQ - 1;
+  static constexpr bool HAS_SOURCE = true;
+  static constexpr bool HAS_FLUX_DOT = false;
+  static constexpr int MINW_GRAD = 1, MINW_FLUX = 1;
+  typedef PlasmaParams<NSP_> Params;
+  struct Transport {};
+
+  // everything the closures need from one conserved state
+  struct State {
+    double ir, k, p, pe, Th, Te, c;  // 1/rho, |rho u|^2/rho, pressures, temperatures, sound speed
+    double vel[NVEL];
+    double n[NSP];
+  };
+
+  __device__ static inline void number_densities(const Params &p, const double *U, double *n) {  // :947-961
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) n[sp] = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) n[sp] = U[NVEL + 2 + sp] / p.mw[sp];
+    double rhoB = U[0];
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) rhoB -= p.mw[sp] * n[sp];
+    if (AMBI) {
+      double ne = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < NACTIVE; sp++) ne += p.charge[sp] * n[sp];
+      ne = fmax(ne, 0.0);
+      n[IE] = ne;
+      rhoB -= ne * p.mw[IE];
+    }
+    n[IB] = rhoB / p.mw[IB];
+  }
+  __device__ static inline double heavies_cv(const Params &p, const double *n) {  // :576-584
+    double c = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++)
+      if (sp != IE) c += n[sp] * p.cv[sp];
+    return c + n[IB] * p.cv[IB];
+  }
+  __device__ static inline double heavies_n(const double *n) {
+    double nh = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++)
+      if (sp != IE) nh += n[sp];
+    return nh + n[IB];
+  }
+  __device__ static inline State make_state(const Params &p, const double *U) {
+    State s;
+    number_densities(p, U, s.n);
+    s.ir = 1.0 / U[0];
+    double m2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) {
+      m2 += U[1 + d] * U[1 + d];
+      s.vel[d] = U[1 + d] * s.ir;
+    }
+    s.k = m2 * s.ir;
+    // computeTemperaturesBase, :1141-1172
+    const double chv = heavies_cv(p, s.n);
+    double ctot = chv;
+    if (!TWOT) ctot += s.n[IE] * p.cv[IE];
+    double e = U[ITH];
+#pragma unroll
+    for (int sp = 0; sp < NSP - 2; sp++) e -= s.n[sp] * p.eform[sp];
+    double Th = -0.5 * s.k + e;
+    if (TWOT) Th -= U[ITE];
+    s.Th = Th / ctot;
+    s.Te = TWOT ? U[ITE] / s.n[IE] / p.cv[IE] : s.Th;
+    // computePressureBase, :1044-1062
+    const double nh = heavies_n(s.n);
+    s.pe = s.n[IE] * kRgas * s.Te;
+    s.p = kRgas * (nh * s.Th + s.n[IE] * s.Te);
+    // speed of sound: heavies' heat ratio, :1311-1340
+    const double gamma = 1.0 + nh * kRgas / chv;
+    s.c = sqrt(gamma * s.p * s.ir);
+    return s;
+  }
+  __device__ static inline double pressure(const Params &p, const double *U) { return make_state(p, U).p; }
+
+  // GetPrimitivesFromConservatives, :679-700
+  __device__ static inline void prim(const Params &p, const double *U, double *Up) {
+    const State s = make_state(p, U);
+    Up[0] = U[0];
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) Up[1 + d] = U[1 + d] / U[0];
+    Up[ITH] = s.Th;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) Up[NVEL + 2 + sp] = s.n[sp];
+    if (TWOT) Up[ITE] = s.Te;
+  }
+  // species densities are clamped to >= 0 wherever a state is interpolated (src/face_integrator.cpp:297-302)
+  __device__ static inline void clamp_species(double *U) {
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) U[NVEL + 2 + sp] = fmax(U[NVEL + 2 + sp], 0.0);
+  }
+  __device__ static inline double max_char_speed(const Params &, const double *, const State &s) {  // :1359-1373
+    return sqrt(s.k * s.ir) + s.c;
+  }
+  __device__ static inline double max_char_speed(const Params &p, const double *U) {
+    return max_char_speed(p, U, make_state(p, U));
+  }
+
+  // F(U).n, src/fluxes.cpp:135-170
+  __device__ static inline void conv_flux_n(const Params &p, const double *U, const State &s, const double *n,
+                                            double *Fn) {
+    double un = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) un += s.vel[d] * n[d];
+    Fn[0] = U[0] * un;
+#pragma unroll
+    for (int i = 0; i < NVEL; i++) Fn[1 + i] = U[1 + i] * un + (i < DIM ? s.p * n[i] : 0.0);
+    Fn[ITH] = un * (U[ITH] + s.p);
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) Fn[NVEL + 2 + sp] = U[NVEL + 2 + sp] * un;
+    if (TWOT) Fn[ITE] = (U[ITE] + s.pe) * un;
+  }
+  __device__ static inline void lax_friedrichs(const Params &p, const double *U1, const double *U2, const double *n,
+                                               double *F) {
+    const State s1 = make_state(p, U1), s2 = make_state(p, U2);
+    const double lam = fmax(max_char_speed(p, U1, s1), max_char_speed(p, U2, s2));
+    double f1[NEQ], f2[NEQ];
+    conv_flux_n(p, U1, s1, n, f1);
+    conv_flux_n(p, U2, s2, n, f2);
+    double nm = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
+    const double hl = 0.5 * lam * sqrt(nm);
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) F[eq] = 0.5 * (f1[eq] + f2[eq]) - hl * (U2[eq] - U1[eq]);
+  }
+
+  // ---- species primitives and mole-fraction gradient --------------------------------------
+  struct Species {
+    double X[NSP], Y[NSP], n[NSP], ntot;
+  };
+  // computeSpeciesPrimitives (:882-927): its own number densities (electrons not clamped, background
+  // from the mass-fraction remainder), kept apart from computeNumberDensities as in the reference
+  __device__ static inline Species species(const Params &p, const double *U) {
+    Species q;
+    const double ir = 1.0 / U[0];
+    double n = 0.0, ne = 0.0, Yb = 1.0;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) q.n[sp] = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) {
+      q.n[sp] = U[NVEL + 2 + sp] / p.mw[sp];
+      n += q.n[sp];
+      if (AMBI) ne += p.charge[sp] * q.n[sp];
+      q.Y[sp] = U[NVEL + 2 + sp] * ir;
+      Yb -= q.Y[sp];
+    }
+    if (AMBI) {
+      q.n[IE] = ne;
+      n += ne;
+      q.Y[IE] = ne * p.mw[IE] * ir;
+      Yb -= q.Y[IE];
+    }
+    q.Y[IB] = Yb;
+    q.n[IB] = Yb * U[0] / p.mw[IB];
+    n += q.n[IB];
+    q.ntot = n;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) q.X[sp] = q.n[sp] / n;
+    return q;
+  }
+  __device__ static inline void mole_fraction_grad(const Params &p, const double *n, double ntot, const double *g,
+                                                   double *gX) {  // :1534-1592
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      double ne = 0.0, nb = g[0 + d * NEQ], nt = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < NACTIVE; sp++) {
+        const double gs = g[(NVEL + 2 + sp) + d * NEQ];
+        if (AMBI) ne += gs * p.charge[sp];
+        nb -= gs * p.mw[sp];
+        nt += gs;
+      }
+      if (AMBI) nb -= p.mw[IE] * ne;
+      nb /= p.mw[IB];
+      if (AMBI) nt += ne;
+      nt += nb;
+      const double in = 1.0 / ntot;
+#pragma unroll
+      for (int sp = 0; sp < NACTIVE; sp++)
+        gX[sp + d * NSP] = g[(NVEL + 2 + sp) + d * NEQ] * in - n[sp] * in * in * nt;
+      if (AMBI) gX[IE + d * NSP] = ne * in - n[IE] * in * in * nt;
+      gX[IB + d * NSP] = nb * in - n[IB] * in * in * nt;
+    }
+  }
+
+  // ---- transport ----------------------------------------------------------------------------
+  struct Trans {
+    double visc, bulk, k, ke;
+    double V[NSP * DIM];  // diffusion velocities [sp + d*NSP]
+    double mtfreq[NSP];   // electron momentum-transfer frequencies (source variant)
+    double n[NSP];        // number densities of computeSpeciesPrimitives
+  };
+  // species positions of the argon ternary mixture are fixed by the mixture ordering (electron
+  // second to last, neutral background last); tpsrhs_create checks the tpsrhs_gas_transport indices
+  static constexpr int I_E = IE, I_N = IB, I_ION = 0;
+  struct Debye {
+    double circle, ndTe, ndTh;
+  };
+  __device__ static inline Debye debye(const double *n, double Th, double Te) {
+    const double dfac = kBoltz * kEps0 / kQe / kQe;
+    const double nOverT = (n[I_E] + kXeps) / Te + (n[I_ION] + kXeps) / Th;
+    const double length = sqrt(dfac / kAvogadro / nOverT);
+    Debye d;
+    d.circle = kPi * length * length;
+    d.ndTe = length * 4.0 * kPi * dfac * Te;
+    d.ndTh = length * 4.0 * kPi * dfac * Th;
+    return d;
+  }
+  __device__ static inline double third_order_ke(const double *X, const Debye &d, double Te, double me, double vf,
+                                                 double kf) {  // :400-489
+    const double Q2[3] = {d.circle * coll::rep22(d.ndTe), d.circle * coll::rep23(d.ndTe), d.circle * coll::rep24(d.ndTe)};
+    const double QI[5] = {d.circle * coll::att11(d.ndTe), d.circle * coll::att12(d.ndTe), d.circle * coll::att13(d.ndTe),
+                          d.circle * coll::att14(d.ndTe), d.circle * coll::att15(d.ndTe)};
+    const double lT = log(Te);
+    double QN[5];
+#pragma unroll
+    for (int r = 1; r <= 5; r++) QN[r - 1] = coll::eAr1r(r, lT);
+    auto L11ea = [](const double *Q) { return 6.25 * Q[0] - 15. * Q[1] + 12. * Q[2]; };
+    auto L12ea = [](const double *Q) { return 10.9375 * Q[0] - 39.375 * Q[1] + 57. * Q[2] - 30. * Q[3]; };
+    auto L22ea = [](const double *Q) {
+      return 19.140625 * Q[0] - 91.875 * Q[1] + 199.5 * Q[2] - 210. * Q[3] + 90. * Q[4];
+    };
+    const double s2 = sqrt(2.0);
+    double L11 = s2 * X[I_E] * Q2[0];
+    L11 += X[I_ION] * L11ea(QI);
+    L11 += X[I_N] * L11ea(QN);
+    double L12 = s2 * X[I_E] * (1.75 * Q2[0] - 2.0 * Q2[1]);
+    L12 += X[I_ION] * L12ea(QI);
+    L12 += X[I_N] * L12ea(QN);
+    double L22 = s2 * X[I_E] * (4.8125 * Q2[0] - 7.0 * Q2[1] + 5. * Q2[2]);
+    L22 += X[I_ION] * L22ea(QI);
+    L22 += X[I_N] * L22ea(QN);
+    return vf * kf * sqrt(2.0 * Te / me) * X[I_E] / (L11 - L12 * L12 / L22);
+  }
+
+  // flux (source=false) or source (source=true) transport: ComputeFluxTransportProperties /
+  // ComputeSourceTransportProperties of the selected model; E-field = 0 (src/fluxes.cpp:200-201)
+  __device__ static inline void transport(const Params &p, const double *U, double Th, double Te, const double *g,
+                                          bool source, Trans &t) {
+    const Species q = species(p, U);
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) t.n[sp] = q.n[sp];
+    double diff[NSP], mob[NSP];
+    if (TRANSPORT == TRANSPORT_CONSTANT) {
+      t.visc = p.c_visc;
+      t.bulk = p.c_bulk;
+      t.k = p.c_k;
+      t.ke = p.c_ke;
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) {
+        diff[sp] = p.c_diff[sp];
+        const double temp = (sp == p.c_eidx) ? Te : Th;
+        mob[sp] = (kQe / kBoltz) * p.charge[sp] / temp * diff[sp];
+        t.mtfreq[sp] = p.c_mtfreq[sp];
+      }
+    } else {
+      const double vf = 5. / 16. * sqrt(kPi * kBoltz), kf = 15. / 4. * kBoltz;
+      const double dfc = 3. / 16. * sqrt(2.0 * kPi * kBoltz) / kAvogadro;
+      const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
+      double mwp[NSP];  // per-particle masses
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) mwp[sp] = p.mw[sp] / kAvogadro;
+      const Debye d = debye(q.n, Th, Te);
+      const double QeAr = coll::eAr1r(1, log(Te)), Qatt = coll::att11(d.ndTe) * d.circle;
+      t.visc = t.bulk = t.k = t.ke = 0.0;
+      if (!source) {
+        double sv[NSP];
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) sv[sp] = 0.0;
+        sv[I_ION] = vf * sqrt(mwp[I_ION] * Th) / (coll::rep22(d.ndTh) * d.circle);
+        sv[I_N] = vf * sqrt(mwp[I_N] * Th) / coll::ArAr22(Th);
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) {
+          t.visc += q.X[sp] * sv[sp];
+          t.k += q.X[sp] * (sv[sp] * kf / mwp[sp]);
+        }
+        if (p.third_order)
+          t.ke = third_order_ke(q.X, d, Te, mwp[I_E], vf, kf);
+        else
+          t.ke = vf * kf * sqrt(Te / mwp[I_E]) * q.X[I_E] / (coll::rep22(d.ndTe) * d.circle);
+      }
+      auto muw = [&](int i, int j) { return mwp[i] * mwp[j] / (mwp[i] + mwp[j]); };
+      double bd[NSP * NSP];
+#pragma unroll
+      for (int i = 0; i < NSP * NSP; i++) bd[i] = 0.0;
+      bd[I_E + I_N * NSP] = bd[I_N + I_E * NSP] = dfc * sqrt(Te / muw(I_E, I_N)) / q.ntot / QeAr;
+      bd[I_N + I_ION * NSP] = bd[I_ION + I_N * NSP] = dfc * sqrt(Th / muw(I_N, I_ION)) / q.ntot / coll::ArAr1P11(Th);
+      bd[I_E + I_ION * NSP] = bd[I_ION + I_E * NSP] = dfc * sqrt(Te / muw(I_ION, I_E)) / q.ntot / Qatt;
+      // CurtissHirschfelder, src/transport_properties.cpp:188-201
+#pragma unroll
+      for (int i = 0; i < NSP; i++) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < NSP; j++)
+          if (i != j) a += (q.X[j] + kXeps) / bd[i + j * NSP];
+        diff[i] = (1.0 - q.Y[i]) / a;
+        const double temp = (i == I_E) ? Te : Th;
+        mob[i] = (kQe / kBoltz) * p.charge[i] / temp * diff[i];
+        t.mtfreq[i] = 0.0;
+      }
+      t.mtfreq[I_ION] = mff * sqrt(Te / mwp[I_E]) * q.n[I_ION] * Qatt;
+      t.mtfreq[I_N] = mff * sqrt(Te / mwp[I_E]) * q.n[I_N] * QeAr;
+      if (p.multiply) {
+        t.visc *= p.mult_flux[0];
+        t.bulk *= p.mult_flux[1];
+        t.k *= p.mult_flux[2];
+        t.ke *= p.mult_flux[3];
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) {
+          diff[sp] *= p.mult_diff;
+          mob[sp] *= p.mult_mobil;
+          t.mtfreq[sp] *= p.mult_spcs;
+        }
+      }
+    }
+    // diffusion velocities: -D grad X / X, ambipolar field, mass-flux correction
+    // (src/transport_properties.cpp:59-136)
+    double mho = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) mho += mob[sp] * q.n[sp] * p.charge[sp];
+    double gX[NSP * DIM];
+    mole_fraction_grad(p, q.n, q.ntot, g, gX);
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] = -diff[sp] * gX[sp + d * NSP] / (q.X[sp] + kXeps);
+      if (AMBI) {
+        double ambE = 0.0;
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) ambE -= t.V[sp + d * NSP] * q.n[sp] * p.charge[sp];
+        ambE /= (mho + kXeps);
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] += mob[sp] * ambE;
+      }
+      double Vc = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) Vc += q.Y[sp] * t.V[sp + d * NSP];
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] -= Vc;
+    }
+  }
+  __device__ static inline void enthalpies(const Params &p, const State &s, double *h) {  // :1192-1207
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) h[sp] = s.n[sp] * (p.cp[sp] * ((sp == IE) ? s.Te : s.Th) + p.eform[sp]);
+  }
+
+  // ComputeViscousFluxes, src/fluxes.cpp:178-335 (3-D / planar 2-D part); Fv[eq + d*NEQ]
+  __device__ static inline void visc_flux(const Params &p, const double *U, const State &s, const double *g,
+                                          double *Fv) {
+#pragma unroll
+    for (int i = 0; i < NEQ * DIM; i++) Fv[i] = 0.0;
+    if (p.eq_system == TPSRHS_EULER) return;
+    Trans t;
+    transport(p, U, s.Th, s.Te, g, false, t);
+    double h[NSP];
+    enthalpies(p, s, h);
+    const double bulk = t.bulk - 2. / 3. * t.visc;
+    double k = t.k;
+    if (TWOT) {
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        const double qe = t.ke * g[ITE + d * NEQ];
+        Fv[ITH + d * NEQ] += qe;
+        Fv[ITE + d * NEQ] += qe - h[IE] * t.V[IE + d * NSP];
+      }
+    } else {
+      k += t.ke;
+    }
+    double divV = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
+#pragma unroll
+    for (int i = 0; i < DIM; i++) {
+      double vt = 0.0;
+#pragma unroll
+      for (int j = 0; j < DIM; j++) {
+        double st = t.visc * (g[(1 + j) + i * NEQ] + g[(1 + i) + j * NEQ]);
+        if (i == j) st += bulk * divV;
+        Fv[(1 + j) + i * NEQ] = st;
+        vt += st * s.vel[j];
+      }
+      double e = vt + k * g[ITH + i * NEQ];
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) e -= h[sp] * t.V[sp + i * NSP];
+      Fv[ITH + i * NEQ] += e;
+#pragma unroll
+      for (int sp = 0; sp < NACTIVE; sp++) Fv[(NVEL + 2 + sp) + i * NEQ] = -U[NVEL + 2 + sp] * t.V[sp + i * NSP];
+    }
+  }
+  __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const double *g,
+                                           double *F) {
+    double Fv[NEQ * DIM];
+    visc_flux(p, U, s, g, Fv);
+    const double H = U[ITH] + s.p;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      F[0 + d * NEQ] = U[1 + d] - Fv[0 + d * NEQ];
+#pragma unroll
+      for (int i = 0; i < NVEL; i++) F[1 + i + d * NEQ] = U[1 + i] * s.vel[d] + (i == d ? s.p : 0.0) - Fv[1 + i + d * NEQ];
+      F[ITH + d * NEQ] = s.vel[d] * H - Fv[ITH + d * NEQ];
+#pragma unroll
+      for (int sp = 0; sp < NACTIVE; sp++)
+        F[(NVEL + 2 + sp) + d * NEQ] = U[NVEL + 2 + sp] * s.vel[d] - Fv[(NVEL + 2 + sp) + d * NEQ];
+      if (TWOT) F[ITE + d * NEQ] = (U[ITE] + s.pe) * s.vel[d] - Fv[ITE + d * NEQ];
+    }
+  }
+  __device__ static inline void visc_flux_n(const Params &p, const double *U, const double *g, const double *n,
+                                            double *Fn) {
+    double Fv[NEQ * DIM];
+    visc_flux(p, U, make_state(p, U), g, Fv);
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) {
+      double a = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) a += Fv[eq + d * NEQ] * n[d];
+      Fn[eq] = a;
+    }
+  }
+  // ComputeBdrViscousFluxes (src/fluxes.cpp:344-505) with the prescriptions of the in-scope walls:
+  // species normal diffusion fluxes = 0; heat fluxes = 0 when `adiabatic`
+  __device__ static inline void bdr_visc_flux(const Params &p, const double *Uw, const double *g, const double *nu,
+                                              bool adiabatic, double *Fn) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) Fn[eq] = 0.0;
+    if (p.eq_system == TPSRHS_EULER) return;
+    const State s = make_state(p, Uw);
+    Trans t;
+    transport(p, Uw, s.Th, s.Te, g, false, t);
+    const double bulk = t.bulk - 2. / 3. * t.visc;
+    double k = t.k;
+    double divV = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
+    double e = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) {
+      double sn = 0.0;
+#pragma unroll
+      for (int j = 0; j < DIM; j++) {
+        double st = t.visc * (g[(1 + j) + i * NEQ] + g[(1 + i) + j * NEQ]);
+        if (i == j) st += bulk * divV;
+        sn += st * nu[j];
+      }
+      Fn[1 + i] = sn;
+      e += sn * s.vel[i];
+    }
+    double qe = 0.0, qh = 0.0;  // heat fluxes (standard sign); species fluxes are prescribed zero
+    if (!adiabatic) {
+      if (TWOT) {
+#pragma unroll
+        for (int d = 0; d < DIM; d++) qe -= t.ke * g[ITE + d * NEQ] * nu[d];
+      } else {
+        k += t.ke;
+      }
+#pragma unroll
+      for (int d = 0; d < DIM; d++) qh -= k * g[ITH + d * NEQ] * nu[d];
+    }
+    Fn[ITH] = e - qh;
+    if (TWOT) {
+      Fn[ITH] -= qe;
+      Fn[ITE] = -qe;
+    }
+  }
+
+  // ---- boundary conditions ------------------------------------------------------------------
+  __device__ static inline void stagnant_with_temp(const Params &p, const double *U, double T, double *Uw) {  // :1596-1620
+    double n[NSP];
+    number_densities(p, U, n);
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) Uw[eq] = U[eq];
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) Uw[1 + d] = 0.0;
+    const double Ue = n[IE] * p.cv[IE] * T;
+    double e = heavies_cv(p, n) * T + Ue;
+    if (TWOT) Uw[ITE] = Ue;
+#pragma unroll
+    for (int sp = 0; sp < NSP - 2; sp++) e += n[sp] * p.eform[sp];
+    Uw[ITH] = e;
+  }
+  __device__ static inline void energy_for_pressure(const Params &p, const double *Uin, double pres, bool modE,
+                                                    double *Uo) {  // :1698-1742
+    double n[NSP];
+    number_densities(p, Uin, n);
+    double pe = 0.0, nsum = 0.0;
+    if (TWOT && !modE) pe = n[IE] * kRgas * (Uin[ITE] / (n[IE] + kXeps) / p.cv[IE]);
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++)
+      if (!(TWOT && !modE && sp == IE)) nsum += n[sp];
+    const double Th = (pres - pe) / (nsum * kRgas);
+    double rE = heavies_cv(p, n) * Th;
+    double ee;
+    if (TWOT)
+      ee = modE ? n[IE] * p.cv[IE] * Th : Uin[ITE];
+    else
+      ee = n[IE] * p.cv[IE] * Th;
+    rE += ee;
+    double ke = 0.0;
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) ke += 0.5 * Uin[1 + d] * Uin[1 + d] / Uin[0];
+    rE += ke;
+#pragma unroll
+    for (int sp = 0; sp < NSP - 2; sp++) rE += n[sp] * p.eform[sp];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) Uo[eq] = Uin[eq];
+    if (TWOT) Uo[ITE] = ee;
+    Uo[ITH] = rE;
+  }
+  __device__ static inline void bc_ghost(const Params &p, const BcDev &bc, const double *U, const double *n,
+                                         double *Ug) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) Ug[eq] = U[eq];
+    if (bc.category == TPSRHS_INLET) {  // src/inletBC.cpp:729-757
+      const double pres = pressure(p, U);
+      double s2[NEQ];
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) s2[eq] = U[eq];
+      s2[0] = bc.data[0];
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) s2[1 + d] = bc.data[0] * bc.data[1 + d];
+#pragma unroll
+      for (int sp = 0; sp < NACTIVE; sp++) s2[NVEL + 2 + sp] = bc.data[4 + sp];
+      energy_for_pressure(p, s2, pres, true, Ug);
+    } else if (bc.category == TPSRHS_OUTLET) {  // src/outletBC.cpp:731-737
+      energy_for_pressure(p, U, bc.data[0], false, Ug);
+    } else if (bc.type == TPSRHS_INV) {  // src/wallBC.cpp:277-301
+      double nm = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
+      nm = sqrt(nm);
+      double vn = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) vn += (U[1 + d] / U[0]) * (n[d] / nm);
+#pragma unroll
+      for (int d = 0; d < DIM; d++) Ug[1 + d] = U[0] * (U[1 + d] / U[0] - 2.0 * vn * (n[d] / nm));
+    } else if (bc.type == TPSRHS_VISC_ADIAB) {  // GasMixture::computeStagnationState, :100-115
+      double ke = 0.0;
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) {
+        ke += 0.5 * U[1 + d] * U[1 + d] / U[0];
+        Ug[1 + d] = 0.0;
+      }
+      Ug[ITH] = U[ITH] - ke;
+    } else {  // VISC_ISOTH, src/wallBC.cpp:471-485
+      if (p.use_bc_in_grad) {
+#pragma unroll
+        for (int d = 0; d < NVEL; d++) Ug[1 + d] = -U[1 + d];
+      } else {
+        stagnant_with_temp(p, U, bc.data[0], Ug);
+      }
+    }
+  }
+  __device__ static inline void bc_visc_term(const Params &p, const BcDev &bc, const double *U, const double *g,
+                                             const double *n, double *out) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) out[eq] = 0.0;
+    if (bc.category != TPSRHS_WALL || p.eq_system == TPSRHS_EULER) return;
+    double nm = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
+    nm = sqrt(nm);
+    double fin[NEQ], fw[NEQ];
+    visc_flux_n(p, U, g, n, fin);
+    if (bc.type == TPSRHS_INV) {
+      double Ug[NEQ];
+      bc_ghost(p, bc, U, n, Ug);
+      visc_flux_n(p, Ug, g, n, fw);
+    } else {
+      double Uw[NEQ], nu[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) nu[d] = n[d] / nm;
+      if (bc.type == TPSRHS_VISC_ADIAB) {
+        double ke = 0.0;
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) Uw[eq] = U[eq];
+#pragma unroll
+        for (int d = 0; d < NVEL; d++) {
+          ke += 0.5 * U[1 + d] * U[1 + d] / U[0];
+          Uw[1 + d] = 0.0;
+        }
+        Uw[ITH] = U[ITH] - ke;
+        bdr_visc_flux(p, Uw, g, nu, true, fw);
+      } else {
+        stagnant_with_temp(p, U, bc.data[0], Uw);
+        bdr_visc_flux(p, Uw, g, nu, false, fw);
+      }
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) fw[eq] *= nm;
+    }
+#pragma unroll
+    for (int eq = 1; eq < NEQ; eq++) out[eq] = -0.5 * fw[eq] - 0.5 * fin[eq];
+  }
+  __device__ static inline void bc_grad_prim(const Params &p, const BcDev &bc, const double *Up, double *UpB) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) UpB[eq] = Up[eq];
+    if (p.use_bc_in_grad && bc.category == TPSRHS_WALL && bc.type == TPSRHS_VISC_ISOTH) {
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) UpB[1 + d] = 0.0;
+      UpB[ITH] = bc.data[0];
+    }
+  }
+
+  // ---- SourceTerm::updateTerms at one node, src/source_term.cpp:107-251 ------------------------
+  __device__ static inline void source(const Params &p, const double *Uin, const double *Upin, const double *g,
+                                       double *src) {
+    double U[NEQ], Up[NEQ];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) {
+      U[eq] = Uin[eq];
+      Up[eq] = Upin[eq];
+      src[eq] = 0.0;
+    }
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) {
+      const int eq = 3 + 2 + sp;  // hard-coded nvel = 3 in the reference (src/source_term.cpp:129)
+      if (eq < NEQ) {
+        U[eq] = fmax(U[eq], 0.0);
+        Up[eq] = fmax(Up[eq], 0.0);
+      }
+    }
+    // temperatures come from the nodal primitives, number densities from the (clamped) state
+    const double Th = Up[ITH], Te = TWOT ? Up[ITE] : Up[ITH];
+    Trans t;
+    transport(p, U, Th, Te, g, true, t);
+    const ChemDev &c = *p.chem;
+    double progress[TPSRHS_MAXREACTIONS];
+    if (c.num_reactions > 0) {
+      const double Thl = fmax(Th, c.min_temperature), Tel = fmax(Te, c.min_temperature);
+      double creation[NSP];
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) creation[sp] = 0.0;
+      for (int r = 0; r < c.num_reactions; r++) {
+        const bool el = (c.electron_index < 0) ? false : (c.reactant[c.electron_index + r * NSP] != 0);
+        const double temp = el ? Tel : Thl;
+        const double A = c.rate[0 + r * 3], b = c.rate[1 + r * 3], E = c.rate[2 + r * 3];
+        double kf;
+        if (c.model[r] == TPSRHS_ARRHENIUS) {
+          kf = A * pow(temp, b) * exp(-E / kRgas / temp);
+        } else if (c.model[r] == TPSRHS_HOFFERTLIEN) {
+          const double tf = E / kBoltz / temp;
+          kf = A * pow(temp, b) * (tf + 2.0) * exp(-tf);
+        } else {
+          kf = table_eval(c.table[r], temp);
+        }
+        double rate = 1.0;
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) rate *= ipow(t.n[sp], c.reactant[sp + r * NSP]);
+        if (c.detailed_balance[r]) {
+          const double kc = c.keq[0 + r * 3] * pow(temp, c.keq[1 + r * 3]) * exp(-c.keq[2 + r * 3] / temp);
+          double bwd = 1.0;
+#pragma unroll
+          for (int sp = 0; sp < NSP; sp++) bwd *= ipow(t.n[sp], c.product[sp + r * NSP]);
+          rate -= bwd / kc;
+        }
+        progress[r] = kf * rate;
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) creation[sp] += progress[r] * (c.product[sp + r * NSP] - c.reactant[sp + r * NSP]);
+      }
+#pragma unroll
+      for (int sp = 0; sp < NACTIVE; sp++) src[NVEL + 2 + sp] += creation[sp] * p.mw[sp];
+    }
+    if (c.radiation == TPSRHS_NET_EMISSION) src[ITH] += -4.0 * kPi * table_eval(c.nec, Th);
+    if (TWOT) {
+      for (int r = 0; r < c.num_reactions; r++) {
+        const bool el = (c.electron_index < 0) ? false : (c.reactant[c.electron_index + r * NSP] != 0);
+        if (el) src[ITE] -= c.energy[r] * progress[r];
+      }
+      // u . grad p_e, src/equation_of_state.cpp:1847-1870
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        double neg = 0.0;
+        if (AMBI) {
+#pragma unroll
+          for (int sp = 0; sp < NACTIVE; sp++) neg += g[(NVEL + 2 + sp) + d * NEQ] * p.charge[sp];
+        } else {
+          neg = g[(NVEL + NSP) + d * NEQ];
+        }
+        src[ITE] += (neg * Te + t.n[IE] * g[ITE + d * NEQ]) * kRgas * Up[1 + d];
+      }
+      const double me = p.mw[IE], ne = t.n[IE];
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) {
+        if (sp == IE) continue;
+        const double ms = p.mw[sp];
+        double e = 1.5 * kRgas * (Te - Th);
+        e *= 2.0 * me * ms / (ms + me) / (ms + me) * ne * t.mtfreq[sp];
+        src[ITE] -= e;
+      }
+    }
+  }
+};
+
+}  // namespace tpsrhs
+#endif

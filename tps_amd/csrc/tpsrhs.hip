@@ -3,177 +3,131 @@
 // Host side: builds the face topology and the 1-D operator tables, keeps every field resident in
 // HBM, and enqueues the three sweeps of kernels.hpp on one HIP stream per operator.  There is no
 // CPU fallback: without a HIP device tpsrhs_create returns TPSRHS_ERR_NO_DEVICE.
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstring>
-#include <memory>
-#include <stdexcept>
-#include <string>
-#include <vector>
-
-#include "../../include/tpsrhs.h"
-#include "basis.hpp"
-#include "kernels.hpp"
+#include "operator.hpp"
 #include "physics_dryair.hpp"
-#include "topology.hpp"
+#include "physics_plasma.hpp"
 
-using namespace tpsrhs;
+#include <cmath>
+#include <new>
+
+// kernel families instantiated in their own translation units
+void pick_plasma3d(tpsrhs_operator *op, bool two_temperature, int transport);
+void pick_plasma2d(tpsrhs_operator *op, bool two_temperature, int transport);
 
 static thread_local std::string g_last_error;
 
 namespace {
 
-struct DeviceError : std::runtime_error {
-  explicit DeviceError(const std::string &s) : std::runtime_error(s) {}
-};
-struct Unsupported : std::runtime_error {
-  explicit Unsupported(const std::string &s) : std::runtime_error(s) {}
-};
-
-#define HIP_CHECK(expr)                                                                                   \
-  do {                                                                                                    \
-    hipError_t _e = (expr);                                                                               \
-    if (_e != hipSuccess)                                                                                 \
-      throw DeviceError(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
-  } while (0)
-
-template <class T>
-T *dev_alloc(size_t n) {
-  T *p = nullptr;
-  HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)));
-  return p;
-}
-template <class T>
-T *dev_upload(const std::vector<T> &v) {
-  T *p = dev_alloc<T>(v.size());
-  if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-  return p;
-}
-
-constexpr int NKERN = 3;
-const char *kKernelNames[NKERN] = {"k_traces", "k_gradient", "k_flux"};
-
-}  // namespace
-
-struct tpsrhs_operator {
-  int dim = 0, order = 0, neq = 0, nvel = 0;
-  int ne = 0, nfaces = 0, nf = 0, nq = 0;
-  int64_t ndofs = 0;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  Topology topo;
-  tpsrhs_physics phys;
-  DryAirParams dry;
-  // device data
-  double *d_verts = nullptr;
-  int2 *d_face_info = nullptr;
-  double *d_Up = nullptr, *d_gradUp = nullptr, *d_TA = nullptr, *d_TB = nullptr;
-  double *d_speed = nullptr, *d_block_speed = nullptr;
-  int flux_grid = 0;
-  double *d_xh = nullptr, *d_yh = nullptr;  // staging for tpsrhs_mult_host
-  // halo
-  tpsrhs_halo_fn halo = nullptr;
-  void *halo_ctx = nullptr;
-  int32_t *d_shared_slot = nullptr;
-  uint8_t *d_shared_orient = nullptr;
-  double *d_send = nullptr;
-  std::vector<int64_t> send_off[2], recv_off[2];
-  // timing
-  // per-kernel timing: a ring of event sets so that a timed loop never synchronises
-  static constexpr int MAXSETS = 128;
-  bool timing = false;
-  hipEvent_t evs[MAXSETS][NKERN + 1] = {};
-  int64_t sets_recorded = 0;
-  hipEvent_t *ev = evs[0];
-
-  void (*launch)(tpsrhs_operator *, const double *, double *, bool) = nullptr;
-
-  MeshDev mesh_dev() const {
-    MeshDev m;
-    m.ne = ne;
-    m.ndofs = ndofs;
-    m.verts = d_verts;
-    m.face_info = d_face_info;
-    return m;
+// LinearTable::LinearTable (src/table.cpp:39-50): interval coefficients, uploaded with the abscissae
+TableDev upload_table(tpsrhs_operator *op, const tpsrhs_table &t) {
+  if (t.n_data < 2 || !t.x_data || !t.f_data) throw std::invalid_argument("table needs >= 2 points");
+  const int N = t.n_data;
+  std::vector<double> buf(3 * static_cast<size_t>(N), 0.0);
+  double *x = buf.data(), *a = x + N, *b = a + N;
+  for (int k = 0; k < N; k++) x[k] = t.x_data[k];
+  for (int k = 0; k < N - 1; k++) {
+    const double f0 = t.f_data[k], f1 = t.f_data[k + 1];
+    a[k] = t.f_log_scale ? std::log(f0) : f0;
+    const double df = t.f_log_scale ? (std::log(f1) - std::log(f0)) : (f1 - f0);
+    b[k] = t.x_log_scale ? df / (std::log(x[k + 1]) - std::log(x[k])) : df / (x[k + 1] - x[k]);
+    a[k] -= t.x_log_scale ? b[k] * std::log(x[k]) : b[k] * x[k];
   }
-  ~tpsrhs_operator() {
-    (void)hipSetDevice(device);
-    for (void *p : {static_cast<void *>(d_verts), static_cast<void *>(d_face_info),
-                    static_cast<void *>(d_Up), static_cast<void *>(d_gradUp),
-                    static_cast<void *>(d_TA), static_cast<void *>(d_TB), static_cast<void *>(d_speed), static_cast<void *>(d_block_speed),
-                    static_cast<void *>(d_xh), static_cast<void *>(d_yh), static_cast<void *>(d_shared_slot),
-                    static_cast<void *>(d_shared_orient), static_cast<void *>(d_send)})
-      if (p) (void)hipFree(p);
-    for (auto &set : evs)
-      for (auto &e : set)
-        if (e) (void)hipEventDestroy(e);
-  }
-};
-
-namespace {
-
-void exchange(tpsrhs_operator *op, int phase, double *T, int nfld, int per) {
-  const Topology &tp = op->topo;
-  if (tp.num_shared == 0) return;
-  const int n1 = (phase == 0) ? op->order + 1 : ((op->dim - 1) + 2 * op->order) / 2 + 1;
-  const int64_t total = static_cast<int64_t>(tp.num_shared) * nfld * per;
-  const int grid = static_cast<int>(std::min<int64_t>((total + 255) / 256, 2048));
-  if (op->dim == 3)
-    hipLaunchKernelGGL(k_pack<3>, dim3(grid), dim3(256), 0, op->stream, tp.num_shared, nfld, n1, op->d_shared_slot,
-                       op->d_shared_orient, T, op->d_send);
-  else
-    hipLaunchKernelGGL(k_pack<2>, dim3(grid), dim3(256), 0, op->stream, tp.num_shared, nfld, n1, op->d_shared_slot,
-                       op->d_shared_orient, T, op->d_send);
-  HIP_CHECK(hipGetLastError());
-  double *recv = T + static_cast<int64_t>(op->ne) * op->nfaces * nfld * per;
-  const int st = op->halo(op->halo_ctx, phase, op->d_send, recv, static_cast<int>(tp.nbr_ranks.size()),
-                          tp.nbr_ranks.data(), op->send_off[phase].data(), op->recv_off[phase].data(), op->stream);
-  if (st != 0) throw std::runtime_error("halo callback failed in phase " + std::to_string(phase));
+  double *d = dev_upload(buf);
+  op->d_extra.push_back(d);
+  TableDev td;
+  td.n = N;
+  td.x_log = t.x_log_scale;
+  td.f_log = t.f_log_scale;
+  td.pad = 0;
+  td.x = d;
+  td.a = d + N;
+  td.b = d + 2 * N;
+  return td;
 }
 
-template <int DIM, int P, class PH>
-void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_only) {
-  typedef Cfg<DIM, P> C;
-  const MeshDev m = op->mesh_dev();
-  const int grid = (op->ne + C::EPB - 1) / C::EPB;
-  const typename PH::Params &prm = op->dry;
-  hipStream_t s = op->stream;
-  if (op->timing) {
-    op->ev = op->evs[op->sets_recorded % tpsrhs_operator::MAXSETS];
-    HIP_CHECK(hipEventRecord(op->ev[0], s));
+void fill_plasma_params(tpsrhs_operator *op, const tpsrhs_disc *disc, const tpsrhs_physics *phys, int num_bcs,
+                        const tpsrhs_bc *bcs) {
+  constexpr int NSP = 3;
+  const tpsrhs_perfect_mixture &mx = phys->mixture;
+  PlasmaParams<NSP> &p = *new (op->params) PlasmaParams<NSP>;
+  std::memset(&p, 0, sizeof(p));
+  for (int sp = 0; sp < NSP; sp++) {
+    p.mw[sp] = mx.gas_params[sp + TPSRHS_SPECIES_MW * NSP];
+    p.charge[sp] = mx.gas_params[sp + TPSRHS_SPECIES_CHARGES * NSP];
+    p.eform[sp] = mx.gas_params[sp + TPSRHS_FORMATION_ENERGY * NSP];
+    p.cv[sp] = mx.molar_cv[sp] * kRgas;
+    p.cp[sp] = p.cv[sp] + kRgas;
   }
-  hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_Up, op->d_TA);
-  HIP_CHECK(hipGetLastError());
-  if (op->timing) HIP_CHECK(hipEventRecord(op->ev[1], s));
-  exchange(op, 0, op->d_TA, 2 * PH::NEQ, C::NF);
-  hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_TA, op->d_gradUp, op->d_TB);
-  HIP_CHECK(hipGetLastError());
-  if (op->timing) HIP_CHECK(hipEventRecord(op->ev[2], s));
-  if (gradients_only) return;
-  exchange(op, 1, op->d_TB, PH::NEQ, C::NQ);
-  if (!op->d_block_speed) {
-    op->d_block_speed = dev_alloc<double>(grid);
-    op->flux_grid = grid;
+  // PerfectMixture::PerfectMixture consistency checks, src/equation_of_state.cpp:505-530
+  if (p.charge[NSP - 1] != 0.0 || p.eform[NSP - 2] != 0.0 || p.eform[NSP - 1] != 0.0)
+    throw std::invalid_argument("mixture: background must be neutral; background/electron formation energy must be 0");
+  const tpsrhs_constant_transport &ct = phys->constant_transport;
+  p.c_visc = ct.viscosity;
+  p.c_bulk = ct.bulk_viscosity;
+  p.c_k = ct.thermal_conductivity;
+  p.c_ke = ct.electron_thermal_conductivity;
+  for (int sp = 0; sp < NSP; sp++) {
+    p.c_diff[sp] = ct.diffusivity[sp];
+    p.c_mtfreq[sp] = ct.mt_freq[sp];
   }
-  hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_gradUp, op->d_TA, op->d_TB, y,
-                     op->d_block_speed);
-  HIP_CHECK(hipGetLastError());
-  if (op->timing) {
-    HIP_CHECK(hipEventRecord(op->ev[3], s));
-    op->sets_recorded++;
+  p.c_eidx = ct.electron_index;
+  if (phys->transport_model == TPSRHS_CONSTANT && mx.two_temperature && ct.electron_index < 0)
+    throw std::invalid_argument("constant transport: electron index required for two-temperature plasma");
+  const tpsrhs_gas_transport &gt = phys->gas_transport;
+  if (phys->transport_model == TPSRHS_ARGON_MINIMAL) {
+    // GasMinimalTransport::GasMinimalTransport, src/gas_transport.cpp:43-128
+    if (gt.electron_index != NSP - 2 || gt.neutral_index != NSP - 1 || gt.ion_index != 0)
+      throw std::invalid_argument("argon transport: species must be ordered (ion, electron, neutral background)");
+    if (std::fabs(p.mw[gt.neutral_index] - p.mw[gt.electron_index] - p.mw[gt.ion_index]) >= 1.0e-12)
+      throw std::invalid_argument("argon transport: inconsistent species masses");
   }
-}
-
-template <int DIM, class PH>
-void pick_order(tpsrhs_operator *op) {
-  switch (op->order) {
-    case 1: op->launch = &launch_all<DIM, 1, PH>; break;
-    case 2: op->launch = &launch_all<DIM, 2, PH>; break;
-    case 3: op->launch = &launch_all<DIM, 3, PH>; break;
-    case 4: op->launch = &launch_all<DIM, 4, PH>; break;
-    default: throw Unsupported("polynomial order " + std::to_string(op->order) + " is not built (1..4)");
+  p.third_order = gt.third_order_k_electron;
+  p.multiply = gt.multiply;
+  for (int k = 0; k < 4; k++) p.mult_flux[k] = gt.flux_trns_multiplier[k];
+  p.mult_spcs = gt.spcs_trns_multiplier[0];
+  p.mult_diff = gt.diff_mult;
+  p.mult_mobil = gt.mobil_mult;
+  p.eq_system = phys->eq_system;
+  p.use_bc_in_grad = disc->use_bc_in_grad;
+  p.axisymmetric = disc->axisymmetric;
+  p.num_bcs = num_bcs;
+  for (int i = 0; i < num_bcs; i++) {
+    p.bc[i].category = bcs[i].category;
+    p.bc[i].type = bcs[i].type;
+    for (int k = 0; k < 4 + TPSRHS_MAXSPECIES; k++) p.bc[i].data[k] = bcs[i].data[k];
   }
+  // chemistry + radiation block
+  const tpsrhs_chemistry &ch = phys->chemistry;
+  if (ch.num_reactions < 0 || ch.num_reactions > TPSRHS_MAXREACTIONS) throw std::invalid_argument("num_reactions");
+  std::unique_ptr<ChemDev> c(new ChemDev);
+  std::memset(c.get(), 0, sizeof(ChemDev));
+  c->num_reactions = ch.num_reactions;
+  c->electron_index = ch.electron_index;
+  c->min_temperature = ch.minimum_temperature;
+  for (int r = 0; r < ch.num_reactions; r++) {
+    c->energy[r] = ch.reaction_energies[r];
+    c->model[r] = static_cast<signed char>(ch.reaction_models[r]);
+    c->detailed_balance[r] = ch.detailed_balance[r] != 0;
+    if (ch.reaction_models[r] > TPSRHS_TABULATED_RXN || ch.reaction_models[r] < 0)
+      throw Unsupported("reaction model outside the built scope (Arrhenius, Hoffert-Lien, tabulated)");
+    for (int k = 0; k < TPSRHS_MAXCHEMPARAMS; k++) {
+      c->rate[k + r * TPSRHS_MAXCHEMPARAMS] = ch.rate_params[k + r * TPSRHS_MAXCHEMPARAMS];
+      c->keq[k + r * TPSRHS_MAXCHEMPARAMS] = ch.equilibrium_constant_params[k + r * TPSRHS_MAXCHEMPARAMS];
+    }
+    for (int sp = 0; sp < NSP; sp++) {
+      const int a = ch.reactant_stoich[sp + r * NSP], b = ch.product_stoich[sp + r * NSP];
+      if (a < 0 || a > 8 || b < 0 || b > 8) throw std::invalid_argument("stoichiometric coefficient out of range");
+      c->reactant[sp + r * NSP] = static_cast<signed char>(a);
+      c->product[sp + r * NSP] = static_cast<signed char>(b);
+    }
+    if (ch.reaction_models[r] == TPSRHS_TABULATED_RXN) c->table[r] = upload_table(op, ch.rate_tables[r]);
+  }
+  c->radiation = phys->radiation.model;
+  if (c->radiation == TPSRHS_NET_EMISSION) c->nec = upload_table(op, phys->radiation.nec_table);
+  ChemDev *dc = dev_alloc<ChemDev>(1);
+  HIP_CHECK(hipMemcpy(dc, c.get(), sizeof(ChemDev), hipMemcpyHostToDevice));
+  op->d_chem = dc;
+  p.chem = dc;
 }
 
 void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc, const tpsrhs_physics *phys,
@@ -182,9 +136,10 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     throw Unsupported(
         "only the collocated Gauss-Legendre basis + Gauss-Legendre rule (basisType 0, integrationRule 0) is built");
   if (disc->axisymmetric) throw Unsupported("axisymmetric formulation is not built yet");
-  if (phys->working_fluid != TPSRHS_DRY_AIR) throw Unsupported("only WorkingFluid::DRY_AIR is built yet");
+  const bool plasma = phys->working_fluid == TPSRHS_USER_DEFINED;
+  if (phys->working_fluid != TPSRHS_DRY_AIR && !plasma) throw Unsupported("WorkingFluid::LTE_FLUID is out of scope");
   if (phys->eq_system != TPSRHS_EULER && phys->eq_system != TPSRHS_NS) throw Unsupported("NS_PASSIVE is out of scope");
-  if (num_bcs > MAXBC) throw Unsupported("too many boundary conditions");
+  if (num_bcs > (plasma ? PLASMA_MAXBC : MAXBC)) throw Unsupported("too many boundary conditions");
   for (int i = 0; i < num_bcs; i++) {
     const tpsrhs_bc &b = bcs[i];
     const bool ok = (b.category == TPSRHS_INLET && b.type == TPSRHS_SUB_DENS_VEL) ||
@@ -197,6 +152,14 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   op->order = disc->order;
   op->nvel = op->dim;
   op->neq = op->dim + 2;
+  if (plasma) {
+    const tpsrhs_perfect_mixture &mx = phys->mixture;
+    if (mx.num_species != 3 || !mx.is_electron_included || !mx.ambipolar)
+      throw Unsupported("USER_DEFINED fluids: only the ambipolar ternary mixture (ion, electron, neutral) is built");
+    if (phys->transport_model != TPSRHS_CONSTANT && phys->transport_model != TPSRHS_ARGON_MINIMAL)
+      throw Unsupported("transport model outside the built scope (constant, argon_minimal)");
+    op->neq = op->nvel + 2 + (mx.num_species - 2) + (mx.two_temperature ? 1 : 0);
+  }
   op->phys = *phys;
 
   int ndev = 0;
@@ -223,41 +186,43 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   const int npe = (op->dim == 3) ? n1 * n1 * n1 : n1 * n1;
   op->ndofs = static_cast<int64_t>(op->ne) * npe;
 
-  DryAirParams &d = op->dry;
-  std::memset(&d, 0, sizeof(d));
-  d.gamma = phys->dry_air.specific_heat_ratio;
-  d.Rg = phys->dry_air.gas_constant;
-  d.inv_Rg = 1.0 / d.Rg;
-  d.visc_mult = phys->dry_air.visc_mult;
-  d.bulk_mult = phys->dry_air.bulk_visc_mult;
-  d.C1 = phys->dry_air.sutherland_C1;
-  d.S0 = phys->dry_air.sutherland_S0;
-  d.cp_div_pr = d.gamma * d.Rg / (phys->dry_air.sutherland_Pr * (d.gamma - 1.0));
-  d.eq_system = phys->eq_system;
-  d.use_bc_in_grad = disc->use_bc_in_grad;
-  d.num_bcs = num_bcs;
-  for (int i = 0; i < num_bcs; i++) {
-    d.bc[i].category = bcs[i].category;
-    d.bc[i].type = bcs[i].type;
-    for (int k = 0; k < 4 + TPSRHS_MAXSPECIES; k++) d.bc[i].data[k] = bcs[i].data[k];
+  if (plasma) {
+    fill_plasma_params(op, disc, phys, num_bcs, bcs);
+    const int tr = (phys->transport_model == TPSRHS_CONSTANT) ? TRANSPORT_CONSTANT : TRANSPORT_ARGON_MINIMAL;
+    if (op->dim == 3)
+      pick_plasma3d(op, phys->mixture.two_temperature != 0, tr);
+    else
+      pick_plasma2d(op, phys->mixture.two_temperature != 0, tr);
+  } else {
+    DryAirParams &d = *new (op->params) DryAirParams;
+    std::memset(&d, 0, sizeof(d));
+    d.gamma = phys->dry_air.specific_heat_ratio;
+    d.Rg = phys->dry_air.gas_constant;
+    d.inv_Rg = 1.0 / d.Rg;
+    d.visc_mult = phys->dry_air.visc_mult;
+    d.bulk_mult = phys->dry_air.bulk_visc_mult;
+    d.C1 = phys->dry_air.sutherland_C1;
+    d.S0 = phys->dry_air.sutherland_S0;
+    d.cp_div_pr = d.gamma * d.Rg / (phys->dry_air.sutherland_Pr * (d.gamma - 1.0));
+    d.eq_system = phys->eq_system;
+    d.use_bc_in_grad = disc->use_bc_in_grad;
+    d.num_bcs = num_bcs;
+    for (int i = 0; i < num_bcs; i++) {
+      d.bc[i].category = bcs[i].category;
+      d.bc[i].type = bcs[i].type;
+      for (int k = 0; k < 4 + TPSRHS_MAXSPECIES; k++) d.bc[i].data[k] = bcs[i].data[k];
+    }
+    if (op->dim == 3)
+      pick_order<3, DryAirPhys<3>>(op);
+    else
+      pick_order<2, DryAirPhys<2>>(op);
   }
-
-  if (op->dim == 3)
-    pick_order<3, DryAirPhys<3>>(op);
-  else
-    pick_order<2, DryAirPhys<2>>(op);
 
   op->d_verts = dev_upload(tp.verts);
   {
     std::vector<int2> fi(tp.face_nbr.size());
     for (size_t i = 0; i < fi.size(); i++) fi[i] = make_int2(tp.face_nbr[i], tp.face_orient[i]);
     op->d_face_info = dev_upload(fi);
-  }
-  {
-    // 1-D operator tables -> __constant__ memory; a function of (dim, order) only
-    const Tables1D tabs = make_tables(op->order, op->dim);
-    const size_t off = (static_cast<size_t>(op->dim - 2) * (TPSRHS_MAXORDER + 1) + op->order) * sizeof(Tables1D);
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &tabs, sizeof(Tables1D), off, hipMemcpyHostToDevice));
   }
   if (op->ndofs >= (int64_t(1) << 31)) throw Unsupported("more than 2^31 nodes per rank");
   const int64_t nslots = static_cast<int64_t>(op->ne) * op->nfaces + tp.num_shared;
@@ -337,7 +302,7 @@ int tpsrhs_mult(tpsrhs_handle h, const double *x, double *y, double /*time*/, do
     HIP_CHECK(hipSetDevice(h->device));
     h->launch(h, x, y, false);
     if (max_char_speed) {
-      hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_speed);
+      hipLaunchKernelGGL(k_reduce_max<256>, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_speed);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipMemcpyAsync(max_char_speed, h->d_speed, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIP_CHECK(hipStreamSynchronize(h->stream));
