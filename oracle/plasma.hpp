@@ -125,7 +125,9 @@ class PerfectMixture : public GasMixture {
     double rhoB = rho;
     for (int sp = 0; sp < numActiveSpecies; sp++) rhoB -= GetGasParams(sp, TPSRHS_SPECIES_MW) * n_sp[sp];
     if (ambipolar) rhoB -= n_e * GetGasParams(iElectron, TPSRHS_SPECIES_MW);
-    if (rhoB < 0.) throw std::runtime_error("Negative background density");
+    if (rhoB < 0.)  // the reference prints and exits here (src/equation_of_state.cpp:641-647)
+      throw std::runtime_error("Negative background density: rho = " + std::to_string(rho) +
+                               ", n_sp[0] = " + std::to_string(n_sp[0]));
     return rhoB;
   }
   void computeNumberDensities(const double *state, double *n_sp) const {  // :947-961

@@ -57,3 +57,60 @@ def test_use_bc_in_grad():
     c.disc.use_bc_in_grad = 1
     c.physics.dry_air.visc_mult = 2000.0
     _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=5))
+
+
+# ---- argon ternary plasma (PerfectMixture + transport + chemistry sources), SURVEY.md 8a a13-a15 ----
+def _tol(amp):
+    """RHS_RTOL is stated for fields with 5 % variation.  The residual is a second difference of the
+    state: with perturbations of relative size `amp` both the kernels and the oracle lose a factor
+    0.05/amp to cancellation (boosted diffusion makes that term dominant), so the bound scales."""
+    return RHS_RTOL * 0.05 / amp
+
+
+def _boost_transport(ph, factor=300.0):
+    """make the diffusive terms count in the per-equation norms: [plasma_models/transport] multipliers
+    (src/gas_transport.cpp multiply_) or scaled constant coefficients"""
+    gt = ph.gas_transport
+    gt.multiply = 1
+    for k in range(4):
+        gt.flux_trns_multiplier[k] = factor
+    gt.diff_mult, gt.mobil_mult, gt.spcs_trns_multiplier[0] = factor, factor, 3.0
+    ct = ph.constant_transport
+    ct.viscosity *= factor
+    ct.bulk_viscosity = 0.3 * ct.viscosity
+    ct.thermal_conductivity *= factor
+    ct.electron_thermal_conductivity *= factor
+    for sp in range(3):
+        ct.diffusivity[sp] *= factor
+
+
+@pytest.mark.parametrize("order,two_t,transport,reactions,wall,eq", [
+    (2, False, capi.ARGON_MINIMAL, "arrhenius", capi.VISC_ISOTH, capi.NS),   # the physics of cfg3
+    (2, True, capi.ARGON_MINIMAL, "arrhenius", capi.VISC_ADIAB, capi.NS),
+    (1, True, capi.CONSTANT, "balance", capi.INV, capi.NS),
+    (3, False, capi.CONSTANT, "tabulated", capi.VISC_ISOTH, capi.NS),
+    (1, False, capi.ARGON_MINIMAL, "hoffertlien", capi.INV, capi.EULER),
+])
+def test_plasma_cylinder(order, two_t, transport, reactions, wall, eq):
+    c = cases.argon_cyl3d(4, 12, 3, order, two_t, transport, reactions, wall, eq, radiation=(reactions == "tabulated"))
+    _boost_transport(c.physics)
+    # amplitudes keep the interpolated species densities positive on these coarse meshes (the reference
+    # exits on a negative background density and divides by n_e)
+    amp = 0.005 if order == 1 else 0.01
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=2 + order, amp=amp), tol=_tol(amp))
+
+
+@pytest.mark.parametrize("two_t", [False, True])
+def test_plasma_periodic_box(two_t):
+    mesh = meshgen.scramble_orientations(meshgen.box_hex(3, 4, 3, lengths=(1.0, 0.8, 1.2), warp=0.1), 7)
+    ph = capi.argon_ternary_physics(capi.NS, two_t, capi.ARGON_MINIMAL, "arrhenius", third_order_ke=not two_t)
+    _boost_transport(ph)
+    U = cases.plasma_state(node_coordinates(mesh, 2), ph, nvel=3, seed=4, amp=0.01)
+    _compare(mesh, capi.Disc(2, 0, 0, 0, 0), ph, [], U, tol=_tol(0.01))
+
+
+def test_plasma_use_bc_in_grad():
+    c = cases.argon_cyl3d(4, 12, 3, 2, True, capi.CONSTANT, "arrhenius", capi.VISC_ISOTH)
+    c.disc.use_bc_in_grad = 1
+    _boost_transport(c.physics)
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=8, amp=0.01), tol=_tol(0.01))

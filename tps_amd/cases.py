@@ -57,13 +57,13 @@ def dry_air_state(X, seed=12345, amp=0.05, rho0=1.2, vel0=(20.0, 0.0, 0.0), p0=1
     return U
 
 
-def _waves(X, seed):
+def _waves(X, seed, kmax=3):
     rng = np.random.Generator(np.random.MT19937(seed))
     dim = X.shape[0]
     L = np.maximum(X.max(axis=1) - X.min(axis=1), 1e-12)
 
     def wave():
-        k = rng.integers(1, 4, size=dim) * 2.0 * np.pi / L
+        k = rng.integers(1, kmax + 1, size=dim) * 2.0 * np.pi / L
         ph = rng.uniform(0.0, 2.0 * np.pi)
         return np.sin(np.tensordot(k, X, axes=(0, 0)) + ph)
 
@@ -122,7 +122,7 @@ def plasma_state(X, physics, nvel, seed=12345, amp=0.05, p0=101300.0, vel0=(20.0
     """Smooth argon-plasma state: T_h in [3000, 12000] K, ionisation degree in
     [1e-6, 1e-2] (log-uniform waves), pressure p0(1 + amp wave), velocity free stream + amp waves,
     T_e = T_h (1 + 0.3 + 0.2 wave) for two-temperature mixtures."""
-    wave = _waves(X, seed)
+    wave = _waves(X, seed, kmax=1)  # species densities must stay positive under interpolation
     R = capi.UNIVERSALGASCONSTANT
     mx = physics.mixture
     nsp = mx.num_species
