@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: RHSoperator::Mult on the 3-D p=3 Navier-Stokes cylinder workload.
+"""Benchmark of the hot path: RHSoperator::Mult on the 3-D p=3 cylinder workloads.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload argon_p3|cfg2|cfg3]
 
 A "step" is one ``Mult`` (one explicit DG right-hand-side evaluation) over state resident in HBM.
-N = 1: BASELINE.json configs[1] (28x112x16 = 50 176 hexes, p = 3, 3 211 264 nodes, 5 equations).
+The mesh of every workload is the 28x112x16 = 50 176-hex O-grid cylinder of BASELINE.json
+configs[1]/[2] per GPU.  Workloads:
+  argon_p3 (default)  what BASELINE.json's metric is quoted on -- "3D p=3 reacting cyl": the argon
+                      ternary plasma of configs[2] (ambipolar, single temperature, argon-minimal
+                      transport, 2 Arrhenius reactions) at the p=3 of configs[1]; 6 equations
+  cfg2                configs[1]: perfect-gas Navier-Stokes, p=3, 5 equations (no chemistry)
+  cfg3                configs[2]: the argon plasma at p=2
 N > 1 (launched by ``torch.distributed.run``, one rank per GPU): every rank owns one such block --
 spanwise slabs of an N-times longer cylinder -- and exchanges the traces of its two shared planes
 with RCCL send/recv (weak scaling, no collective on the data path).
@@ -37,7 +43,31 @@ def algorithmic_bytes_per_node(neq, dim, p):
     return {"k_gradient": sweep1, "k_flux": sweep2, "mult": sweep1 + sweep2}
 
 
-def cpu_baseline(neq, order, budget_s=20.0):
+def workload(name):
+    """-> order, physics, bcs(physics), state(X, physics), description, sample-case builder"""
+    from tps_amd import capi, cases
+
+    if name == "cfg2":
+        return (3, capi.dry_air_physics(capi.NS), lambda ph: cases.cylinder_bcs(capi.VISC_ISOTH, 300.0),
+                lambda X, ph: cases.dry_air_state(X, seed=12345),
+                "perfect-gas Navier-Stokes (dry air, Sutherland), inlet SUB_DENS_VEL / outlet SUB_P / isothermal "
+                "wall (BASELINE.json configs[1])",
+                lambda order: cases.cyl3d(7, 28, 4, order, capi.NS, capi.VISC_ISOTH))
+    if name in ("argon_p3", "cfg3"):
+        order = 3 if name == "argon_p3" else 2
+        what = ("BASELINE.json metric: 3D p=3 reacting cylinder = configs[2] physics at configs[1] order"
+                if name == "argon_p3" else "BASELINE.json configs[2]")
+        return (order, capi.argon_ternary_physics(capi.NS, False, capi.ARGON_MINIMAL, "arrhenius"),
+                lambda ph: cases.plasma_cylinder_bcs(ph, capi.VISC_ISOTH, 3000.0),
+                lambda X, ph: cases.plasma_state(X, ph, nvel=3, seed=12345, amp=0.05),
+                "reacting argon ternary plasma (Ar+, e, Ar; ambipolar, single temperature), argon-minimal "
+                "collision-integral transport with 3rd-order electron conductivity, 2 Arrhenius reactions, inlet "
+                f"SUB_DENS_VEL / outlet SUB_P / isothermal wall ({what})",
+                lambda order: cases.argon_cyl3d(7, 28, 4, order))
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(neq, order, sample_case, budget_s=20.0):
     """The oracle (CPU restatement, reference-faithful dense formulation) timed on this host on a
     bounded sample of the same workload: a 7x28x4 = 784-element O-grid block of the cylinder at the
     same order, physics and boundary conditions."""
@@ -46,7 +76,7 @@ def cpu_baseline(neq, order, budget_s=20.0):
 
     from tps_amd import capi, cases
 
-    c = cases.cyl3d(7, 28, 4, order, capi.NS, capi.VISC_ISOTH)
+    c = sample_case(order)
     # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe
     threads = min(len(os.sched_getaffinity(0)), 16)
     o = Oracle(c.mesh, c.disc, c.physics, c.bcs, threads=threads)
@@ -60,7 +90,7 @@ def cpu_baseline(neq, order, budget_s=20.0):
     dt = (time.perf_counter() - t0) / n
     ndofs = U.shape[1]
     return {"value": ndofs * neq / dt / 1e6, "unit": "MDOF/s", "cores": threads, "kind": "port",
-            "sample": f"cyl3d O-grid 7x28x4 = {c.mesh.num_elements} hexes, p={order}, NS dry air, "
+            "sample": f"cyl3d O-grid 7x28x4 = {c.mesh.num_elements} hexes, p={order}, {c.description}, "
                       f"{ndofs} nodes, {n} Mult calls, OpenMP over elements/faces/nodes",
             "evals_per_s_on_sample": 1.0 / dt}
 
@@ -73,7 +103,8 @@ def main():
     ap.add_argument("--nr", type=int, default=28)
     ap.add_argument("--ntheta", type=int, default=112)
     ap.add_argument("--nz", type=int, default=16)
-    ap.add_argument("--order", type=int, default=3)
+    ap.add_argument("--order", type=int, default=0, help="override the workload's polynomial order")
+    ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -99,13 +130,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         halo = HaloExchange(device=torch.device("cuda", local_rank))
 
-    order = args.order
+    order, physics, make_bcs, make_state, description, sample_case = workload(args.workload)
+    order = args.order or order
     mesh = meshgen.ogrid_cylinder_slab(args.nr, args.ntheta, args.nz, rank, world)
     disc = capi.Disc(order, 0, 0, 0, 0)
-    physics = capi.dry_air_physics(capi.NS)
-    bcs = cases.cylinder_bcs(capi.VISC_ISOTH, 300.0)
+    bcs = make_bcs(physics)
     X = node_coordinates(mesh, order)
-    U = cases.dry_air_state(X, seed=12345)
+    U = make_state(X, physics)
     del X
 
     op = RHSoperator(mesh, disc, physics, bcs, device=local_rank, halo=halo)
@@ -161,9 +192,8 @@ def main():
             "value": value, "unit": "MDOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} hexes per GPU, p={order}, "
-                                   "perfect-gas Navier-Stokes (dry air, Sutherland), GL basis + GL rule, "
-                                   "inlet SUB_DENS_VEL / outlet SUB_P / isothermal wall (BASELINE.json configs[1])",
+            "config": {"workload": f"{args.workload}: cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} hexes per GPU, "
+                                   f"p={order}, GL basis + GL rule, {description}",
                        "elements_per_gpu": mesh.num_elements, "nodes_per_gpu": ndofs, "num_equation": neq,
                        "partition": "spanwise slabs, RCCL send/recv of face traces" if world > 1 else "single GPU"},
             "rhs_evals_per_s": evals_per_s,
@@ -175,7 +205,7 @@ def main():
                          "mult_algorithmic_GBps": alg["mult"] * ndofs / (ms_per_step * 1e-3) / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(neq, order)
+            out["cpu_baseline"] = cpu_baseline(neq, order, sample_case)
         print(json.dumps(out))
     op.close()
     if world > 1:

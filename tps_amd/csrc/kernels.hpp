@@ -614,15 +614,12 @@ __device__ inline void grad_jump_dir(const MeshDev &m, const int2 *sFI, const ty
   block_sync<C::BLOCK>();
 }
 
-// viscous normal-flux traces of one direction pair
+// viscous normal-flux traces of one direction pair: [U | gradUp] at the face quadrature points ...
 template <class C, class PH, int D>
-__device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
-                                       const double *sU,
-                                       const double *sG, double *Tb, double *Wb, const double *sV, const Tab<C> &tab,
-                                       const Tables1D &ct, double *__restrict__ TB, int tid) {
+__device__ inline void visc_interp_dir(const double *sU, const double *sG, double *Tb, double *Wb, const Tab<C> &tab,
+                                       const Tables1D &ct, double (&v)[C::Q_ROUNDS][GradLds<C, PH>::NVF], int tid) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   typedef GradLds<C, PH> L;
-  double v[C::Q_ROUNDS][L::NVF];
 #pragma unroll
   for (int c0 = 0; c0 < L::NVF; c0 += L::CH) {
     // fields c0 .. c0+CH of [U | gradUp]
@@ -653,6 +650,24 @@ __device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const 
     }
     block_sync<C::BLOCK>();
   }
+}
+template <class C>
+__device__ inline void face_geometry_rt(int d, const double *verts, const Tab<C> &tab, int s, int q, double *n, double &wq,
+                                        double *Xq) {
+  if (d == 0)
+    face_geometry<C, 0>(verts, tab, s, q, n, wq, Xq);
+  else if (d == 1 || C::DIM == 2)
+    face_geometry<C, 1>(verts, tab, s, q, n, wq, Xq);
+  else
+    face_geometry<C, (C::DIM == 3 ? 2 : 0)>(verts, tab, s, q, n, wq, Xq);
+}
+// ... and the point physics on them.  `d` is a run-time value here so that physics with a large body
+// (PH::HEAVY: plasma transport) is instantiated once per kernel, not once per direction pair.
+template <class C, class PH>
+__device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0, int d,
+                                   double (&v)[C::Q_ROUNDS][GradLds<C, PH>::NVF], const double *sV, const Tab<C> &tab,
+                                   double *__restrict__ TB, int tid) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
 #pragma unroll
   for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
     const int item = tid + rd * C::BLOCK;
@@ -661,21 +676,34 @@ __device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const 
     const int le = pf >> 1, s = pf & 1;
     const int e = e0 + le;
     if (e >= m.ne) continue;
-    const int slot = e * C::NFACES + 2 * D + s;
-    const int nb = sFI[le * C::NFACES + 2 * D + s].x;
+    const int slot = e * C::NFACES + 2 * d + s;
+    const int nb = sFI[le * C::NFACES + 2 * d + s].x;
     double fn[NEQ];
     PH::clamp_species(v[rd]);
     double n[DIM], wq, Xq[DIM];
-    face_geometry<C, D>(&sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
-    if (nb >= 0) {
-      PH::visc_flux_n(prm, v[rd], v[rd] + NEQ, n, fn);
+    face_geometry_rt<C>(d, &sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
+    if constexpr (PH::HEAVY) {
+      PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, fn);
     } else {
-      PH::bc_visc_term(prm, prm.bc[-nb - 1], v[rd], v[rd] + NEQ, n, fn);
+      if (nb >= 0) {
+        PH::visc_flux_n(prm, v[rd], v[rd] + NEQ, n, fn);
+      } else {
+        PH::bc_visc_term(prm, prm.bc[-nb - 1], v[rd], v[rd] + NEQ, n, fn);
+      }
     }
     double *out = TB + static_cast<int64_t>(slot) * (NEQ * C::NQ) + q;
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) out[eq * C::NQ] = fn[eq];
   }
+}
+template <class C, class PH, int D>
+__device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
+                                       const double *sU,
+                                       const double *sG, double *Tb, double *Wb, const double *sV, const Tab<C> &tab,
+                                       const Tables1D &ct, double *__restrict__ TB, int tid) {
+  double v[C::Q_ROUNDS][GradLds<C, PH>::NVF];
+  visc_interp_dir<C, PH, D>(sU, sG, Tb, Wb, tab, ct, v, tid);
+  visc_points<C, PH>(m, sFI, prm, e0, D, v, sV, tab, TB, tid);
 }
 
 template <class C, class PH>
@@ -787,9 +815,24 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
 
   // ---- viscous normal-flux traces (T chunk in the sUp region, W chunk in Y)
   if (!(TPSRHS_ABLATE & 16)) {
-    visc_traces_dir<C, PH, 0>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
-    visc_traces_dir<C, PH, 1>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
-    if (DIM == 3) visc_traces_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
+    if constexpr (PH::HEAVY) {
+#pragma clang loop unroll(disable)
+      for (int d = 0; d < DIM; d++) {
+        double v[C::Q_ROUNDS][L::NVF];
+        if (d == 0)
+          visc_interp_dir<C, PH, 0>(sU, sG, sUp, sY, tab, ct, v, tid);
+        else if (d == 1)
+          visc_interp_dir<C, PH, 1>(sU, sG, sUp, sY, tab, ct, v, tid);
+        else
+          visc_interp_dir<C, PH, (DIM == 3 ? 2 : 0)>(sU, sG, sUp, sY, tab, ct, v, tid);
+        visc_points<C, PH>(m, sFI, prm, e0, d, v, sV, tab, TB, tid);
+        block_sync<C::BLOCK>();
+      }
+    } else {
+      visc_traces_dir<C, PH, 0>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
+      visc_traces_dir<C, PH, 1>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
+      if (DIM == 3) visc_traces_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
+    }
   }
 }
 

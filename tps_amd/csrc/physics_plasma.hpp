@@ -92,19 +92,31 @@ __device__ inline double table_eval(const TableDev &t, double xe) {  // src/tabl
 }
 
 namespace coll {  // collision-integral fits, src/collision_integrals.cpp
-__device__ inline double cfit(double c0, double c1, double c2, double c3, double Tp) {
-  return c0 * pow(log(1.0 + c1 * pow(Tp, c2)), c3) / Tp / Tp;
+// c0 log(1 + c1 Tp^c2)^c3 / Tp^2 with the powers taken through exp/log of the argument's logarithm,
+// which the fits of one point share (the reference calls pow twice per fit; the results agree to a few
+// ulp, far inside the stated tolerance, at a third of the FP64 instructions)
+struct Arg {
+  double ln, inv2;  // log(Tp), 1/Tp^2
+};
+__device__ inline Arg arg(double Tp) {
+  Arg a;
+  a.ln = log(Tp);
+  a.inv2 = 1.0 / (Tp * Tp);
+  return a;
 }
-__device__ inline double att11(double Tp) { return cfit(0.2150, 5.2194, 1.0472, 1.2435, Tp); }
-__device__ inline double att12(double Tp) { return cfit(0.0991, 7.4684, 1.0155, 1.1536, Tp); }
-__device__ inline double att13(double Tp) { return cfit(0.0616, 7.8271, 0.9452, 1.1105, Tp); }
-__device__ inline double att14(double Tp) { return cfit(0.0308, 13.9567, 0.9511, 1.1803, Tp); }
-__device__ inline double att15(double Tp) { return cfit(0.0232, 13.7888, 0.9148, 1.1532, Tp); }
-__device__ inline double rep22(double Tp) { return cfit(0.4128, 1.2436, 1.1830, 1.0123, Tp); }
-__device__ inline double rep23(double Tp) { return cfit(0.2203, 1.8832, 1.2059, 0.9851, Tp); }
-__device__ inline double rep24(double Tp) { return cfit(0.1323, 2.7248, 1.2129, 0.9847, Tp); }
-__device__ inline double ArAr22(double T) { return 1.7e-18 * pow(T, -0.25); }
-__device__ inline double ArAr1P11(double T) { return 4.574321e-18 * pow(T, -0.1805); }
+__device__ inline double cfit(double c0, double c1, double c2, double c3, const Arg &a) {
+  return c0 * exp(c3 * log(log(1.0 + c1 * exp(c2 * a.ln)))) * a.inv2;
+}
+__device__ inline double att11(const Arg &a) { return cfit(0.2150, 5.2194, 1.0472, 1.2435, a); }
+__device__ inline double att12(const Arg &a) { return cfit(0.0991, 7.4684, 1.0155, 1.1536, a); }
+__device__ inline double att13(const Arg &a) { return cfit(0.0616, 7.8271, 0.9452, 1.1105, a); }
+__device__ inline double att14(const Arg &a) { return cfit(0.0308, 13.9567, 0.9511, 1.1803, a); }
+__device__ inline double att15(const Arg &a) { return cfit(0.0232, 13.7888, 0.9148, 1.1532, a); }
+__device__ inline double rep22(const Arg &a) { return cfit(0.4128, 1.2436, 1.1830, 1.0123, a); }
+__device__ inline double rep23(const Arg &a) { return cfit(0.2203, 1.8832, 1.2059, 0.9851, a); }
+__device__ inline double rep24(const Arg &a) { return cfit(0.1323, 2.7248, 1.2129, 0.9847, a); }
+__device__ inline double ArAr22(double T) { return 1.7e-18 / sqrt(sqrt(T)); }  // T^-0.25
+__device__ inline double ArAr1P11(double lnT) { return 4.574321e-18 * exp(-0.1805 * lnT); }
 __device__ inline double eAr1r(int r, double logT) {
   const double C[5][9] = {
       {6.36254140e-18, 1.84835040e-18, -5.87727093e-18, 3.20023027e-18, -8.50509054e-19, 1.28163820e-19,
@@ -329,14 +341,14 @@ struct PlasmaPhys {
   struct Trans {
     double visc, bulk, k, ke;
     double V[NSP * DIM];  // diffusion velocities [sp + d*NSP]
-    double mtfreq[NSP];   // electron momentum-transfer frequencies (source variant)
     double n[NSP];        // number densities of computeSpeciesPrimitives
   };
   // species positions of the argon ternary mixture are fixed by the mixture ordering (electron
   // second to last, neutral background last); tpsrhs_create checks the tpsrhs_gas_transport indices
   static constexpr int I_E = IE, I_N = IB, I_ION = 0;
   struct Debye {
-    double circle, ndTe, ndTh;
+    double circle;
+    coll::Arg e, h;  // nondimensional electron / heavy temperatures
   };
   __device__ static inline Debye debye(const double *n, double Th, double Te) {
     const double dfac = kBoltz * kEps0 / kQe / kQe;
@@ -344,19 +356,19 @@ struct PlasmaPhys {
     const double length = sqrt(dfac / kAvogadro / nOverT);
     Debye d;
     d.circle = kPi * length * length;
-    d.ndTe = length * 4.0 * kPi * dfac * Te;
-    d.ndTh = length * 4.0 * kPi * dfac * Th;
+    const double f = length * 4.0 * kPi * dfac;
+    d.e = coll::arg(f * Te);
+    d.h = TWOT ? coll::arg(f * Th) : d.e;
     return d;
   }
-  __device__ static inline double third_order_ke(const double *X, const Debye &d, double Te, double me, double vf,
-                                                 double kf) {  // :400-489
-    const double Q2[3] = {d.circle * coll::rep22(d.ndTe), d.circle * coll::rep23(d.ndTe), d.circle * coll::rep24(d.ndTe)};
-    const double QI[5] = {d.circle * coll::att11(d.ndTe), d.circle * coll::att12(d.ndTe), d.circle * coll::att13(d.ndTe),
-                          d.circle * coll::att14(d.ndTe), d.circle * coll::att15(d.ndTe)};
-    const double lT = log(Te);
+  __device__ static inline double third_order_ke(const double *X, const Debye &d, double Te, double lnTe, double att11c,
+                                                 double me, double vf, double kf) {  // :400-489
+    const double Q2[3] = {d.circle * coll::rep22(d.e), d.circle * coll::rep23(d.e), d.circle * coll::rep24(d.e)};
+    const double QI[5] = {att11c, d.circle * coll::att12(d.e), d.circle * coll::att13(d.e), d.circle * coll::att14(d.e),
+                          d.circle * coll::att15(d.e)};
     double QN[5];
 #pragma unroll
-    for (int r = 1; r <= 5; r++) QN[r - 1] = coll::eAr1r(r, lT);
+    for (int r = 1; r <= 5; r++) QN[r - 1] = coll::eAr1r(r, lnTe);
     auto L11ea = [](const double *Q) { return 6.25 * Q[0] - 15. * Q[1] + 12. * Q[2]; };
     auto L12ea = [](const double *Q) { return 10.9375 * Q[0] - 39.375 * Q[1] + 57. * Q[2] - 30. * Q[3]; };
     auto L22ea = [](const double *Q) {
@@ -375,13 +387,15 @@ struct PlasmaPhys {
     return vf * kf * sqrt(2.0 * Te / me) * X[I_E] / (L11 - L12 * L12 / L22);
   }
 
-  // flux (source=false) or source (source=true) transport: ComputeFluxTransportProperties /
-  // ComputeSourceTransportProperties of the selected model; E-field = 0 (src/fluxes.cpp:200-201)
+  // ComputeFluxTransportProperties of the selected model; E-field = 0 (src/fluxes.cpp:200-201).
+  // `diffusion` = false skips the diffusion velocities (walls prescribe zero species fluxes).
   __device__ static inline void transport(const Params &p, const double *U, double Th, double Te, const double *g,
-                                          bool source, Trans &t) {
+                                          bool diffusion, Trans &t) {
     const Species q = species(p, U);
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++) t.n[sp] = q.n[sp];
+#pragma unroll
+    for (int k = 0; k < NSP * DIM; k++) t.V[k] = 0.0;
     double diff[NSP], mob[NSP];
     if (TRANSPORT == TRANSPORT_CONSTANT) {
       t.visc = p.c_visc;
@@ -393,55 +407,52 @@ struct PlasmaPhys {
         diff[sp] = p.c_diff[sp];
         const double temp = (sp == p.c_eidx) ? Te : Th;
         mob[sp] = (kQe / kBoltz) * p.charge[sp] / temp * diff[sp];
-        t.mtfreq[sp] = p.c_mtfreq[sp];
       }
     } else {
       const double vf = 5. / 16. * sqrt(kPi * kBoltz), kf = 15. / 4. * kBoltz;
       const double dfc = 3. / 16. * sqrt(2.0 * kPi * kBoltz) / kAvogadro;
-      const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
       double mwp[NSP];  // per-particle masses
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) mwp[sp] = p.mw[sp] / kAvogadro;
       const Debye d = debye(q.n, Th, Te);
-      const double QeAr = coll::eAr1r(1, log(Te)), Qatt = coll::att11(d.ndTe) * d.circle;
-      t.visc = t.bulk = t.k = t.ke = 0.0;
-      if (!source) {
-        double sv[NSP];
+      const double lnTe = log(Te), lnTh = TWOT ? log(Th) : lnTe;
+      const double QeAr = coll::eAr1r(1, lnTe), Qatt = coll::att11(d.e) * d.circle;
+      double sv[NSP];
 #pragma unroll
-        for (int sp = 0; sp < NSP; sp++) sv[sp] = 0.0;
-        sv[I_ION] = vf * sqrt(mwp[I_ION] * Th) / (coll::rep22(d.ndTh) * d.circle);
-        sv[I_N] = vf * sqrt(mwp[I_N] * Th) / coll::ArAr22(Th);
+      for (int sp = 0; sp < NSP; sp++) sv[sp] = 0.0;
+      sv[I_ION] = vf * sqrt(mwp[I_ION] * Th) / (coll::rep22(d.h) * d.circle);
+      sv[I_N] = vf * sqrt(mwp[I_N] * Th) / coll::ArAr22(Th);
+      t.visc = t.bulk = t.k = 0.0;
 #pragma unroll
-        for (int sp = 0; sp < NSP; sp++) {
-          t.visc += q.X[sp] * sv[sp];
-          t.k += q.X[sp] * (sv[sp] * kf / mwp[sp]);
+      for (int sp = 0; sp < NSP; sp++) {
+        t.visc += q.X[sp] * sv[sp];
+        t.k += q.X[sp] * (sv[sp] * kf / mwp[sp]);
+      }
+      if (p.third_order)
+        t.ke = third_order_ke(q.X, d, Te, lnTe, Qatt, mwp[I_E], vf, kf);
+      else
+        t.ke = vf * kf * sqrt(Te / mwp[I_E]) * q.X[I_E] / (coll::rep22(d.e) * d.circle);
+      if (diffusion) {
+        auto muw = [&](int i, int j) { return mwp[i] * mwp[j] / (mwp[i] + mwp[j]); };
+        double bd[NSP * NSP];
+#pragma unroll
+        for (int i = 0; i < NSP * NSP; i++) bd[i] = 0.0;
+        bd[I_E + I_N * NSP] = bd[I_N + I_E * NSP] = dfc * sqrt(Te / muw(I_E, I_N)) / q.ntot / QeAr;
+        bd[I_N + I_ION * NSP] = bd[I_ION + I_N * NSP] =
+            dfc * sqrt(Th / muw(I_N, I_ION)) / q.ntot / coll::ArAr1P11(lnTh);
+        bd[I_E + I_ION * NSP] = bd[I_ION + I_E * NSP] = dfc * sqrt(Te / muw(I_ION, I_E)) / q.ntot / Qatt;
+        // CurtissHirschfelder, src/transport_properties.cpp:188-201
+#pragma unroll
+        for (int i = 0; i < NSP; i++) {
+          double a = 0.0;
+#pragma unroll
+          for (int j = 0; j < NSP; j++)
+            if (i != j) a += (q.X[j] + kXeps) / bd[i + j * NSP];
+          diff[i] = (1.0 - q.Y[i]) / a;
+          const double temp = (i == I_E) ? Te : Th;
+          mob[i] = (kQe / kBoltz) * p.charge[i] / temp * diff[i];
         }
-        if (p.third_order)
-          t.ke = third_order_ke(q.X, d, Te, mwp[I_E], vf, kf);
-        else
-          t.ke = vf * kf * sqrt(Te / mwp[I_E]) * q.X[I_E] / (coll::rep22(d.ndTe) * d.circle);
       }
-      auto muw = [&](int i, int j) { return mwp[i] * mwp[j] / (mwp[i] + mwp[j]); };
-      double bd[NSP * NSP];
-#pragma unroll
-      for (int i = 0; i < NSP * NSP; i++) bd[i] = 0.0;
-      bd[I_E + I_N * NSP] = bd[I_N + I_E * NSP] = dfc * sqrt(Te / muw(I_E, I_N)) / q.ntot / QeAr;
-      bd[I_N + I_ION * NSP] = bd[I_ION + I_N * NSP] = dfc * sqrt(Th / muw(I_N, I_ION)) / q.ntot / coll::ArAr1P11(Th);
-      bd[I_E + I_ION * NSP] = bd[I_ION + I_E * NSP] = dfc * sqrt(Te / muw(I_ION, I_E)) / q.ntot / Qatt;
-      // CurtissHirschfelder, src/transport_properties.cpp:188-201
-#pragma unroll
-      for (int i = 0; i < NSP; i++) {
-        double a = 0.0;
-#pragma unroll
-        for (int j = 0; j < NSP; j++)
-          if (i != j) a += (q.X[j] + kXeps) / bd[i + j * NSP];
-        diff[i] = (1.0 - q.Y[i]) / a;
-        const double temp = (i == I_E) ? Te : Th;
-        mob[i] = (kQe / kBoltz) * p.charge[i] / temp * diff[i];
-        t.mtfreq[i] = 0.0;
-      }
-      t.mtfreq[I_ION] = mff * sqrt(Te / mwp[I_E]) * q.n[I_ION] * Qatt;
-      t.mtfreq[I_N] = mff * sqrt(Te / mwp[I_E]) * q.n[I_N] * QeAr;
       if (p.multiply) {
         t.visc *= p.mult_flux[0];
         t.bulk *= p.mult_flux[1];
@@ -451,10 +462,10 @@ struct PlasmaPhys {
         for (int sp = 0; sp < NSP; sp++) {
           diff[sp] *= p.mult_diff;
           mob[sp] *= p.mult_mobil;
-          t.mtfreq[sp] *= p.mult_spcs;
         }
       }
     }
+    if (!diffusion) return;
     // diffusion velocities: -D grad X / X, ambipolar field, mass-flux correction
     // (src/transport_properties.cpp:59-136)
     double mho = 0.0;
@@ -481,6 +492,35 @@ struct PlasmaPhys {
       for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] -= Vc;
     }
   }
+  // what SourceTerm uses of ComputeSourceTransportProperties (src/gas_transport.cpp:592-773,
+  // src/transport_properties.cpp:392-449): the number densities of computeSpeciesPrimitives and the
+  // electron momentum-transfer frequencies.  (The reference also evaluates the diffusion velocities and
+  // the electric conductivity there; no term of the hot path reads them.)
+  __device__ static inline void source_props(const Params &p, const double *U, double Th, double Te, double *n,
+                                             double *mtfreq) {
+    const Species q = species(p, U);
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) {
+      n[sp] = q.n[sp];
+      mtfreq[sp] = 0.0;
+    }
+    if (!TWOT) return;  // the frequencies enter the electron-energy exchange only
+    if (TRANSPORT == TRANSPORT_CONSTANT) {
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) mtfreq[sp] = p.c_mtfreq[sp];
+    } else {
+      const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
+      const double me = p.mw[I_E] / kAvogadro;
+      const Debye d = debye(q.n, Th, Te);
+      const double QeAr = coll::eAr1r(1, log(Te)), Qatt = coll::att11(d.e) * d.circle;
+      mtfreq[I_ION] = mff * sqrt(Te / me) * q.n[I_ION] * Qatt;
+      mtfreq[I_N] = mff * sqrt(Te / me) * q.n[I_N] * QeAr;
+      if (p.multiply) {
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) mtfreq[sp] *= p.mult_spcs;
+      }
+    }
+  }
   __device__ static inline void enthalpies(const Params &p, const State &s, double *h) {  // :1192-1207
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++) h[sp] = s.n[sp] * (p.cp[sp] * ((sp == IE) ? s.Te : s.Th) + p.eform[sp]);
@@ -493,7 +533,7 @@ struct PlasmaPhys {
     for (int i = 0; i < NEQ * DIM; i++) Fv[i] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
     Trans t;
-    transport(p, U, s.Th, s.Te, g, false, t);
+    transport(p, U, s.Th, s.Te, g, true, t);
     double h[NSP];
     enthalpies(p, s, h);
     const double bulk = t.bulk - 2. / 3. * t.visc;
@@ -546,34 +586,30 @@ struct PlasmaPhys {
       if (TWOT) F[ITE + d * NEQ] = (U[ITE] + s.pe) * s.vel[d] - Fv[ITE + d * NEQ];
     }
   }
-  __device__ static inline void visc_flux_n(const Params &p, const double *U, const double *g, const double *n,
-                                            double *Fn) {
-    double Fv[NEQ * DIM];
-    visc_flux(p, U, make_state(p, U), g, Fv);
+  // Normal viscous flux Fv(U, g) . n of ComputeViscousFluxes, or -- with the wall prescriptions of
+  // ComputeBdrViscousFluxes (src/fluxes.cpp:344-505) -- the same with zero species diffusion fluxes
+  // (`zero_species`) and zero heat fluxes (`zero_heat`).  The reference evaluates the boundary variant
+  // with the unit normal and rescales by |n|; the flux is linear in n, so n is used directly.
+  __device__ static inline void visc_normal_flux(const Params &p, const double *U, const double *g, const double *n,
+                                                 bool zero_species, bool zero_heat, double *Fn) {
+    const State s = make_state(p, U);
+    Trans t;
+    transport(p, U, s.Th, s.Te, g, !zero_species, t);
+    double h[NSP], Vn[NSP];
+    enthalpies(p, s, h);
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) {
+    for (int sp = 0; sp < NSP; sp++) {
       double a = 0.0;
 #pragma unroll
-      for (int d = 0; d < DIM; d++) a += Fv[eq + d * NEQ] * n[d];
-      Fn[eq] = a;
+      for (int d = 0; d < DIM; d++) a += t.V[sp + d * NSP] * n[d];
+      Vn[sp] = a;  // zero when the diffusion velocities were skipped
     }
-  }
-  // ComputeBdrViscousFluxes (src/fluxes.cpp:344-505) with the prescriptions of the in-scope walls:
-  // species normal diffusion fluxes = 0; heat fluxes = 0 when `adiabatic`
-  __device__ static inline void bdr_visc_flux(const Params &p, const double *Uw, const double *g, const double *nu,
-                                              bool adiabatic, double *Fn) {
-#pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) Fn[eq] = 0.0;
-    if (p.eq_system == TPSRHS_EULER) return;
-    const State s = make_state(p, Uw);
-    Trans t;
-    transport(p, Uw, s.Th, s.Te, g, false, t);
     const double bulk = t.bulk - 2. / 3. * t.visc;
-    double k = t.k;
     double divV = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
     double e = 0.0;
+    Fn[0] = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) {
       double sn = 0.0;
@@ -581,27 +617,28 @@ struct PlasmaPhys {
       for (int j = 0; j < DIM; j++) {
         double st = t.visc * (g[(1 + j) + i * NEQ] + g[(1 + i) + j * NEQ]);
         if (i == j) st += bulk * divV;
-        sn += st * nu[j];
+        sn += st * n[j];
       }
       Fn[1 + i] = sn;
       e += sn * s.vel[i];
     }
-    double qe = 0.0, qh = 0.0;  // heat fluxes (standard sign); species fluxes are prescribed zero
-    if (!adiabatic) {
+    double qh = 0.0, qe = 0.0;  // k grad T . n
+    if (!zero_heat) {
+      const double k = TWOT ? t.k : t.k + t.ke;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) qh += k * g[ITH + d * NEQ] * n[d];
       if (TWOT) {
 #pragma unroll
-        for (int d = 0; d < DIM; d++) qe -= t.ke * g[ITE + d * NEQ] * nu[d];
-      } else {
-        k += t.ke;
+        for (int d = 0; d < DIM; d++) qe += t.ke * g[ITE + d * NEQ] * n[d];
       }
+    }
+    e += qh + qe;
 #pragma unroll
-      for (int d = 0; d < DIM; d++) qh -= k * g[ITH + d * NEQ] * nu[d];
-    }
-    Fn[ITH] = e - qh;
-    if (TWOT) {
-      Fn[ITH] -= qe;
-      Fn[ITE] = -qe;
-    }
+    for (int sp = 0; sp < NSP; sp++) e -= h[sp] * Vn[sp];
+    Fn[ITH] = e;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) Fn[NVEL + 2 + sp] = -U[NVEL + 2 + sp] * Vn[sp];
+    if (TWOT) Fn[ITE] = qe - h[IE] * Vn[IE];
   }
 
   // ---- boundary conditions ------------------------------------------------------------------
@@ -691,45 +728,64 @@ struct PlasmaPhys {
       }
     }
   }
-  __device__ static inline void bc_visc_term(const Params &p, const BcDev &bc, const double *U, const double *g,
-                                             const double *n, double *out) {
+  // The viscous trace of one face quadrature point.  Interior face (nb >= 0): Fv(U, g) . n.  Boundary
+  // face: the complete additive viscous boundary term -1/2 (Fv_wall + Fv_in) . n of the wall types
+  // (src/wallBC.cpp:302-320,448-468,492-510), zero for inlets and outlets.  One transport evaluation
+  // site, looped: the kernels carry a single copy of the transport code.
+  static constexpr bool HEAVY = true;
+  __device__ static inline void visc_trace(const Params &p, int nb, const double *U, const double *g, const double *n,
+                                           double *fn) {
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) out[eq] = 0.0;
-    if (bc.category != TPSRHS_WALL || p.eq_system == TPSRHS_EULER) return;
-    double nm = 0.0;
+    for (int eq = 0; eq < NEQ; eq++) fn[eq] = 0.0;
+    if (p.eq_system == TPSRHS_EULER) return;
+    int type = -1;
+    double twall = 0.0;
+    if (nb < 0) {
+      const BcDev &bc = p.bc[-nb - 1];
+      if (bc.category != TPSRHS_WALL) return;
+      type = bc.type;
+      twall = bc.data[0];
+    }
+    const int npass = (nb < 0) ? 2 : 1;
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < npass; pass++) {
+      double Us[NEQ];
 #pragma unroll
-    for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
-    nm = sqrt(nm);
-    double fin[NEQ], fw[NEQ];
-    visc_flux_n(p, U, g, n, fin);
-    if (bc.type == TPSRHS_INV) {
-      double Ug[NEQ];
-      bc_ghost(p, bc, U, n, Ug);
-      visc_flux_n(p, Ug, g, n, fw);
-    } else {
-      double Uw[NEQ], nu[DIM];
-#pragma unroll
-      for (int d = 0; d < DIM; d++) nu[d] = n[d] / nm;
-      if (bc.type == TPSRHS_VISC_ADIAB) {
+      for (int eq = 0; eq < NEQ; eq++) Us[eq] = U[eq];
+      bool zs = false, zh = false;
+      if (pass == 1) {  // the wall-side state
         double ke = 0.0;
 #pragma unroll
-        for (int eq = 0; eq < NEQ; eq++) Uw[eq] = U[eq];
+        for (int d = 0; d < NVEL; d++) ke += 0.5 * U[1 + d] * U[1 + d] / U[0];
+        if (type == TPSRHS_INV) {
+          double nm = 0.0, vn = 0.0;
 #pragma unroll
-        for (int d = 0; d < NVEL; d++) {
-          ke += 0.5 * U[1 + d] * U[1 + d] / U[0];
-          Uw[1 + d] = 0.0;
+          for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
+          nm = sqrt(nm);
+#pragma unroll
+          for (int d = 0; d < DIM; d++) vn += (U[1 + d] / U[0]) * (n[d] / nm);
+#pragma unroll
+          for (int d = 0; d < DIM; d++) Us[1 + d] = U[0] * (U[1 + d] / U[0] - 2.0 * vn * (n[d] / nm));
+        } else if (type == TPSRHS_VISC_ADIAB) {
+#pragma unroll
+          for (int d = 0; d < NVEL; d++) Us[1 + d] = 0.0;
+          Us[ITH] = U[ITH] - ke;
+          zs = zh = true;
+        } else {
+          stagnant_with_temp(p, U, twall, Us);
+          zs = true;
         }
-        Uw[ITH] = U[ITH] - ke;
-        bdr_visc_flux(p, Uw, g, nu, true, fw);
-      } else {
-        stagnant_with_temp(p, U, bc.data[0], Uw);
-        bdr_visc_flux(p, Uw, g, nu, false, fw);
       }
+      double f[NEQ];
+      visc_normal_flux(p, Us, g, n, zs, zh, f);
+      if (nb >= 0) {
 #pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) fw[eq] *= nm;
+        for (int eq = 0; eq < NEQ; eq++) fn[eq] = f[eq];
+      } else {
+#pragma unroll
+        for (int eq = 1; eq < NEQ; eq++) fn[eq] -= 0.5 * f[eq];
+      }
     }
-#pragma unroll
-    for (int eq = 1; eq < NEQ; eq++) out[eq] = -0.5 * fw[eq] - 0.5 * fin[eq];
   }
   __device__ static inline void bc_grad_prim(const Params &p, const BcDev &bc, const double *Up, double *UpB) {
 #pragma unroll
@@ -761,10 +817,12 @@ struct PlasmaPhys {
     }
     // temperatures come from the nodal primitives, number densities from the (clamped) state
     const double Th = Up[ITH], Te = TWOT ? Up[ITE] : Up[ITH];
-    Trans t;
-    transport(p, U, Th, Te, g, true, t);
+    struct {
+      double n[NSP], mtfreq[NSP];
+    } t;
+    source_props(p, U, Th, Te, t.n, t.mtfreq);
     const ChemDev &c = *p.chem;
-    double progress[TPSRHS_MAXREACTIONS];
+    double e_loss = 0.0;  // sum of reaction energy x progress rate over the electron-impact reactions
     if (c.num_reactions > 0) {
       const double Thl = fmax(Th, c.min_temperature), Tel = fmax(Te, c.min_temperature);
       double creation[NSP];
@@ -775,11 +833,11 @@ struct PlasmaPhys {
         const double temp = el ? Tel : Thl;
         const double A = c.rate[0 + r * 3], b = c.rate[1 + r * 3], E = c.rate[2 + r * 3];
         double kf;
-        if (c.model[r] == TPSRHS_ARRHENIUS) {
-          kf = A * pow(temp, b) * exp(-E / kRgas / temp);
+        if (c.model[r] == TPSRHS_ARRHENIUS) {  // A T^b exp(-E/RT) in one exponential
+          kf = A * exp(b * log(temp) - E / kRgas / temp);
         } else if (c.model[r] == TPSRHS_HOFFERTLIEN) {
           const double tf = E / kBoltz / temp;
-          kf = A * pow(temp, b) * (tf + 2.0) * exp(-tf);
+          kf = A * (tf + 2.0) * exp(b * log(temp) - tf);
         } else {
           kf = table_eval(c.table[r], temp);
         }
@@ -787,25 +845,23 @@ struct PlasmaPhys {
 #pragma unroll
         for (int sp = 0; sp < NSP; sp++) rate *= ipow(t.n[sp], c.reactant[sp + r * NSP]);
         if (c.detailed_balance[r]) {
-          const double kc = c.keq[0 + r * 3] * pow(temp, c.keq[1 + r * 3]) * exp(-c.keq[2 + r * 3] / temp);
+          const double kc = c.keq[0 + r * 3] * exp(c.keq[1 + r * 3] * log(temp) - c.keq[2 + r * 3] / temp);
           double bwd = 1.0;
 #pragma unroll
           for (int sp = 0; sp < NSP; sp++) bwd *= ipow(t.n[sp], c.product[sp + r * NSP]);
           rate -= bwd / kc;
         }
-        progress[r] = kf * rate;
+        const double progress = kf * rate;
+        if (TWOT && el) e_loss += c.energy[r] * progress;
 #pragma unroll
-        for (int sp = 0; sp < NSP; sp++) creation[sp] += progress[r] * (c.product[sp + r * NSP] - c.reactant[sp + r * NSP]);
+        for (int sp = 0; sp < NSP; sp++) creation[sp] += progress * (c.product[sp + r * NSP] - c.reactant[sp + r * NSP]);
       }
 #pragma unroll
       for (int sp = 0; sp < NACTIVE; sp++) src[NVEL + 2 + sp] += creation[sp] * p.mw[sp];
     }
     if (c.radiation == TPSRHS_NET_EMISSION) src[ITH] += -4.0 * kPi * table_eval(c.nec, Th);
     if (TWOT) {
-      for (int r = 0; r < c.num_reactions; r++) {
-        const bool el = (c.electron_index < 0) ? false : (c.reactant[c.electron_index + r * NSP] != 0);
-        if (el) src[ITE] -= c.energy[r] * progress[r];
-      }
+      src[ITE] -= e_loss;
       // u . grad p_e, src/equation_of_state.cpp:1847-1870
 #pragma unroll
       for (int d = 0; d < DIM; d++) {
