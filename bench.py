@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--order", type=int, default=0, help="override the workload's polynomial order")
     ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="N=1 only: skip the secondary workloads reported under other_workloads")
     args = ap.parse_args()
 
     import numpy as np
@@ -130,84 +132,102 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         halo = HaloExchange(device=torch.device("cuda", local_rank))
 
-    order, physics, make_bcs, make_state, description, sample_case = workload(args.workload)
-    order = args.order or order
-    mesh = meshgen.ogrid_cylinder_slab(args.nr, args.ntheta, args.nz, rank, world)
-    disc = capi.Disc(order, 0, 0, 0, 0)
-    bcs = make_bcs(physics)
-    X = node_coordinates(mesh, order)
-    U = make_state(X, physics)
-    del X
-
-    op = RHSoperator(mesh, disc, physics, bcs, device=local_rank, halo=halo)
-    neq, ndofs = op.num_equation, op.NDofs
-    x = torch.tensor(U.ravel(), dtype=torch.float64, device=op.device)
-    y = torch.empty_like(x)
-    del U
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        op.Mult(x, y)
-    torch.cuda.synchronize()
-    barrier()
-    op.enable_kernel_timing(True)  # hipEvent records on the operator's stream, no synchronisation
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        op.Mult(x, y)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=op.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ktimes = op.kernel_times()  # ms, averaged over the timed Mults
-    op.enable_kernel_timing(False)
-    finite = bool(torch.isfinite(y).all().item())
-
-    if rank == 0:
-        ms_per_step = 1e3 * dt / args.steps
-        evals_per_s = args.steps / dt
-        total_dofs = world * ndofs * neq
-        value = total_dofs * evals_per_s / 1e6
+    def run(wname, steps, warmup):
+        """-> the JSON fields of one workload (rank 0; None elsewhere)"""
+        order, physics, make_bcs, make_state, description, sample_case = workload(wname)
+        order = args.order or order
+        mesh = meshgen.ogrid_cylinder_slab(args.nr, args.ntheta, args.nz, rank, world)
+        disc = capi.Disc(order, 0, 0, 0, 0)
+        bcs = make_bcs(physics)
+        X = node_coordinates(mesh, order)
+        U = make_state(X, physics)
+        del X
+        op = RHSoperator(mesh, disc, physics, bcs, device=local_rank, halo=halo)
+        neq, ndofs = op.num_equation, op.NDofs
+        x = torch.tensor(U.ravel(), dtype=torch.float64, device=op.device)
+        y = torch.empty_like(x)
+        del U
+        for _ in range(warmup):
+            op.Mult(x, y)
+        torch.cuda.synchronize()
+        barrier()
+        op.enable_kernel_timing(True)  # hipEvent records on the operator's stream, no synchronisation
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            op.Mult(x, y)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=op.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        ktimes = op.kernel_times()  # ms, averaged over the timed Mults
+        op.enable_kernel_timing(False)
+        finite = bool(torch.isfinite(y).all().item())
+        op.close()
+        del x, y
+        if rank != 0:
+            return None
+        ms_per_step = 1e3 * dt / steps
+        evals_per_s = steps / dt
+        value = world * ndofs * neq * evals_per_s / 1e6
         alg = algorithmic_bytes_per_node(neq, mesh.dim, order)
         dom = max((k for k in ktimes if k in alg), key=lambda k: ktimes[k])
         achieved = alg[dom] * ndofs / (ktimes[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("nodes") == ndofs and dom in tj.get("bytes_per_launch", {}):
-                    traffic = tj["bytes_per_launch"][dom]
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "DG RHS evals/sec (MDOF/s) for 3D p=3 reacting cyl at 1/2/4/8 MI355X",
-            "value": value, "unit": "MDOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} hexes per GPU, "
+        traffic = valu = None
+        try:  # written by tools/profile_summary.py from the rocprofv3 --pmc passes of this workload
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(wname, {})
+            if tj.get("nodes") == ndofs and dom in tj.get("bytes_per_launch", {}):
+                traffic = tj["bytes_per_launch"][dom]
+        except Exception:
+            traffic = None
+        res = {
+            "value": value, "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
+            "config": {"workload": f"{wname}: cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} hexes per GPU, "
                                    f"p={order}, GL basis + GL rule, {description}",
                        "elements_per_gpu": mesh.num_elements, "nodes_per_gpu": ndofs, "num_equation": neq,
                        "partition": "spanwise slabs, RCCL send/recv of face traces" if world > 1 else "single GPU"},
-            "rhs_evals_per_s": evals_per_s,
-            "kernel_ms": ktimes,
-            "finite": finite,
+            "rhs_evals_per_s": evals_per_s, "kernel_ms": ktimes, "finite": finite,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_node": alg[dom],
                          "mult_algorithmic_GBps": alg["mult"] * ndofs / (ms_per_step * 1e-3) / 1e9},
         }
+        return res, (neq, order, sample_case)
+
+    r = run(args.workload, args.steps, args.warmup)
+    others = {}
+    if world == 1 and not args.no_other_workloads:
+        for wname in ("argon_p3", "cfg2", "cfg3"):
+            if wname != args.workload:
+                o, _ = run(wname, max(args.steps // 2, 5), min(args.warmup, 3))
+                others[wname] = {k: o[k] for k in ("value", "ms_per_step", "rhs_evals_per_s", "kernel_ms", "finite")}
+                others[wname]["unit"] = "MDOF/s"
+                others[wname]["workload"] = o["config"]["workload"]
+                others[wname]["roofline_frac"] = o["roofline"]["frac"]
+                others[wname]["roofline_kernel"] = o["roofline"]["kernel"]
+    if rank == 0:
+        res, (neq, order, sample_case) = r
+        out = {
+            "metric": "DG RHS evals/sec (MDOF/s) for 3D p=3 reacting cyl at 1/2/4/8 MI355X",
+            "value": res["value"], "unit": "MDOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic", "config": res["config"],
+            "rhs_evals_per_s": res["rhs_evals_per_s"], "kernel_ms": res["kernel_ms"], "finite": res["finite"],
+            "roofline": res["roofline"],
+        }
+        if others:
+            out["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(neq, order, sample_case)
         print(json.dumps(out))
-    op.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,85 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties.
+
+The oracle needs minutes for 50 176 hexes, so the full-size runs are pinned to it indirectly:
+  * spanwise invariance -- the O-grid is periodic and extruded in z; for a state that does not depend
+    on z every one of the 16 element layers must reproduce, node for node, the result of a 3-layer
+    mesh of the same cross-section, and THAT mesh is compared with the oracle;
+  * free-stream preservation -- on a warped periodic box of the same node count a uniform state has a
+    zero residual (the discrete metric identities hold for trilinear hexes at these quadrature orders),
+    which exercises every face record, orientation code and geometry recomputation at scale.
+"""
+import numpy as np
+import pytest
+
+from parity_util import RHS_RTOL, hip_mult, oracle_mult, rel_maxnorm
+from tps_amd import capi, cases, meshgen
+from tps_amd.rhs_operator import node_coordinates
+
+pytestmark = pytest.mark.gpu
+
+NR, NTHETA, NZ = 28, 112, 16  # the mesh of BASELINE.json configs[1] and [2]
+
+
+def _extruded_case(kind, order, nz):
+    mesh = meshgen.ogrid_cylinder(NR, NTHETA, nz, span=2.0 * nz / NZ)
+    disc = capi.Disc(order, 0, 0, 0, 0)
+    X = node_coordinates(mesh, order)
+    X[2] = 0.0  # the state is a function of (x, y) only
+    if kind == "dry_air":
+        ph = capi.dry_air_physics(capi.NS)
+        bcs = cases.cylinder_bcs(capi.VISC_ISOTH, 300.0)
+        U = cases.dry_air_state(X, seed=12345)
+    else:
+        ph = capi.argon_ternary_physics(capi.NS, False, capi.ARGON_MINIMAL, "arrhenius")
+        bcs = cases.plasma_cylinder_bcs(ph, capi.VISC_ISOTH, 3000.0)
+        U = cases.plasma_state(X, ph, nvel=3, seed=12345, amp=0.05)
+    return mesh, disc, ph, bcs, U
+
+
+@pytest.mark.parametrize("kind,order", [("dry_air", 3), ("argon", 3), ("argon", 2)])
+def test_full_size_layers_reproduce_the_oracle_checked_slab(kind, order):
+    """cfg2 (dry air p=3), the headline workload (argon p=3) and cfg3 (argon p=2) at 50 176 hexes."""
+    mesh, disc, ph, bcs, U = _extruded_case(kind, order, NZ)
+    full = hip_mult(mesh, disc, ph, bcs, U, want_grad=False)
+    smesh, sdisc, sph, sbcs, sU = _extruded_case(kind, order, 3)
+    small = hip_mult(smesh, sdisc, sph, sbcs, sU, want_grad=False)
+    ref = oracle_mult(smesh, sdisc, sph, sbcs, sU)
+    # the spanwise momentum residual vanishes by symmetry up to the rounding of the pressure terms, so
+    # the three momentum rows are measured against their common scale
+    scale = np.abs(ref["y"]).max(axis=1, keepdims=True)
+    scale[1:4] = scale[1:4].max()
+    err = (np.abs(small["y"] - ref["y"]) / scale).max(axis=1)
+    print("3-layer slab vs oracle:", err)
+    assert err.max() < RHS_RTOL
+    per_layer = NR * NTHETA * (order + 1) ** 3
+    assert (np.abs(sU[:, :per_layer] - U[:, :per_layer]) <= 1e-13 * np.abs(U).max(axis=1, keepdims=True)).all()
+    y0 = small["y"][:, :per_layer]
+    for k in range(NZ):
+        yk = full["y"][:, k * per_layer:(k + 1) * per_layer]
+        # same arithmetic in the same order; only the vertex z-coordinates differ by the layer offset
+        assert (np.abs(yk - y0) <= RHS_RTOL * scale).all(), k
+    assert abs(full["max_char_speed"] - ref["max_char_speed"]) < 1e-12 * ref["max_char_speed"]
+
+
+@pytest.mark.parametrize("kind", ["dry_air", "argon"])
+def test_free_stream_preservation_at_full_size(kind):
+    n = 37  # 37^3 = 50 653 hexes, p = 3: 3.24 M nodes
+    mesh = meshgen.scramble_orientations(meshgen.box_hex(n, n, n, lengths=(1.0, 0.8, 1.2), warp=0.08), 3)
+    disc = capi.Disc(3, 0, 0, 0, 0)
+    X = node_coordinates(mesh, 3)
+    if kind == "dry_air":
+        ph = capi.dry_air_physics(capi.NS)
+        U = cases.dry_air_state(X, seed=1, amp=0.0)
+    else:
+        ph = capi.argon_ternary_physics(capi.NS, False, capi.ARGON_MINIMAL, reactions=None)  # no sources
+        U = cases.plasma_state(X, ph, nvel=3, seed=1, amp=0.0)
+    got = hip_mult(mesh, disc, ph, [], U, want_grad=True)
+    assert np.isfinite(got["y"]).all()
+    # the residual of a uniform state is rounding noise of the flux divergence: |F| / h * eps
+    h = 1.0 / n / 4
+    flux_scale = np.abs(U).max(axis=1) * 20.0 + 101300.0
+    bound = 1e-12 * flux_scale / h
+    resid = np.abs(got["y"]).max(axis=1)
+    print("residual of the uniform state per equation:", resid, "bound", bound)
+    assert (resid <= bound).all()
+    assert np.abs(got["gradUp"]).max() <= 1e-10 * np.abs(got["Up"]).max() / h
