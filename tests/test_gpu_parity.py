@@ -74,6 +74,14 @@ def _boost_transport(ph, factor=300.0):
     gt.multiply = 1
     for k in range(4):
         gt.flux_trns_multiplier[k] = factor
+    if gt.third_order_k_electron:
+        # Devoto's third-order k_e is ill-conditioned in double precision: the e-Ar collision integrals are
+        # degree-8 polynomials in log(T_e) whose terms cancel to 1 part in 2e4, and L11 - L12^2/L22 loses
+        # another factor ~25, so ONE ulp of difference in log(T_e) (device vs glibc) moves k_e by ~4e-10
+        # (measured).  Where electron conduction dominates the residual, agreement beyond that is luck for
+        # any two libm's; the boost therefore leaves k_e alone (it stays in the comparison at its physical
+        # weight, and boosted in the non-third-order and constant-transport cases).
+        gt.flux_trns_multiplier[3] = 1.0
     gt.diff_mult, gt.mobil_mult, gt.spcs_trns_multiplier[0] = factor, factor, 3.0
     ct = ph.constant_transport
     ct.viscosity *= factor
@@ -114,3 +122,22 @@ def test_plasma_use_bc_in_grad():
     c.disc.use_bc_in_grad = 1
     _boost_transport(c.physics)
     _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=8, amp=0.01), tol=_tol(0.01))
+
+
+# ---- axisymmetric formulation (dim 2, nvel 3; r-weighted mass, volume and face terms, 1/r sources) ----
+@pytest.mark.parametrize("order,two_t,transport,wall,r_in,warp", [
+    (3, True, capi.CONSTANT, capi.VISC_ISOTH, 0.0, 0.0),       # the physics of cfg5, axis on the boundary
+    (2, True, capi.ARGON_MINIMAL, capi.VISC_ADIAB, 0.01, 0.06),
+    (1, False, capi.ARGON_MINIMAL, capi.INV, 0.02, 0.06),
+    (3, False, capi.CONSTANT, capi.VISC_ISOTH, 0.01, 0.05),
+])
+def test_plasma_axisymmetric(order, two_t, transport, wall, r_in, warp):
+    c = cases.argon_axisym(6, 9, order, two_t, transport, "arrhenius", True, wall, r_in=r_in, warp=warp)
+    _boost_transport(c.physics, 30.0)
+    amp = 0.005 if order == 1 else 0.01
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=5 + order, amp=amp), tol=_tol(amp))
+
+
+def test_plasma_axisymmetric_euler():
+    c = cases.argon_axisym(6, 9, 2, True, capi.CONSTANT, None, False, capi.INV, r_in=0.0, eq_system=capi.EULER)
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=9, amp=0.01), tol=_tol(0.01))

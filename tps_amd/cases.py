@@ -27,7 +27,9 @@ class Case:
     def state(self, seed=12345, amp=0.05, coords=None):
         X = node_coordinates(self.mesh, self.disc.order) if coords is None else coords
         if self.physics.working_fluid == capi.USER_DEFINED:
-            return plasma_state(X, self.physics, nvel=3 if self.disc.axisymmetric else X.shape[0], seed=seed, amp=amp)
+            if self.disc.axisymmetric:
+                return plasma_state(X, self.physics, nvel=3, seed=seed, amp=amp, vel0=(1.0, 20.0, 3.0))
+            return plasma_state(X, self.physics, nvel=X.shape[0], seed=seed, amp=amp)
         return dry_air_state(X, seed=seed, amp=amp)
 
 
@@ -170,6 +172,21 @@ def argon_cyl3d(nr, ntheta, nz, order, two_temperature=False, transport=capi.ARG
                 plasma_cylinder_bcs(ph, wall_type), "O-grid cylinder, argon ternary plasma")
 
 
+def argon_axisym(nr, nz, order, two_temperature=True, transport=capi.CONSTANT, reactions="arrhenius", radiation=True,
+                 wall_type=capi.VISC_ISOTH, r_in=0.0, r_out=0.05, length=0.25, warp=0.0, eq_system=capi.NS, name=None):
+    """Axisymmetric (r, z) tube in an argon plasma: patch 1 inlet at z = 0 (axial flow with swirl), 2 outlet at
+    z = L, 3 outer wall, 4 the axis / inner boundary (inviscid wall).  The shape of BASELINE.json configs[4]."""
+    attrs = {(0, 0): 4, (0, 1): 3, (1, 0): 1, (1, 1): 2}
+    mesh = meshgen.box_quad(nr, nz, lengths=(r_out - r_in, length), periodic=(False, False), bdr_attr=attrs, warp=warp,
+                            origin=(r_in, 0.0))
+    ph = capi.argon_ternary_physics(eq_system, two_temperature, transport, reactions, radiation=radiation)
+    inlet = argon_inlet_state(ph, 3, vel0=(0.0, 20.0, 2.0))
+    bcs = [capi.make_bc(1, capi.INLET, capi.SUB_DENS_VEL, inlet), capi.make_bc(2, capi.OUTLET, capi.SUB_P, [101300.0]),
+           capi.make_bc(3, capi.WALL, wall_type, [3000.0]), capi.make_bc(4, capi.WALL, capi.INV)]
+    return Case(name or f"argon_axisym_{nr}x{nz}_p{order}", mesh, capi.Disc(order, 0, 0, 1, 0), ph, bcs,
+                "axisymmetric argon ternary plasma")
+
+
 def cylinder_bcs(wall_type=capi.VISC_ISOTH, t_wall=300.0, dim=3):
     inlet = capi.make_bc(1, capi.INLET, capi.SUB_DENS_VEL, [1.2, 20.0, 0.0, 0.0])
     outlet = capi.make_bc(2, capi.OUTLET, capi.SUB_P, [101300.0])
@@ -194,6 +211,8 @@ def config(i: int) -> Case:
         return cyl3d(28, 112, 16, 3, capi.NS, name="cfg2_cyl3d_ns_p3")
     if i == 3:
         return argon_cyl3d(28, 112, 16, 2, name="cfg3_argon_minimal_p2")
+    if i == 5:
+        return argon_axisym(400, 500, 3, name="cfg5_plasma_axisym_p3")
     if i == 4:
         return cyl3d(56, 224, 32, 3, capi.NS, name="cfg4_cyl3d_ns_p3_8gpu")
     raise NotImplementedError(f"configuration {i} is not built yet")

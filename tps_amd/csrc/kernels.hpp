@@ -172,6 +172,17 @@ __device__ inline void jacobian(const double *V, const double *xi, double *J) {
     }
   }
 }
+// physical coordinates of reference point xi (2-D; used for the radius of the axisymmetric formulation)
+template <int DIM>
+__device__ inline void position(const double *V, const double *xi, double *X) {
+  static_assert(DIM == 2, "only the axisymmetric (2-D) path needs nodal coordinates");
+  const double x = xi[0], y = xi[1];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const double v00 = V[0 * 2 + i], v10 = V[1 * 2 + i], v01 = V[2 * 2 + i], v11 = V[3 * 2 + i];
+    X[i] = (v00 * (1.0 - x) + v10 * x) * (1.0 - y) + (v01 * (1.0 - x) + v11 * x) * y;
+  }
+}
 // adjugate A[m + i*DIM] = det(J) * dxi_m/dx_i and determinant
 template <int DIM>
 __device__ inline double adjugate(const double *J, double *A) {
@@ -683,7 +694,7 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const type
     double n[DIM], wq, Xq[DIM];
     face_geometry_rt<C>(d, &sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
     if constexpr (PH::HEAVY) {
-      PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, fn);
+      PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, PH::AXISYM ? Xq[0] : -1.0, fn);
     } else {
       if (nb >= 0) {
         PH::visc_flux_n(prm, v[rd], v[rd] + NEQ, n, fn);
@@ -898,6 +909,7 @@ __device__ inline void face_flux_dir(const MeshDev &m, const typename PH::Params
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] += tb.own[rd][eq];
     }
+    if (PH::AXISYM) wq *= Xq[0];  // r-weighted face integrals (src/face_integrator.cpp:338, BCintegrator.cpp:427)
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] *= wq;
   }
@@ -974,6 +986,14 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
   for (int eq = 0; eq < NEQ; eq++) src[eq] = 0.0;
   if (node_on) {
     double F[NEQ * DIM];
+    double radius = 1.0;  // axisymmetric: r of the node (x-coordinate), weights the mass and the volume term
+    if constexpr (PH::AXISYM) {
+      double xi[DIM], Xn[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) xi[d] = tab.x[idx[d]];
+      position<DIM>(&sV[le_n * C::NV * DIM], xi, Xn);
+      radius = Xn[0];
+    }
     {
       double uc[NEQ];
 #pragma unroll
@@ -985,12 +1005,18 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
         double up[NEQ];
         PH::prim(prm, u, up);
         PH::source(prm, u, up, gr, src);
+        if constexpr (PH::AXISYM) PH::axisym_source(prm, u, up, gr, radius, src);
       }
       if (TPSRHS_ABLATE & 2) {
 #pragma unroll
         for (int k = 0; k < NEQ * DIM; k++) F[k] = uc[k % NEQ] + gr[k];
       } else {
-        PH::total_flux(prm, uc, st, gr, F);
+        if constexpr (PH::AXISYM)
+          PH::total_flux(prm, uc, st, gr, radius, F);
+        else if constexpr (PH::HEAVY)
+          PH::total_flux(prm, uc, st, gr, -1.0, F);
+        else
+          PH::total_flux(prm, uc, st, gr, F);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1005,6 +1031,10 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
     jacobian<DIM>(&sV[le_n * C::NV * DIM], xi, J);
     const double det = adjugate<DIM>(J, A);
     inv_mass = iwn * fast_rcp(det);
+    if (PH::AXISYM) {  // Me_inv_rad and the r-weighted DomainIntegrator (src/rhs_operator.cpp:198-201,
+      inv_mass *= fast_rcp(radius);  // src/domain_integrator.cpp:78-81)
+      wn *= radius;
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++)

@@ -68,6 +68,7 @@ struct DryAirPhys {
   static constexpr int NEQ = DIM_ + 2;
   static constexpr int NACTIVE = 0;
   static constexpr bool HAS_SOURCE = false;
+  static constexpr bool AXISYM = false;
   static constexpr bool HEAVY = false;  // light point physics: inlined at every face pass
   static constexpr int MINW_GRAD = TPSRHS_MINW_GRAD, MINW_FLUX = TPSRHS_MINW_FLUX;  // launch-bound waves per SIMD
   typedef DryAirParams Params;

@@ -154,6 +154,7 @@ struct PlasmaPhys {
   static constexpr int ITH = NVEL_ + 1, ITE = NEQ - 1;
   static constexpr bool HAS_SOURCE = true;
   static constexpr bool HAS_FLUX_DOT = false;
+  static constexpr bool AXISYM = NVEL_ > DIM_;  // dim 2 with (r, z, theta) velocity components
   static constexpr int MINW_GRAD = 2, MINW_FLUX = 2;
   typedef PlasmaParams<NSP_> Params;
   struct Transport {};
@@ -533,7 +534,7 @@ struct PlasmaPhys {
 
   // ComputeViscousFluxes, src/fluxes.cpp:178-335 (3-D / planar 2-D part); Fv[eq + d*NEQ]
   __device__ static inline void visc_flux(const Params &p, const double *U, const State &s, const double *g,
-                                          double *Fv) {
+                                          double radius, double *Fv) {
 #pragma unroll
     for (int i = 0; i < NEQ * DIM; i++) Fv[i] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
@@ -556,6 +557,14 @@ struct PlasmaPhys {
     double divV = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
+    double tau_t[DIM] = {};  // axisymmetric: tau_{theta r}, tau_{theta z} (src/fluxes.cpp:300-313)
+    if (AXISYM) {
+      if (radius > 0) divV += s.vel[0] / radius;
+      double ttr = g[3 + 0 * NEQ];
+      if (radius > 0) ttr -= s.vel[2] / radius;
+      tau_t[0] = ttr * t.visc;
+      tau_t[1] = t.visc * g[3 + 1 * NEQ];
+    }
 #pragma unroll
     for (int i = 0; i < DIM; i++) {
       double vt = 0.0;
@@ -566,6 +575,10 @@ struct PlasmaPhys {
         Fv[(1 + j) + i * NEQ] = st;
         vt += st * s.vel[j];
       }
+      if (AXISYM) {
+        Fv[(1 + 2) + i * NEQ] = tau_t[i];
+        vt += s.vel[2] * tau_t[i];
+      }
       double e = vt + k * g[ITH + i * NEQ];
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) e -= h[sp] * t.V[sp + i * NSP];
@@ -575,9 +588,9 @@ struct PlasmaPhys {
     }
   }
   __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const double *g,
-                                           double *F) {
+                                           double radius, double *F) {
     double Fv[NEQ * DIM];
-    visc_flux(p, U, s, g, Fv);
+    visc_flux(p, U, s, g, radius, Fv);
     const double H = U[ITH] + s.p;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
@@ -596,7 +609,7 @@ struct PlasmaPhys {
   // (`zero_species`) and zero heat fluxes (`zero_heat`).  The reference evaluates the boundary variant
   // with the unit normal and rescales by |n|; the flux is linear in n, so n is used directly.
   __device__ static inline void visc_normal_flux(const Params &p, const double *U, const double *g, const double *n,
-                                                 bool zero_species, bool zero_heat, double *Fn) {
+                                                 double radius, bool zero_species, bool zero_heat, double *Fn) {
     const State s = make_state(p, U);
     Trans t;
     transport(p, U, s.Th, s.Te, g, !zero_species, t);
@@ -613,6 +626,7 @@ struct PlasmaPhys {
     double divV = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
+    if (AXISYM && radius > 0) divV += s.vel[0] / radius;
     double e = 0.0;
     Fn[0] = 0.0;
 #pragma unroll
@@ -626,6 +640,13 @@ struct PlasmaPhys {
       }
       Fn[1 + i] = sn;
       e += sn * s.vel[i];
+    }
+    if (AXISYM) {  // tau_{theta r} n_r + tau_{theta z} n_z, src/fluxes.cpp:300-313,457-466
+      double ttr = g[3 + 0 * NEQ];
+      if (radius > 0) ttr -= s.vel[2] / radius;
+      const double tn = t.visc * (ttr * n[0] + g[3 + 1 * NEQ] * n[1]);
+      Fn[1 + 2] = tn;
+      e += tn * s.vel[2];
     }
     double qh = 0.0, qe = 0.0;  // k grad T . n
     if (!zero_heat) {
@@ -739,7 +760,7 @@ struct PlasmaPhys {
   // site, looped: the kernels carry a single copy of the transport code.
   static constexpr bool HEAVY = true;
   __device__ static inline void visc_trace(const Params &p, int nb, const double *U, const double *g, const double *n,
-                                           double *fn) {
+                                           double radius, double *fn) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) fn[eq] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
@@ -782,7 +803,7 @@ struct PlasmaPhys {
         }
       }
       double f[NEQ];
-      visc_normal_flux(p, Us, g, n, zs, zh, f);
+      visc_normal_flux(p, Us, g, n, radius, zs, zh, f);
       if (nb >= 0) {
 #pragma unroll
         for (int eq = 0; eq < NEQ; eq++) fn[eq] = f[eq];
@@ -800,6 +821,81 @@ struct PlasmaPhys {
       for (int d = 0; d < NVEL; d++) UpB[1 + d] = 0.0;
       UpB[ITH] = bc.data[0];
     }
+  }
+
+  // GetViscosities of the selected transport (src/transport_properties.cpp:440-449,
+  // src/gas_transport.cpp:775-822): shear and bulk viscosity only
+  __device__ static inline void viscosities(const Params &p, const double *U, double Th, double Te, double &visc,
+                                            double &bulk) {
+    if (TRANSPORT == TRANSPORT_CONSTANT) {
+      visc = p.c_visc;
+      bulk = p.c_bulk;
+      return;
+    }
+    const Species q = species(p, U);
+    const double vf = 5. / 16. * sqrt(kPi * kBoltz);
+    const Debye d = debye(q.n, Th, Te);
+    const double sv_ion = vf * sqrt(p.mw[I_ION] / kAvogadro * Th) / (coll::rep22(d.h) * d.circle);
+    const double sv_n = vf * sqrt(p.mw[I_N] / kAvogadro * Th) / coll::ArAr22(Th);
+    visc = q.X[I_ION] * sv_ion + q.X[I_N] * sv_n;
+    bulk = 0.0;
+    if (p.multiply) {
+      visc *= p.mult_flux[0];
+      bulk *= p.mult_flux[1];
+    }
+  }
+  // AxisymmetricSource::updateTerms at one node (src/forcing_terms.cpp:293-380): the 1/r terms of the
+  // radial and azimuthal momentum equations
+  __device__ static inline void axisym_source(const Params &p, const double *Uin, const double *Upin, const double *g,
+                                              double radius, double *src) {
+    double U[NEQ], Up[NEQ];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) {
+      U[eq] = Uin[eq];
+      Up[eq] = Upin[eq];
+    }
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) {
+      const int eq = 3 + 2 + sp;  // src/forcing_terms.cpp:314 (nvel = 3 here)
+      if (eq < NEQ) {
+        U[eq] = fmax(U[eq], 0.0);
+        Up[eq] = fmax(Up[eq], 0.0);
+      }
+    }
+    const double rho = Up[0], ur = Up[1], ut = Up[3];
+    // ComputePressureFromPrimitives, src/equation_of_state.cpp:988-1010
+    double ne = 0.0, rhoB = Up[0], nh = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) {
+      const double nsp = Up[NVEL + 2 + sp];
+      if (AMBI) ne += p.charge[sp] * nsp;
+      rhoB -= p.mw[sp] * nsp;
+      if (sp != IE) nh += nsp;
+    }
+    if (AMBI) {
+      ne = fmax(ne, 0.0);
+      rhoB -= ne * p.mw[IE];
+    } else {
+      ne = Up[NVEL + 2 + IE];
+    }
+    nh += rhoB / p.mw[IB];
+    const double Th = Up[ITH], Te = TWOT ? Up[ITE] : Up[ITH];
+    const double pres = kRgas * (nh * Th + ne * Te);
+    double tau_tt = 0.0, tau_tr = 0.0;
+    if (p.eq_system != TPSRHS_EULER) {
+      double visc, bulkv;
+      viscosities(p, U, Th, Te, visc, bulkv);
+      const double bulk = bulkv - 2. / 3. * visc;
+      double divV = g[1 + 0 * NEQ] + g[2 + 1 * NEQ];
+      if (radius > 0) divV += ur / radius;
+      tau_tt = (radius > 0) ? 2.0 * ur / radius * visc : 0.0;
+      tau_tt += bulk * divV;
+      tau_tr = g[3 + 0 * NEQ];
+      if (radius > 0) tau_tr -= ut / radius;
+      tau_tr *= visc;
+    }
+    src[1] += (pres + rho * ut * ut - tau_tt) / radius;
+    src[3] += (-rho * ur * ut + tau_tr) / radius;
   }
 
   // ---- SourceTerm::updateTerms at one node, src/source_term.cpp:107-251 ------------------------

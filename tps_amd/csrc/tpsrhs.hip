@@ -13,6 +13,7 @@
 // kernel families instantiated in their own translation units
 void pick_plasma3d(tpsrhs_operator *op, bool two_temperature, int transport);
 void pick_plasma2d(tpsrhs_operator *op, bool two_temperature, int transport);
+void pick_plasma_axisym(tpsrhs_operator *op, bool two_temperature, int transport);
 
 static thread_local std::string g_last_error;
 
@@ -135,8 +136,9 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   if (disc->basis_type != TPSRHS_BASIS_GAUSS_LEGENDRE || disc->int_rule_type != 0)
     throw Unsupported(
         "only the collocated Gauss-Legendre basis + Gauss-Legendre rule (basisType 0, integrationRule 0) is built");
-  if (disc->axisymmetric) throw Unsupported("axisymmetric formulation is not built yet");
   const bool plasma = phys->working_fluid == TPSRHS_USER_DEFINED;
+  if (disc->axisymmetric && (!plasma || mesh->dim != 2))
+    throw Unsupported("the axisymmetric formulation is built for USER_DEFINED (plasma) fluids on 2-D meshes");
   if (phys->working_fluid != TPSRHS_DRY_AIR && !plasma) throw Unsupported("WorkingFluid::LTE_FLUID is out of scope");
   if (phys->eq_system != TPSRHS_EULER && phys->eq_system != TPSRHS_NS) throw Unsupported("NS_PASSIVE is out of scope");
   if (num_bcs > (plasma ? PLASMA_MAXBC : MAXBC)) throw Unsupported("too many boundary conditions");
@@ -150,7 +152,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   }
   op->dim = mesh->dim;
   op->order = disc->order;
-  op->nvel = op->dim;
+  op->nvel = disc->axisymmetric ? 3 : op->dim;
   op->neq = op->dim + 2;
   if (plasma) {
     const tpsrhs_perfect_mixture &mx = phys->mixture;
@@ -191,6 +193,8 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     const int tr = (phys->transport_model == TPSRHS_CONSTANT) ? TRANSPORT_CONSTANT : TRANSPORT_ARGON_MINIMAL;
     if (op->dim == 3)
       pick_plasma3d(op, phys->mixture.two_temperature != 0, tr);
+    else if (disc->axisymmetric)
+      pick_plasma_axisym(op, phys->mixture.two_temperature != 0, tr);
     else
       pick_plasma2d(op, phys->mixture.two_temperature != 0, tr);
   } else {
