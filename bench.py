@@ -10,9 +10,11 @@ configs[1]/[2] per GPU.  Workloads:
                   perfect-gas Navier-Stokes, 5 equations, 3 211 264 nodes
   cfg3            configs[2]: reacting argon ternary plasma (ambipolar, single temperature, argon-minimal
                   transport, 2 Arrhenius reactions) at p=2, 6 equations
+  cfg5            configs[4] on one GPU: axisymmetric 400x500 quads, p=3, two-temperature argon plasma with
+                  constant transport, reactions and the NEC radiation source, 7 equations
   argon_p3        the metric's "3D p=3 reacting cyl" read literally: the physics of configs[2] at the
                   order of configs[1] (no entry of `configs` is both)
-At N = 1 the JSON line also carries the two workloads that were not selected, under `other_workloads`.
+At N = 1 the JSON line also carries the workloads that were not selected, under `other_workloads`.
 N > 1 (launched by ``torch.distributed.run``, one rank per GPU): every rank owns one such block --
 spanwise slabs of an N-times longer cylinder -- and exchanges the traces of its two shared planes
 with RCCL send/recv (weak scaling, no collective on the data path).
@@ -66,6 +68,14 @@ def workload(name):
                 "collision-integral transport with 3rd-order electron conductivity, 2 Arrhenius reactions, inlet "
                 f"SUB_DENS_VEL / outlet SUB_P / isothermal wall ({what})",
                 lambda order: cases.argon_cyl3d(7, 28, 4, order))
+    if name == "cfg5":
+        ph = capi.argon_ternary_physics(capi.NS, True, capi.CONSTANT, "arrhenius", radiation=True)
+        return (3, ph, lambda p: cases.argon_axisym(2, 2, 3).bcs,
+                lambda X, p: cases.plasma_state(X, p, nvel=3, seed=12345, amp=0.05, vel0=(1.0, 20.0, 3.0)),
+                "AXISYMMETRIC (r, z) 400x500 quads, two-temperature argon ternary plasma, constant transport, "
+                "2 Arrhenius reactions, NEC radiation table, inlet / outlet / isothermal wall / axis "
+                "(BASELINE.json configs[4] on one GPU)",
+                lambda order: cases.argon_axisym(40, 50, order))
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -106,7 +116,7 @@ def main():
     ap.add_argument("--ntheta", type=int, default=112)
     ap.add_argument("--nz", type=int, default=16)
     ap.add_argument("--order", type=int, default=0, help="override the workload's polynomial order")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "argon_p3"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "argon_p3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="N=1 only: skip the secondary workloads reported under other_workloads")
@@ -142,8 +152,14 @@ def main():
         """-> the JSON fields of one workload (rank 0; None elsewhere)"""
         order, physics, make_bcs, make_state, description, sample_case = workload(wname)
         order = args.order or order
-        mesh = meshgen.ogrid_cylinder_slab(args.nr, args.ntheta, args.nz, rank, world)
-        disc = capi.Disc(order, 0, 0, 0, 0)
+        axisym = wname == "cfg5"
+        if axisym:
+            if world > 1:
+                raise SystemExit("cfg5 is benchmarked on one GPU (no partitioned generator for the (r, z) block yet)")
+            mesh = cases.argon_axisym(400, 500, order).mesh
+        else:
+            mesh = meshgen.ogrid_cylinder_slab(args.nr, args.ntheta, args.nz, rank, world)
+        disc = capi.Disc(order, 0, 0, 1 if axisym else 0, 0)
         bcs = make_bcs(physics)
         X = node_coordinates(mesh, order)
         U = make_state(X, physics)
@@ -192,8 +208,9 @@ def main():
             traffic = None
         res = {
             "value": value, "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
-            "config": {"workload": f"{wname}: cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} hexes per GPU, "
-                                   f"p={order}, GL basis + GL rule, {description}",
+            "config": {"workload": (f"{wname}: " + ("" if axisym else f"cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} "
+                                                            "hexes per GPU, ") +
+                                    f"p={order}, GL basis + GL rule, {description}"),
                        "elements_per_gpu": mesh.num_elements, "nodes_per_gpu": ndofs, "num_equation": neq,
                        "partition": "spanwise slabs, RCCL send/recv of face traces" if world > 1 else "single GPU"},
             "rhs_evals_per_s": evals_per_s, "kernel_ms": ktimes, "finite": finite,
@@ -207,7 +224,7 @@ def main():
     r = run(args.workload, args.steps, args.warmup)
     others = {}
     if world == 1 and not args.no_other_workloads:
-        for wname in ("argon_p3", "cfg2", "cfg3"):
+        for wname in ("cfg2", "argon_p3", "cfg3", "cfg5"):
             if wname != args.workload:
                 o, _ = run(wname, max(args.steps // 2, 5), min(args.warmup, 3))
                 others[wname] = {k: o[k] for k in ("value", "ms_per_step", "rhs_evals_per_s", "kernel_ms", "finite")}
