@@ -102,6 +102,8 @@ struct Tab {
 };
 
 struct MeshDev {
+  const int *blocks;           // workgroup -> block of EPB consecutive elements (NULL: identity); lets one
+                               // launch cover the interior and another the blocks that touch shared faces
   int ne;
   int64_t ndofs;
   const double *verts;         // [ne][NV][DIM] lexicographic corners
@@ -510,7 +512,8 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Par
   __shared__ double sF[2 * NEQ * C::NODES];
   __shared__ double sT[2 * NEQ * C::TN];
   const int tid = threadIdx.x;
-  const int e0 = blockIdx.x * C::EPB;
+  const int bid = m.blocks ? m.blocks[blockIdx.x] : static_cast<int>(blockIdx.x);
+  const int e0 = bid * C::EPB;
   if (tid < C::NODES) {
     const int le = tid / C::NPE, nd = tid - le * C::NPE;
     const int e = e0 + le;
@@ -733,7 +736,8 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
   double *sY = pool + L::O_Y;
 
   const int tid = threadIdx.x;
-  const int e0 = blockIdx.x * C::EPB;
+  const int bid = m.blocks ? m.blocks[blockIdx.x] : static_cast<int>(blockIdx.x);
+  const int e0 = bid * C::EPB;
   __shared__ int2 sFI[C::EPB * C::NFACES];
   load_face_info<C>(sFI, m, e0);
   load_tables<C>(tab, ct);
@@ -951,7 +955,8 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
   double *sX = sGf, *sY = sGf + L::X;
 
   const int tid = threadIdx.x;
-  const int e0 = blockIdx.x * C::EPB;
+  const int bid = m.blocks ? m.blocks[blockIdx.x] : static_cast<int>(blockIdx.x);
+  const int e0 = bid * C::EPB;
   __shared__ int2 sFI[C::EPB * C::NFACES];
   load_face_info<C>(sFI, m, e0);
   load_tables<C>(tab, ct);
@@ -1054,7 +1059,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
     if (C::BLOCK == 64) {
-      if (tid == 0) block_speed[blockIdx.x] = v;
+      if (tid == 0) block_speed[bid] = v;
     } else {
       __shared__ double swave[C::BLOCK / 64];
       if ((tid & 63) == 0) swave[tid >> 6] = v;
@@ -1063,7 +1068,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
         double b = swave[0];
 #pragma unroll
         for (int w = 1; w < C::BLOCK / 64; w++) b = fmax(b, swave[w]);
-        block_speed[blockIdx.x] = b;
+        block_speed[bid] = b;
       }
     }
   }

@@ -75,6 +75,10 @@ struct tpsrhs_operator {
   // halo
   tpsrhs_halo_fn halo = nullptr;
   void *halo_ctx = nullptr;
+  hipStream_t comm_stream = nullptr;  // second stream: pack + exchange overlap the interior blocks
+  hipEvent_t ev_halo[4] = {};         // traces of the halo blocks ready / TA received / TB ready / TB received
+  int *d_blocks_halo = nullptr, *d_blocks_interior = nullptr;
+  int n_blocks_halo = 0, n_blocks_interior = 0;
   int32_t *d_shared_slot = nullptr;
   uint8_t *d_shared_orient = nullptr;
   double *d_send = nullptr;
@@ -91,6 +95,7 @@ struct tpsrhs_operator {
 
   MeshDev mesh_dev() const {
     MeshDev m;
+    m.blocks = nullptr;
     m.ne = ne;
     m.ndofs = ndofs;
     m.verts = d_verts;
@@ -106,6 +111,11 @@ struct tpsrhs_operator {
                     static_cast<void *>(d_shared_orient), static_cast<void *>(d_send)})
       if (p) (void)hipFree(p);
     if (d_chem) (void)hipFree(d_chem);
+    if (d_blocks_halo) (void)hipFree(d_blocks_halo);
+    if (d_blocks_interior) (void)hipFree(d_blocks_interior);
+    for (auto &e : ev_halo)
+      if (e) (void)hipEventDestroy(e);
+    if (comm_stream) (void)hipStreamDestroy(comm_stream);
     for (void *p : d_extra) (void)hipFree(p);
     for (auto &set : evs)
       for (auto &e : set)
@@ -115,53 +125,105 @@ struct tpsrhs_operator {
 
 namespace {
 
-inline void exchange(tpsrhs_operator *op, int phase, double *T, int nfld, int per) {
+inline void exchange(tpsrhs_operator *op, int phase, double *T, int nfld, int per, hipStream_t stream) {
   const Topology &tp = op->topo;
   if (tp.num_shared == 0) return;
   const int n1 = (phase == 0) ? op->order + 1 : ((op->dim - 1) + 2 * op->order) / 2 + 1;
   const int64_t total = static_cast<int64_t>(tp.num_shared) * nfld * per;
   const int grid = static_cast<int>(std::min<int64_t>((total + 255) / 256, 2048));
   if (op->dim == 3)
-    hipLaunchKernelGGL(k_pack<3>, dim3(grid), dim3(256), 0, op->stream, tp.num_shared, nfld, n1, op->d_shared_slot,
+    hipLaunchKernelGGL(k_pack<3>, dim3(grid), dim3(256), 0, stream, tp.num_shared, nfld, n1, op->d_shared_slot,
                        op->d_shared_orient, T, op->d_send);
   else
-    hipLaunchKernelGGL(k_pack<2>, dim3(grid), dim3(256), 0, op->stream, tp.num_shared, nfld, n1, op->d_shared_slot,
+    hipLaunchKernelGGL(k_pack<2>, dim3(grid), dim3(256), 0, stream, tp.num_shared, nfld, n1, op->d_shared_slot,
                        op->d_shared_orient, T, op->d_send);
   HIP_CHECK(hipGetLastError());
   double *recv = T + static_cast<int64_t>(op->ne) * op->nfaces * nfld * per;
   const int st = op->halo(op->halo_ctx, phase, op->d_send, recv, static_cast<int>(tp.nbr_ranks.size()),
-                          tp.nbr_ranks.data(), op->send_off[phase].data(), op->recv_off[phase].data(), op->stream);
+                          tp.nbr_ranks.data(), op->send_off[phase].data(), op->recv_off[phase].data(), stream);
   if (st != 0) throw std::runtime_error("halo callback failed in phase " + std::to_string(phase));
 }
 
 template <int DIM, int P, class PH>
 void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_only) {
   typedef Cfg<DIM, P> C;
-  const MeshDev m = op->mesh_dev();
-  const int grid = (op->ne + C::EPB - 1) / C::EPB;
   static_assert(sizeof(typename PH::Params) <= sizeof(op->params), "parameter block too large");
   const typename PH::Params &prm = *reinterpret_cast<const typename PH::Params *>(op->params);
+  const int nblocks = (op->ne + C::EPB - 1) / C::EPB;
   hipStream_t s = op->stream;
+  if (!op->d_block_speed && !gradients_only) {
+    op->d_block_speed = dev_alloc<double>(nblocks);
+    op->flux_grid = nblocks;
+  }
+  auto traces = [&](const MeshDev &m, int grid) {
+    hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_Up, op->d_TA);
+    HIP_CHECK(hipGetLastError());
+  };
+  auto gradient = [&](const MeshDev &m, int grid) {
+    hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_TA, op->d_gradUp, op->d_TB);
+    HIP_CHECK(hipGetLastError());
+  };
+  auto flux = [&](const MeshDev &m, int grid) {
+    hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_gradUp, op->d_TA, op->d_TB, y,
+                       op->d_block_speed);
+    HIP_CHECK(hipGetLastError());
+  };
   if (op->timing) {
     op->ev = op->evs[op->sets_recorded % tpsrhs_operator::MAXSETS];
     HIP_CHECK(hipEventRecord(op->ev[0], s));
   }
-  hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_Up, op->d_TA);
-  HIP_CHECK(hipGetLastError());
-  if (op->timing) HIP_CHECK(hipEventRecord(op->ev[1], s));
-  exchange(op, 0, op->d_TA, 2 * PH::NEQ, C::NF);
-  hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_TA, op->d_gradUp, op->d_TB);
-  HIP_CHECK(hipGetLastError());
-  if (op->timing) HIP_CHECK(hipEventRecord(op->ev[2], s));
-  if (gradients_only) return;
-  exchange(op, 1, op->d_TB, PH::NEQ, C::NQ);
-  if (!op->d_block_speed) {
-    op->d_block_speed = dev_alloc<double>(grid);
-    op->flux_grid = grid;
+  const MeshDev all = op->mesh_dev();
+  if (op->topo.num_shared == 0) {
+    traces(all, nblocks);
+    if (op->timing) HIP_CHECK(hipEventRecord(op->ev[1], s));
+    gradient(all, nblocks);
+    if (op->timing) HIP_CHECK(hipEventRecord(op->ev[2], s));
+    if (gradients_only) return;
+    flux(all, nblocks);
+  } else {
+    // Partitioned mesh.  Blocks that touch a shared face ("halo blocks") run first in the producing
+    // sweeps and last in the consuming ones; packing and the neighbour exchange run on the second
+    // stream while the interior blocks compute (the reference overlaps its MPI exchange with the
+    // volume work the same way, src/rhs_operator.cpp:361-372,775-831).
+    if (!op->d_blocks_halo) {
+      std::vector<int> halo, interior;
+      std::vector<char> is_halo(nblocks, 0);
+      for (int i = 0; i < op->topo.num_shared; i++) is_halo[(op->topo.shared_slot[i] / op->nfaces) / C::EPB] = 1;
+      for (int b = 0; b < nblocks; b++) (is_halo[b] ? halo : interior).push_back(b);
+      op->n_blocks_halo = static_cast<int>(halo.size());
+      op->n_blocks_interior = static_cast<int>(interior.size());
+      op->d_blocks_halo = dev_upload(halo);
+      op->d_blocks_interior = dev_upload(interior);
+      HIP_CHECK(hipStreamCreateWithFlags(&op->comm_stream, hipStreamNonBlocking));
+      for (auto &e : op->ev_halo) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    MeshDev mh = all, mi = all;
+    mh.blocks = op->d_blocks_halo;
+    mi.blocks = op->d_blocks_interior;
+    const int nh = op->n_blocks_halo, ni = op->n_blocks_interior;
+    hipStream_t c = op->comm_stream;
+    // host order: the interior launches are enqueued BEFORE the (host-side, slow) exchange callback, so
+    // the compute stream never waits for the host
+    traces(mh, nh);
+    HIP_CHECK(hipEventRecord(op->ev_halo[0], s));
+    if (ni) traces(mi, ni);
+    if (op->timing) HIP_CHECK(hipEventRecord(op->ev[1], s));
+    if (ni) gradient(mi, ni);
+    HIP_CHECK(hipStreamWaitEvent(c, op->ev_halo[0], 0));
+    exchange(op, 0, op->d_TA, 2 * PH::NEQ, C::NF, c);  // overlaps the two interior launches above
+    HIP_CHECK(hipEventRecord(op->ev_halo[1], c));
+    HIP_CHECK(hipStreamWaitEvent(s, op->ev_halo[1], 0));
+    gradient(mh, nh);
+    if (op->timing) HIP_CHECK(hipEventRecord(op->ev[2], s));
+    if (gradients_only) return;
+    HIP_CHECK(hipEventRecord(op->ev_halo[2], s));
+    if (ni) flux(mi, ni);
+    HIP_CHECK(hipStreamWaitEvent(c, op->ev_halo[2], 0));
+    exchange(op, 1, op->d_TB, PH::NEQ, C::NQ, c);  // overlaps the interior flux launch
+    HIP_CHECK(hipEventRecord(op->ev_halo[3], c));
+    HIP_CHECK(hipStreamWaitEvent(s, op->ev_halo[3], 0));
+    flux(mh, nh);
   }
-  hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_gradUp, op->d_TA, op->d_TB, y,
-                     op->d_block_speed);
-  HIP_CHECK(hipGetLastError());
   if (op->timing) {
     HIP_CHECK(hipEventRecord(op->ev[3], s));
     op->sets_recorded++;

@@ -43,34 +43,43 @@ class HaloExchange:
         return torch.as_tensor(_DevPtr(ptr, n), device=self.device)
 
     def callback(self, ctx, phase, send, recv, nnbr, ranks, send_off, recv_off, stream):
+        """Everything is enqueued on `stream` (the operator's communication stream): the pack kernel ran
+        there, the sends/receives are ordered after it, and the operator makes its compute stream wait
+        for an event recorded after this returns -- no host synchronisation with the nccl backend."""
         try:
-            ops, stage = [], []
-            for r in range(nnbr):
-                ns = send_off[r + 1] - send_off[r]
-                nr = recv_off[r + 1] - recv_off[r]
-                s = self._view(send + 8 * send_off[r], ns)
-                t = self._view(recv + 8 * recv_off[r], nr)
-                peer = ranks[r]
-                if self.backend == "nccl" or self.host_buffers:
-                    ops.append(dist.P2POp(dist.isend, s, peer, self.group))
-                    ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
-                else:  # device buffers over a CPU backend: stage through host
-                    hs = s.cpu()
-                    ht = torch.empty(nr, dtype=torch.float64)
-                    stage.append((t, ht))
-                    ops.append(dist.P2POp(dist.isend, hs, peer, self.group))
-                    ops.append(dist.P2POp(dist.irecv, ht, peer, self.group))
-                self.bytes_sent += 8 * ns
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            for t, ht in stage:
-                t.copy_(ht)
-            self.calls += 1
-            return 0
+            if not self.host_buffers and torch.cuda.is_available():
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0), device=self.device)):
+                    return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
+            return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
         except Exception as exc:  # never let an exception cross the C boundary
             import traceback
 
             traceback.print_exc()
             self.error = exc
             return 1
+
+    def _exchange(self, send, recv, nnbr, ranks, send_off, recv_off):
+        ops, stage = [], []
+        for r in range(nnbr):
+            ns = send_off[r + 1] - send_off[r]
+            nr = recv_off[r + 1] - recv_off[r]
+            s = self._view(send + 8 * send_off[r], ns)
+            t = self._view(recv + 8 * recv_off[r], nr)
+            peer = ranks[r]
+            if self.backend == "nccl" or self.host_buffers:
+                ops.append(dist.P2POp(dist.isend, s, peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
+            else:  # device buffers over a CPU backend: stage through host
+                hs = s.cpu()
+                ht = torch.empty(nr, dtype=torch.float64)
+                stage.append((t, ht))
+                ops.append(dist.P2POp(dist.isend, hs, peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, ht, peer, self.group))
+            self.bytes_sent += 8 * ns
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for t, ht in stage:
+            t.copy_(ht)
+        self.calls += 1
+        return 0
