@@ -31,11 +31,20 @@ inline double att12(double Tp) { return fit(0.0991, 7.4684, 1.0155, 1.1536, Tp);
 inline double att13(double Tp) { return fit(0.0616, 7.8271, 0.9452, 1.1105, Tp); }
 inline double att14(double Tp) { return fit(0.0308, 13.9567, 0.9511, 1.1803, Tp); }
 inline double att15(double Tp) { return fit(0.0232, 13.7888, 0.9148, 1.1532, Tp); }
+inline double att22(double Tp) { return fit(0.2423, 4.6796, 1.3290, 1.1279, Tp); }
+inline double att23(double Tp) { return fit(0.1221, 8.7542, 1.3875, 1.1110, Tp); }
+inline double att24(double Tp) { return fit(0.0619, 18.2538, 1.4341, 1.1618, Tp); }
+inline double rep11(double Tp) { return fit(0.3904, 0.9100, 1.1025, 1.0544, Tp); }
+inline double rep12(double Tp) { return fit(0.1547, 1.6597, 1.1725, 0.9792, Tp); }
+inline double rep13(double Tp) { return fit(0.0814, 2.5815, 1.1948, 0.9570, Tp); }
+inline double rep14(double Tp) { return fit(0.0683, 1.9774, 1.2033, 0.8264, Tp); }
+inline double rep15(double Tp) { return fit(0.0346, 4.5177, 1.2132, 0.9294, Tp); }
 inline double rep22(double Tp) { return fit(0.4128, 1.2436, 1.1830, 1.0123, Tp); }
 inline double rep23(double Tp) { return fit(0.2203, 1.8832, 1.2059, 0.9851, Tp); }
 inline double rep24(double Tp) { return fit(0.1323, 2.7248, 1.2129, 0.9847, Tp); }
 }  // namespace charged
 namespace argon {  // src/collision_integrals.cpp:124-201; T in K, result in m^2
+inline double ArAr11(double T) { return 2.2910e-18 * std::pow(T, -0.3032); }
 inline double ArAr22(double T) { return 1.7e-18 * std::pow(T, -0.25); }
 inline double ArAr1P11(double T) { return 4.574321e-18 * std::pow(T, -0.1805); }
 inline double logT_fit(double logT, const double c[9]) {
@@ -454,17 +463,19 @@ class GasMinimalTransport : public TransportProperties {
   bool thirdOrderkElectron_, multiply_;
   double fluxTrnsMultiplier_[4], spcsTrnsMultiplier_[1], diffMult_, mobilMult_;
 
-  GasMinimalTransport(PerfectMixture *m, const tpsrhs_gas_transport &in) : TransportProperties(m), pm(m) {
+  GasMinimalTransport(PerfectMixture *m, const tpsrhs_gas_transport &in, bool ternary = true)
+      : TransportProperties(m), pm(m) {
     viscosityFactor_ = 5. / 16. * std::sqrt(PI_ * kB_);
     kOverEtaFactor_ = 15. / 4. * kB_;
     diffusivityFactor_ = 3. / 16. * std::sqrt(2.0 * PI_ * kB_) / AVOGADRONUMBER;
     mfFreqFactor_ = 4. / 3. * AVOGADRONUMBER * std::sqrt(8. * kB_ / PI_);
-    if (numSpecies != 3) throw std::runtime_error("argon ternary transport supports Ar, Ar.+1, E only");
+    if (ternary && numSpecies != 3) throw std::runtime_error("argon ternary transport supports Ar, Ar.+1, E only");
+    if (numSpecies > 7) throw std::runtime_error("argon mixture transport supports at most 7 species");
     neutralIndex_ = in.neutral_index;
     ionIndex_ = in.ion_index;
     electronIndex_ = in.electron_index;
     if (neutralIndex_ < 0 || ionIndex_ < 0 || electronIndex_ < 0) throw std::runtime_error("argon transport indices");
-    for (int sp = 0; sp < 3; sp++) mw_[sp] = m->GetGasParams(sp, TPSRHS_SPECIES_MW);
+    for (int sp = 0; sp < numSpecies; sp++) mw_[sp] = m->GetGasParams(sp, TPSRHS_SPECIES_MW);
     if (std::fabs(mw_[neutralIndex_] - mw_[electronIndex_] - mw_[ionIndex_]) >= 1.0e-12)
       throw std::runtime_error("argon transport: inconsistent species masses");
     for (int sp = 0; sp < numSpecies; sp++) mw_[sp] /= AVOGADRONUMBER;
@@ -652,12 +663,196 @@ class GasMinimalTransport : public TransportProperties {
   }
 };
 
+// ------------------------------------------------------------------------------------------
+// GasMixtureTransport, argon (src/gas_transport.cpp:870-1560): any number of species, every pair's
+// collision integral picked from the input table (src/gas_transport.cpp:995-1283)
+// ------------------------------------------------------------------------------------------
+class GasMixtureTransport : public GasMinimalTransport {
+ public:
+  int collisionIndex_[MAXSP * MAXSP];
+  struct CollisionInputs {
+    double Te, Th, debyeCircle, ndimTe, ndimTh;
+  };
+  GasMixtureTransport(PerfectMixture *m, const tpsrhs_gas_transport &in) : GasMinimalTransport(m, in, /*ternary*/ false) {
+    for (int i = 0; i < numSpecies; i++)
+      for (int j = i; j < numSpecies; j++) {
+        const int c = in.collision_index[i + j * numSpecies];
+        if (c < TPSRHS_CLMB_ATT || c > TPSRHS_AR_AR) throw std::runtime_error("collision type outside the argon set");
+        collisionIndex_[i + j * numSpecies] = c;
+      }
+  }
+  CollisionInputs computeCollisionInputs(const double *primitive, const double *n_sp) const {  // :185-204
+    CollisionInputs c;
+    c.Te = twoTemperature ? primitive[num_equation - 1] : primitive[nvel + 1];
+    c.Th = primitive[nvel + 1];
+    double nOverT = 0.0;
+    for (int sp = 0; sp < numSpecies; sp++) {
+      const double q = mixture->GetGasParams(sp, TPSRHS_SPECIES_CHARGES);
+      nOverT += (n_sp[sp] + Xeps_) / c.Te * q * q;
+    }
+    const double debyeLength = std::sqrt(debyeFactor_ / AVOGADRONUMBER / nOverT);
+    c.debyeCircle = PI_ * debyeLength * debyeLength;
+    c.ndimTe = debyeLength * 4.0 * PI_ * debyeFactor_ * c.Te;
+    c.ndimTh = debyeLength * 4.0 * PI_ * debyeFactor_ * c.Th;
+    return c;
+  }
+  double collisionIntegral(int a, int b, int l, int r, const CollisionInputs &c) const {
+    const int spI = std::min(a, b), spJ = std::max(a, b);
+    const int idx = collisionIndex_[spI + spJ * numSpecies];
+    const bool withE = (spI == electronIndex_) || (spJ == electronIndex_);
+    namespace ch = collision::charged;
+    namespace ar = collision::argon;
+    if (idx == TPSRHS_CLMB_ATT || idx == TPSRHS_CLMB_REP) {
+      const double t = withE ? c.ndimTe : c.ndimTh;
+      typedef double (*F)(double);
+      static const F att1[5] = {ch::att11, ch::att12, ch::att13, ch::att14, ch::att15};
+      static const F att2[3] = {ch::att22, ch::att23, ch::att24};
+      static const F rep1[5] = {ch::rep11, ch::rep12, ch::rep13, ch::rep14, ch::rep15};
+      static const F rep2[3] = {ch::rep22, ch::rep23, ch::rep24};
+      if (l == 1 && r >= 1 && r <= 5) return c.debyeCircle * (idx == TPSRHS_CLMB_ATT ? att1 : rep1)[r - 1](t);
+      if (l == 2 && r >= 2 && r <= 4) return c.debyeCircle * (idx == TPSRHS_CLMB_ATT ? att2 : rep2)[r - 2](t);
+      throw std::runtime_error("Coulomb collision integral order not supported");
+    }
+    const double t = withE ? c.Te : c.Th;
+    switch (idx) {
+      case TPSRHS_AR_AR1P:
+        if (l == 1 && r == 1) return ar::ArAr1P11(t);
+        break;
+      case TPSRHS_AR_E:
+        if (l == 1 && r >= 1 && r <= 5) return ar::eAr1r(r, t);
+        break;
+      case TPSRHS_AR_AR:
+        if (l == 1 && r == 1) return ar::ArAr11(t);
+        if (l == 2 && r == 2) return ar::ArAr22(t);
+        break;
+    }
+    throw std::runtime_error("collision integral not supported for this pair");
+  }
+  double thirdOrderKe(const double *X_sp, const CollisionInputs &c) const {  // :1388-1407
+    double Q2[3];
+    for (int r = 0; r < 3; r++) Q2[r] = collisionIntegral(electronIndex_, electronIndex_, 2, r + 2, c);
+    double L11 = std::sqrt(2.0) * X_sp[electronIndex_] * L11ee(Q2);
+    double L12 = std::sqrt(2.0) * X_sp[electronIndex_] * L12ee(Q2);
+    double L22 = std::sqrt(2.0) * X_sp[electronIndex_] * L22ee(Q2);
+    for (int sp = 0; sp < numSpecies; sp++) {
+      if (sp == electronIndex_) continue;
+      double Q1[5];
+      for (int r = 0; r < 5; r++) Q1[r] = collisionIntegral(sp, electronIndex_, 1, r + 1, c);
+      L11 += X_sp[sp] * L11ea(Q1);
+      L12 += X_sp[sp] * L12ea(Q1);
+      L22 += X_sp[sp] * L22ea(Q1);
+    }
+    return viscosityFactor_ * kOverEtaFactor_ * std::sqrt(2.0 * c.Te / mw_[electronIndex_]) * X_sp[electronIndex_] /
+           (L11 - L12 * L12 / L22);
+  }
+  void mixtureDiffusion(const double *X_sp, const double *Y_sp, double nTotal, const CollisionInputs &c,
+                        double *diffusivity, double *mobility) const {
+    double binaryDiff[MAXSP * MAXSP];
+    for (int i = 0; i < MAXSP * MAXSP; i++) binaryDiff[i] = 0.0;
+    for (int spI = 0; spI < numSpecies - 1; spI++)
+      for (int spJ = spI + 1; spJ < numSpecies; spJ++) {
+        const double temp = ((spI == electronIndex_) || (spJ == electronIndex_)) ? c.Te : c.Th;
+        binaryDiff[spI + spJ * numSpecies] =
+            diffusivityFactor_ * std::sqrt(temp / getMuw(spI, spJ)) / nTotal / collisionIntegral(spI, spJ, 1, 1, c);
+        binaryDiff[spJ + spI * numSpecies] = binaryDiff[spI + spJ * numSpecies];
+      }
+    CurtissHirschfelder(X_sp, Y_sp, binaryDiff, diffusivity);
+    for (int sp = 0; sp < numSpecies; sp++) {
+      const double temp = (sp == electronIndex_) ? c.Te : c.Th;
+      mobility[sp] = qeOverkB_ * mixture->GetGasParams(sp, TPSRHS_SPECIES_CHARGES) / temp * diffusivity[sp];
+    }
+  }
+  void ComputeFluxTransportProperties(const double *state, const double *gradUp, const double *Efield, double, double,
+                                      double *tb, double *diffusionVelocity) override {  // :1285-1386
+    for (int p = 0; p < NUM_FLUX_TRANS; p++) tb[p] = 0.0;
+    double prim[MAXEQ];
+    mixture->GetPrimitivesFromConservatives(state, prim);
+    double n_sp[MAXSP], X_sp[MAXSP], Y_sp[MAXSP];
+    pm->computeSpeciesPrimitives(state, X_sp, Y_sp, n_sp);
+    double nTotal = 0.0;
+    for (int sp = 0; sp < numSpecies; sp++) nTotal += n_sp[sp];
+    const CollisionInputs c = computeCollisionInputs(prim, n_sp);
+    double sv[MAXSP], sk[MAXSP];
+    for (int sp = 0; sp < numSpecies; sp++) {
+      if (sp == electronIndex_) {
+        sv[sp] = sk[sp] = 0.0;
+        continue;
+      }
+      sv[sp] = viscosityFactor_ * std::sqrt(mw_[sp] * c.Th) / collisionIntegral(sp, sp, 2, 2, c);
+      sk[sp] = sv[sp] * kOverEtaFactor_ / mw_[sp];
+    }
+    tb[VISCOSITY] = linearAverage(X_sp, sv);
+    tb[HEAVY_THERMAL_CONDUCTIVITY] = linearAverage(X_sp, sk);
+    tb[BULK_VISCOSITY] = 0.0;
+    if (thirdOrderkElectron_) {
+      tb[ELECTRON_THERMAL_CONDUCTIVITY] = thirdOrderKe(X_sp, c);
+    } else {
+      tb[ELECTRON_THERMAL_CONDUCTIVITY] = viscosityFactor_ * kOverEtaFactor_ * std::sqrt(c.Te / mw_[electronIndex_]) *
+                                          X_sp[electronIndex_] / collisionIntegral(electronIndex_, electronIndex_, 2, 2, c);
+    }
+    double diffusivity[MAXSP], mobility[MAXSP];
+    mixtureDiffusion(X_sp, Y_sp, nTotal, c, diffusivity, mobility);
+    if (multiply_) {
+      for (int t = 0; t < NUM_FLUX_TRANS; t++) tb[t] *= fluxTrnsMultiplier_[t];
+      for (int sp = 0; sp < numSpecies; sp++) {
+        diffusivity[sp] *= diffMult_;
+        mobility[sp] *= mobilMult_;
+      }
+    }
+    velocities(X_sp, Y_sp, n_sp, gradUp, Efield, diffusivity, mobility, diffusionVelocity);
+  }
+  void ComputeSourceTransportProperties(const double *state, const double *Up, const double *gradUp,
+                                        const double *Efield, double, double *globalTransport, double *speciesTransport,
+                                        double *diffusionVelocity, double *n_sp) override {  // :1409-1497
+    for (int p = 0; p < NUM_SRC_TRANS; p++) globalTransport[p] = 0.0;
+    for (int sp = 0; sp < numSpecies; sp++) speciesTransport[sp] = 0.0;
+    double X_sp[MAXSP], Y_sp[MAXSP];
+    pm->computeSpeciesPrimitives(state, X_sp, Y_sp, n_sp);
+    double nTotal = 0.0;
+    for (int sp = 0; sp < numSpecies; sp++) nTotal += n_sp[sp];
+    const CollisionInputs c = computeCollisionInputs(Up, n_sp);
+    double diffusivity[MAXSP], mobility[MAXSP];
+    mixtureDiffusion(X_sp, Y_sp, nTotal, c, diffusivity, mobility);
+    for (int sp = 0; sp < numSpecies; sp++) {
+      if (sp == electronIndex_) continue;
+      speciesTransport[sp + MF_FREQUENCY * numSpecies] = mfFreqFactor_ * std::sqrt(c.Te / mw_[electronIndex_]) * n_sp[sp] *
+                                                         collisionIntegral(sp, electronIndex_, 1, 1, c);
+    }
+    if (multiply_) {
+      for (int sp = 0; sp < numSpecies; sp++) {
+        diffusivity[sp] *= diffMult_;
+        mobility[sp] *= mobilMult_;
+        speciesTransport[sp + MF_FREQUENCY * numSpecies] *= spcsTrnsMultiplier_[MF_FREQUENCY];
+      }
+    }
+    globalTransport[ELECTRIC_CONDUCTIVITY] = computeMixtureElectricConductivity(mobility, n_sp) * MOLARELECTRONCHARGE;
+    velocities(X_sp, Y_sp, n_sp, gradUp, Efield, diffusivity, mobility, diffusionVelocity);
+  }
+  void GetViscosities(const double *conserved, const double *primitive, double *visc) override {  // :1499-1535
+    double n_sp[MAXSP], X_sp[MAXSP], Y_sp[MAXSP];
+    pm->computeSpeciesPrimitives(conserved, X_sp, Y_sp, n_sp);
+    const CollisionInputs c = computeCollisionInputs(primitive, n_sp);
+    double sv[MAXSP];
+    for (int sp = 0; sp < numSpecies; sp++)
+      sv[sp] = (sp == electronIndex_) ? 0.0
+                                      : viscosityFactor_ * std::sqrt(mw_[sp] * c.Th) / collisionIntegral(sp, sp, 2, 2, c);
+    visc[0] = linearAverage(X_sp, sv);
+    visc[1] = 0.0;
+    if (multiply_) {
+      visc[0] *= fluxTrnsMultiplier_[VISCOSITY];
+      visc[1] *= fluxTrnsMultiplier_[BULK_VISCOSITY];
+    }
+  }
+};
+
 inline TransportProperties *make_transport(PerfectMixture *pm, const tpsrhs_physics &p) {
   switch (p.transport_model) {
     case TPSRHS_CONSTANT:
       return new ConstantTransport(pm, p.constant_transport);
     case TPSRHS_ARGON_MINIMAL:
       return new GasMinimalTransport(pm, p.gas_transport);
+    case TPSRHS_ARGON_MIXTURE:
+      return new GasMixtureTransport(pm, p.gas_transport);
     default:
       throw std::runtime_error("transport model outside the hot-path scope");
   }

@@ -98,6 +98,8 @@ def _boost_transport(ph, factor=300.0):
     (1, True, capi.CONSTANT, "balance", capi.INV, capi.NS),
     (3, False, capi.CONSTANT, "tabulated", capi.VISC_ISOTH, capi.NS),
     (1, False, capi.ARGON_MINIMAL, "hoffertlien", capi.INV, capi.EULER),
+    (2, True, capi.ARGON_MIXTURE, "arrhenius", capi.VISC_ISOTH, capi.NS),    # GasMixtureTransport, pair table
+    (3, False, capi.ARGON_MIXTURE, "arrhenius", capi.VISC_ADIAB, capi.NS),
 ])
 def test_plasma_cylinder(order, two_t, transport, reactions, wall, eq):
     c = cases.argon_cyl3d(4, 12, 3, order, two_t, transport, reactions, wall, eq, radiation=(reactions == "tabulated"))
@@ -130,6 +132,7 @@ def test_plasma_use_bc_in_grad():
     (2, True, capi.ARGON_MINIMAL, capi.VISC_ADIAB, 0.01, 0.06),
     (1, False, capi.ARGON_MINIMAL, capi.INV, 0.02, 0.06),
     (3, False, capi.CONSTANT, capi.VISC_ISOTH, 0.01, 0.05),
+    (3, True, capi.ARGON_MIXTURE, capi.VISC_ISOTH, 0.0, 0.0),   # cfg5 with its second transport option
 ])
 def test_plasma_axisymmetric(order, two_t, transport, wall, r_in, warp):
     c = cases.argon_axisym(6, 9, order, two_t, transport, "arrhenius", True, wall, r_in=r_in, warp=warp)

@@ -164,3 +164,27 @@ def test_species_clamp_offset_is_the_references():
     Up[5] = -abs(Up[5])
     s = o3.source(U, Up, np.zeros(3 * o3.neq))
     assert np.isfinite(s).all() and s[5] == 0.0  # n_i = n_e = 0 after the clamp: no reaction progress
+
+
+@pytest.mark.parametrize("two_t", [False, True])
+def test_mixture_transport_against_the_ternary_special_case(two_t):
+    """GasMixtureTransport with the argon pair table evaluates the same integrals as GasMinimalTransport;
+    the two differ only in the Debye length: sum_sp Z^2 n_sp / T_e (src/gas_transport.cpp:185-204) versus
+    n_e/T_e + n_i/T_h (:226-229), i.e. they agree for a single temperature."""
+    omin, ph = tiny_oracle(two_t, capi.ARGON_MINIMAL)
+    omix, _ = tiny_oracle(two_t, capi.ARGON_MIXTURE)
+    rng = np.random.default_rng(2)
+    for U in sample_states(ph, 3, n=8, seed=4):
+        Up = omin.prim(U)
+        g = rng.normal(size=3 * omin.neq) * np.tile(np.abs(Up), 3)
+        b0, V0 = omin.flux_transport(U, g)
+        b1, V1 = omix.flux_transport(U, g)
+        s0 = omin.source_transport(U, Up, g)
+        s1 = omix.source_transport(U, Up, g)
+        if not two_t:
+            assert np.allclose(b1, b0, rtol=1e-13) and np.allclose(V1, V0, rtol=1e-12, atol=1e-14 * np.abs(V0).max())
+            assert np.allclose(s1[1], s0[1], rtol=1e-13) and s1[0] == pytest.approx(s0[0], rel=1e-13)
+        else:
+            assert np.isfinite(b1).all() and b1[0] > 0
+            assert not np.allclose(b1, b0, rtol=1e-6)  # the Debye lengths differ
+            assert np.allclose(b1, b0, rtol=0.5)       # ... through a logarithm only

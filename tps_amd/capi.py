@@ -172,6 +172,10 @@ def argon_ternary_physics(eq_system=NS, two_temperature=False, transport=ARGON_M
     ct.electron_index = 1
     gt = ph.gas_transport
     gt.neutral_index, gt.ion_index, gt.electron_index = 2, 0, 1
+    # collision types of the species pairs, [i + j*nsp] for i <= j (src/M2ulPhyS.cpp identifyCollisionType)
+    pair = {(0, 0): CLMB_REP, (0, 1): CLMB_ATT, (0, 2): AR_AR1P, (1, 1): CLMB_REP, (1, 2): AR_E, (2, 2): AR_AR}
+    for (i, j), c in pair.items():
+        gt.collision_index[i + j * nsp] = c
     gt.third_order_k_electron = int(third_order_ke)
     gt.multiply = 0
     for k in range(4):

@@ -63,6 +63,7 @@ struct PlasmaParams {
   int c_eidx;
   // argon ternary
   int third_order, multiply;
+  int coll[NSP * NSP];  // tpsrhs_gas_coll of the species pairs [i + j*NSP], i <= j (argon mixture transport)
   double mult_flux[4], mult_spcs, mult_diff, mult_mobil;
   const ChemDev *chem;
   int eq_system, use_bc_in_grad, num_bcs, axisymmetric;
@@ -119,6 +120,18 @@ __device__ inline double att15(const Arg &a) { return cfit(0.0232, 13.7888, 0.91
 __device__ inline double rep22(const Arg &a) { return cfit(0.4128, 1.2436, 1.1830, 1.0123, a); }
 __device__ inline double rep23(const Arg &a) { return cfit(0.2203, 1.8832, 1.2059, 0.9851, a); }
 __device__ inline double rep24(const Arg &a) { return cfit(0.1323, 2.7248, 1.2129, 0.9847, a); }
+// Coulomb fits by (attractive 0 / repulsive 1, l, r): c0, c1, c2, c3 (src/collision_integrals.cpp:53-115);
+// rows the reference does not have are zero
+__constant__ static double c_coulomb[2][2][5][4] = {
+    {{{0.2150, 5.2194, 1.0472, 1.2435}, {0.0991, 7.4684, 1.0155, 1.1536}, {0.0616, 7.8271, 0.9452, 1.1105},
+      {0.0308, 13.9567, 0.9511, 1.1803}, {0.0232, 13.7888, 0.9148, 1.1532}},
+     {{0, 0, 0, 0}, {0.2423, 4.6796, 1.3290, 1.1279}, {0.1221, 8.7542, 1.3875, 1.1110}, {0.0619, 18.2538, 1.4341, 1.1618},
+      {0, 0, 0, 0}}},
+    {{{0.3904, 0.9100, 1.1025, 1.0544}, {0.1547, 1.6597, 1.1725, 0.9792}, {0.0814, 2.5815, 1.1948, 0.9570},
+      {0.0683, 1.9774, 1.2033, 0.8264}, {0.0346, 4.5177, 1.2132, 0.9294}},
+     {{0, 0, 0, 0}, {0.4128, 1.2436, 1.1830, 1.0123}, {0.2203, 1.8832, 1.2059, 0.9851}, {0.1323, 2.7248, 1.2129, 0.9847},
+      {0, 0, 0, 0}}}};
+__device__ inline double ArAr11(double lnT) { return 2.2910e-18 * exp(-0.3032 * lnT); }
 __device__ inline double ArAr22(double T) { return 1.7e-18 / sqrt(sqrt(T)); }  // T^-0.25
 __device__ inline double ArAr1P11(double lnT) { return 4.574321e-18 * exp(-0.1805 * lnT); }
 __device__ inline double eAr1r(int r, double logT) {
@@ -143,7 +156,7 @@ __device__ inline double eAr1r(int r, double logT) {
 }
 }  // namespace coll
 
-enum { TRANSPORT_CONSTANT = 0, TRANSPORT_ARGON_MINIMAL = 1 };
+enum { TRANSPORT_CONSTANT = 0, TRANSPORT_ARGON_MINIMAL = 1, TRANSPORT_ARGON_MIXTURE = 2 };
 
 template <int DIM_, int NVEL_, int NSP_, bool AMBI, bool TWOT, int TRANSPORT>
 struct PlasmaPhys {
@@ -392,6 +405,46 @@ struct PlasmaPhys {
     return vf * kf * sqrt(2.0 * Te / me) * X[I_E] / (L11 - L12 * L12 / L22);
   }
 
+  // collisionInputs of the mixture transport (src/gas_transport.cpp:185-204): the Debye length sums
+  // Z^2 n / T_e over all species
+  struct MixColl {
+    double circle, Th, lnTe, lnTh;
+    coll::Arg e, h;
+  };
+  __device__ static inline MixColl mix_inputs(const Params &p, const double *n, double Th, double Te) {
+    const double dfac = kBoltz * kEps0 / kQe / kQe;
+    double nOverT = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) nOverT += (n[sp] + kXeps) / Te * p.charge[sp] * p.charge[sp];
+    const double length = sqrt(dfac / kAvogadro / nOverT);
+    MixColl c;
+    c.circle = kPi * length * length;
+    const double f = length * 4.0 * kPi * dfac;
+    c.e = coll::arg(f * Te);
+    c.h = TWOT ? coll::arg(f * Th) : c.e;
+    c.Th = Th;
+    c.lnTe = log(Te);
+    c.lnTh = TWOT ? log(Th) : c.lnTe;
+    return c;
+  }
+  // GasMixtureTransport::collisionIntegral (src/gas_transport.cpp:995-1283), argon types.  (l, r) and the
+  // species are compile-time after unrolling; the pair's collision type is a uniform run-time value.
+  // tpsrhs_create has checked that every (pair, l, r) the transport asks for exists.
+  template <int L, int R>
+  __device__ static inline double collision(const Params &p, int i, int j, const MixColl &c) {
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    const int type = p.coll[a + b * NSP];
+    const bool with_e = (a == IE) || (b == IE);
+    if (type == TPSRHS_CLMB_ATT || type == TPSRHS_CLMB_REP) {
+      const double *k = coll::c_coulomb[type == TPSRHS_CLMB_REP ? 1 : 0][L - 1][R - 1];
+      return c.circle * coll::cfit(k[0], k[1], k[2], k[3], with_e ? c.e : c.h);
+    }
+    if (type == TPSRHS_AR_E) return coll::eAr1r(R, with_e ? c.lnTe : c.lnTh);
+    if (type == TPSRHS_AR_AR1P) return coll::ArAr1P11(with_e ? c.lnTe : c.lnTh);
+    if (L == 1) return coll::ArAr11(with_e ? c.lnTe : c.lnTh);  // AR_AR
+    return coll::ArAr22(c.Th);
+  }
+
   // ComputeFluxTransportProperties of the selected model; E-field = 0 (src/fluxes.cpp:200-201).
   // `diffusion` = false skips the diffusion velocities (walls prescribe zero species fluxes).
   __device__ static inline void transport(const Params &p, const double *U, double Th, double Te, const double *g,
@@ -412,6 +465,75 @@ struct PlasmaPhys {
         diff[sp] = p.c_diff[sp];
         const double temp = (sp == p.c_eidx) ? Te : Th;
         mob[sp] = (kQe / kBoltz) * p.charge[sp] / temp * diff[sp];
+      }
+    } else if (TRANSPORT == TRANSPORT_ARGON_MIXTURE) {  // GasMixtureTransport, src/gas_transport.cpp:1285-1407
+      const double vf = 5. / 16. * sqrt(kPi * kBoltz), kf = 15. / 4. * kBoltz;
+      const double dfc = 3. / 16. * sqrt(2.0 * kPi * kBoltz) / kAvogadro;
+      double mwp[NSP];
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) mwp[sp] = p.mw[sp] / kAvogadro;
+      const MixColl c = mix_inputs(p, q.n, Th, Te);
+      t.visc = t.bulk = t.k = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) {
+        if (sp == IE) continue;
+        const double sv = vf * sqrt(mwp[sp] * Th) / collision<2, 2>(p, sp, sp, c);
+        t.visc += q.X[sp] * sv;
+        t.k += q.X[sp] * (sv * kf / mwp[sp]);
+      }
+      if (p.third_order) {  // :1388-1407
+        const double s2 = sqrt(2.0);
+        const double Q22 = collision<2, 2>(p, IE, IE, c), Q23 = collision<2, 3>(p, IE, IE, c),
+                     Q24 = collision<2, 4>(p, IE, IE, c);
+        double L11 = s2 * q.X[IE] * Q22;
+        double L12 = s2 * q.X[IE] * (1.75 * Q22 - 2.0 * Q23);
+        double L22 = s2 * q.X[IE] * (4.8125 * Q22 - 7.0 * Q23 + 5. * Q24);
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) {
+          if (sp == IE) continue;
+          const double Q1[5] = {collision<1, 1>(p, sp, IE, c), collision<1, 2>(p, sp, IE, c), collision<1, 3>(p, sp, IE, c),
+                                collision<1, 4>(p, sp, IE, c), collision<1, 5>(p, sp, IE, c)};
+          L11 += q.X[sp] * (6.25 * Q1[0] - 15. * Q1[1] + 12. * Q1[2]);
+          L12 += q.X[sp] * (10.9375 * Q1[0] - 39.375 * Q1[1] + 57. * Q1[2] - 30. * Q1[3]);
+          L22 += q.X[sp] * (19.140625 * Q1[0] - 91.875 * Q1[1] + 199.5 * Q1[2] - 210. * Q1[3] + 90. * Q1[4]);
+        }
+        t.ke = vf * kf * sqrt(2.0 * Te / mwp[IE]) * q.X[IE] / (L11 - L12 * L12 / L22);
+      } else {
+        t.ke = vf * kf * sqrt(Te / mwp[IE]) * q.X[IE] / collision<2, 2>(p, IE, IE, c);
+      }
+      if (diffusion) {
+        double bd[NSP * NSP];
+#pragma unroll
+        for (int i = 0; i < NSP * NSP; i++) bd[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NSP - 1; i++)
+#pragma unroll
+          for (int j = i + 1; j < NSP; j++) {
+            const double temp = (i == IE || j == IE) ? Te : Th;
+            const double muw = mwp[i] * mwp[j] / (mwp[i] + mwp[j]);
+            bd[i + j * NSP] = bd[j + i * NSP] = dfc * sqrt(temp / muw) / q.ntot / collision<1, 1>(p, i, j, c);
+          }
+#pragma unroll
+        for (int i = 0; i < NSP; i++) {
+          double a = 0.0;
+#pragma unroll
+          for (int j = 0; j < NSP; j++)
+            if (i != j) a += (q.X[j] + kXeps) / bd[i + j * NSP];
+          diff[i] = (1.0 - q.Y[i]) / a;
+          const double temp = (i == IE) ? Te : Th;
+          mob[i] = (kQe / kBoltz) * p.charge[i] / temp * diff[i];
+        }
+      }
+      if (p.multiply) {
+        t.visc *= p.mult_flux[0];
+        t.bulk *= p.mult_flux[1];
+        t.k *= p.mult_flux[2];
+        t.ke *= p.mult_flux[3];
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) {
+          diff[sp] *= p.mult_diff;
+          mob[sp] *= p.mult_mobil;
+        }
       }
     } else {
       const double vf = 5. / 16. * sqrt(kPi * kBoltz), kf = 15. / 4. * kBoltz;
@@ -514,6 +636,16 @@ struct PlasmaPhys {
     if (TRANSPORT == TRANSPORT_CONSTANT) {
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) mtfreq[sp] = p.c_mtfreq[sp];
+    } else if (TRANSPORT == TRANSPORT_ARGON_MIXTURE) {  // src/gas_transport.cpp:1445-1459
+      const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
+      const double me = p.mw[IE] / kAvogadro;
+      const MixColl c = mix_inputs(p, q.n, Th, Te);
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) {
+        if (sp == IE) continue;
+        mtfreq[sp] = mff * sqrt(Te / me) * q.n[sp] * collision<1, 1>(p, sp, IE, c);
+        if (p.multiply) mtfreq[sp] *= p.mult_spcs;
+      }
     } else {
       const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
       const double me = p.mw[I_E] / kAvogadro;
@@ -834,6 +966,19 @@ struct PlasmaPhys {
     }
     const Species q = species(p, U);
     const double vf = 5. / 16. * sqrt(kPi * kBoltz);
+    if (TRANSPORT == TRANSPORT_ARGON_MIXTURE) {  // src/gas_transport.cpp:1499-1535
+      const MixColl c = mix_inputs(p, q.n, Th, Te);
+      visc = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++)
+        if (sp != IE) visc += q.X[sp] * (vf * sqrt(p.mw[sp] / kAvogadro * Th) / collision<2, 2>(p, sp, sp, c));
+      bulk = 0.0;
+      if (p.multiply) {
+        visc *= p.mult_flux[0];
+        bulk *= p.mult_flux[1];
+      }
+      return;
+    }
     const Debye d = debye(q.n, Th, Te);
     const double sv_ion = vf * sqrt(p.mw[I_ION] / kAvogadro * Th) / (coll::rep22(d.h) * d.circle);
     const double sv_n = vf * sqrt(p.mw[I_N] / kAvogadro * Th) / coll::ArAr22(Th);

@@ -17,7 +17,9 @@ static void pick(tpsrhs_operator *op) {
 void pick_plasma_axisym(tpsrhs_operator *op, bool two_temperature, int transport) {
   if (transport == TRANSPORT_CONSTANT) {
     if (two_temperature) pick<true, TRANSPORT_CONSTANT>(op); else pick<false, TRANSPORT_CONSTANT>(op);
-  } else {
+  } else if (transport == TRANSPORT_ARGON_MINIMAL) {
     if (two_temperature) pick<true, TRANSPORT_ARGON_MINIMAL>(op); else pick<false, TRANSPORT_ARGON_MINIMAL>(op);
+  } else {
+    if (two_temperature) pick<true, TRANSPORT_ARGON_MIXTURE>(op); else pick<false, TRANSPORT_ARGON_MIXTURE>(op);
   }
 }

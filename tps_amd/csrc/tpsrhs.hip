@@ -82,6 +82,25 @@ void fill_plasma_params(tpsrhs_operator *op, const tpsrhs_disc *disc, const tpsr
     if (std::fabs(p.mw[gt.neutral_index] - p.mw[gt.electron_index] - p.mw[gt.ion_index]) >= 1.0e-12)
       throw std::invalid_argument("argon transport: inconsistent species masses");
   }
+  if (phys->transport_model == TPSRHS_ARGON_MIXTURE) {
+    // GasMixtureTransport::GasMixtureTransport + the (pair, l, r) requests of its closures
+    // (src/gas_transport.cpp:870-990, 1285-1497): every request must have a fit
+    if (gt.electron_index != NSP - 2) throw std::invalid_argument("argon mixture transport: electron index");
+    for (int i = 0; i < NSP; i++)
+      for (int j = i; j < NSP; j++) {
+        const int c = gt.collision_index[i + j * NSP];
+        const bool e_i = (i == NSP - 2), e_j = (j == NSP - 2);
+        bool ok;
+        if (i == j)  // (2,2) for the viscosity / k_e
+          ok = e_i ? (c == TPSRHS_CLMB_REP) : (c == TPSRHS_CLMB_REP || c == TPSRHS_AR_AR);
+        else if (e_i || e_j)  // (1,1..5) against electrons
+          ok = (c == TPSRHS_CLMB_ATT || c == TPSRHS_CLMB_REP || c == TPSRHS_AR_E);
+        else  // (1,1) between heavy species
+          ok = (c == TPSRHS_CLMB_ATT || c == TPSRHS_CLMB_REP || c == TPSRHS_AR_AR1P || c == TPSRHS_AR_AR);
+        if (!ok) throw Unsupported("argon mixture transport: no collision integral for a species pair of this type");
+        p.coll[i + j * NSP] = c;
+      }
+  }
   p.third_order = gt.third_order_k_electron;
   p.multiply = gt.multiply;
   for (int k = 0; k < 4; k++) p.mult_flux[k] = gt.flux_trns_multiplier[k];
@@ -158,8 +177,9 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     const tpsrhs_perfect_mixture &mx = phys->mixture;
     if (mx.num_species != 3 || !mx.is_electron_included || !mx.ambipolar)
       throw Unsupported("USER_DEFINED fluids: only the ambipolar ternary mixture (ion, electron, neutral) is built");
-    if (phys->transport_model != TPSRHS_CONSTANT && phys->transport_model != TPSRHS_ARGON_MINIMAL)
-      throw Unsupported("transport model outside the built scope (constant, argon_minimal)");
+    if (phys->transport_model != TPSRHS_CONSTANT && phys->transport_model != TPSRHS_ARGON_MINIMAL &&
+        phys->transport_model != TPSRHS_ARGON_MIXTURE)
+      throw Unsupported("transport model outside the built scope (constant, argon_minimal, argon_mixture)");
     op->neq = op->nvel + 2 + (mx.num_species - 2) + (mx.two_temperature ? 1 : 0);
   }
   op->phys = *phys;
@@ -190,7 +210,9 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
 
   if (plasma) {
     fill_plasma_params(op, disc, phys, num_bcs, bcs);
-    const int tr = (phys->transport_model == TPSRHS_CONSTANT) ? TRANSPORT_CONSTANT : TRANSPORT_ARGON_MINIMAL;
+    const int tr = (phys->transport_model == TPSRHS_CONSTANT)
+                       ? TRANSPORT_CONSTANT
+                       : (phys->transport_model == TPSRHS_ARGON_MINIMAL ? TRANSPORT_ARGON_MINIMAL : TRANSPORT_ARGON_MIXTURE);
     if (op->dim == 3)
       pick_plasma3d(op, phys->mixture.two_temperature != 0, tr);
     else if (disc->axisymmetric)
