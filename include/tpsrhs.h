@@ -87,6 +87,7 @@ enum tpsrhs_wall_type {
   TPSRHS_VISC_ISOTH = 3,
   TPSRHS_VISC_GNRL = 4
 };
+enum tpsrhs_thermal_condition { TPSRHS_ADIAB = 0, TPSRHS_ISOTH = 1, TPSRHS_SHTH = 2, TPSRHS_NONE_THMCND = 3 };
 enum tpsrhs_basis_type { TPSRHS_BASIS_GAUSS_LEGENDRE = 0, TPSRHS_BASIS_GAUSS_LOBATTO = 1 };
 
 /* ---- mesh: what the reference takes from mfem::ParMesh (src/M2ulPhyS.cpp:296-470) ------------ */
@@ -208,7 +209,9 @@ typedef struct tpsrhs_bc {
   int type;      /* tpsrhs_inlet_type | tpsrhs_outlet_type | tpsrhs_wall_type */
   /* inlet SUB_DENS_VEL: rho, u, v, w, then active species (src/inletBC.cpp:729-757)
    * outlet SUB_P:       p                                  (src/outletBC.cpp:731-737)
-   * wall VISC_ISOTH:    T_wall                             (src/wallBC.cpp:96-111) */
+   * wall VISC_ISOTH:    T_wall                             (src/wallBC.cpp:96-111)
+   * wall VISC_GNRL:     T_h, T_e, heavy thermal condition, electron thermal condition (WallData,
+   *                     src/dataStructures.hpp:564-570; tpsrhs_thermal_condition)  (src/wallBC.cpp:112-148) */
   double data[4 + TPSRHS_MAXSPECIES];
 } tpsrhs_bc;
 

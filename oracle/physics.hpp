@@ -66,6 +66,17 @@ class GasMixture {
   virtual void computeStagnantStateWithTemp(const double *stateIn, double Temp, double *stateOut) const = 0;
   virtual void modifyEnergyForPressure(const double *stateIn, double *stateOut, double p,
                                        bool modifyElectronEnergy = false) const = 0;
+  // GasMixture::modifyStateFromPrimitive, src/equation_of_state.cpp:131-140
+  void modifyStateFromPrimitive(const double *state, const BoundaryPrimitiveData &bcState, double *out) const {
+    double prim[MAXEQ];
+    GetPrimitivesFromConservatives(state, prim);
+    for (int i = 0; i < num_equation; i++)
+      if (bcState.primIdxs[i]) prim[i] = bcState.prim[i];
+    GetConservativesFromPrimitives(prim, out);
+  }
+  virtual void computeSheathBdrFlux(const double *, BoundaryViscousFluxData &) const {
+    throw std::runtime_error("sheath boundary flux needs a plasma mixture");
+  }
   virtual double GetGasConstant() const { return 0.0; }
   virtual double GetSpecificHeatRatio() const { return 0.0; }
   virtual double GetGasParams(int sp, int param) const { return 0.0; }
@@ -543,7 +554,9 @@ class BoundaryCondition {
   bool useBCinGrad;
   double inputState[4 + MAXSP];
   double wallTemp = 0.0;
+  int hvyCond = -1, elecCond = -1;
   BoundaryViscousFluxData bcFlux;
+  BoundaryPrimitiveData bcState;
 
   BoundaryCondition(const tpsrhs_bc &bc, GasMixture *m, Fluxes *f, RiemannSolver *r, bool axisym, bool bcInGrad)
       : category(bc.category), type(bc.type), mixture(m), fluxClass(f), rsolver(r), useBCinGrad(bcInGrad) {
@@ -557,6 +570,8 @@ class BoundaryCondition {
     for (int i = 0; i < MAXEQ; i++) {
       bcFlux.primFlux[i] = 0.0;
       bcFlux.primFluxIdxs[i] = false;
+      bcState.prim[i] = 0.0;
+      bcState.primIdxs[i] = false;
     }
     (void)primFluxSize;
     if (category == TPSRHS_WALL) {  // src/wallBC.cpp:65-148
@@ -577,6 +592,30 @@ class BoundaryCondition {
           for (int i = 0; i < numSpecies; i++) bcFlux.primFluxIdxs[i] = true;
           wallTemp = bc.data[0];
           break;
+        case TPSRHS_VISC_GNRL: {  // src/wallBC.cpp:112-148
+          hvyCond = static_cast<int>(bc.data[2]);
+          elecCond = static_cast<int>(bc.data[3]);
+          for (int d = 0; d < nvel; d++) bcState.primIdxs[d + 1] = true;
+          for (int i = 0; i < numSpecies; i++) bcFlux.primFluxIdxs[i] = true;
+          if (hvyCond == TPSRHS_ISOTH) {
+            bcState.prim[nvel + 1] = bc.data[0];
+            bcState.primIdxs[nvel + 1] = true;
+          } else if (hvyCond == TPSRHS_ADIAB) {
+            bcFlux.primFluxIdxs[numSpecies + nvel] = true;
+          } else {
+            throw std::runtime_error("Thermal condition not understood.");
+          }
+          if (elecCond == TPSRHS_ISOTH) {
+            bcState.prim[num_equation - 1] = bc.data[1];
+            bcState.primIdxs[num_equation - 1] = true;
+          } else if (elecCond == TPSRHS_ADIAB) {
+            bcFlux.primFluxIdxs[numSpecies + nvel + 1] = true;
+          } else if (elecCond == TPSRHS_SHTH) {
+            if (m->twoTemperature) bcFlux.primFluxIdxs[numSpecies + nvel + 1] = true;
+          } else {
+            throw std::runtime_error("Electron thermal condition not understood.");
+          }
+        } break;
         default:
           throw std::runtime_error("wall type outside the hot-path scope");
       }
@@ -680,6 +719,24 @@ class BoundaryCondition {
         for (int d = 0; d < dim; d++) normN += normal[d] * normal[d];
         for (int d = 0; d < dim; d++) bcFlux.normal[d] = normal[d] * (1. / std::sqrt(normN));
         mixture->computeStagnantStateWithTemp(stateIn, wallTemp, wallState);
+        double wallViscF[MAXEQ];
+        fluxClass->ComputeBdrViscousFluxes(wallState, gradState, transip, delta, 0.0, bcFlux, wallViscF);
+        for (int eq = 0; eq < num_equation; eq++) wallViscF[eq] *= std::sqrt(normN);
+        double viscF[MAXEQ * MAXDIM];
+        fluxClass->ComputeViscousFluxes(stateIn, gradState, transip, delta, 0.0, viscF);
+        for (int eq = 1; eq < num_equation; eq++) {
+          bdrFlux[eq] -= 0.5 * wallViscF[eq];
+          for (int d = 0; d < dim; d++) bdrFlux[eq] -= 0.5 * viscF[eq + d * num_equation] * normal[d];
+        }
+      } break;
+      case TPSRHS_VISC_GNRL: {  // src/wallBC.cpp:512-543
+        double wallState[MAXEQ];
+        mixture->modifyStateFromPrimitive(stateIn, bcState, wallState);
+        rsolver->Eval_LF(stateIn, wallState, normal, bdrFlux);
+        double normN = 0.;
+        for (int d = 0; d < dim; d++) normN += normal[d] * normal[d];
+        for (int d = 0; d < dim; d++) bcFlux.normal[d] = normal[d] * (1. / std::sqrt(normN));
+        if (elecCond == TPSRHS_SHTH) mixture->computeSheathBdrFlux(wallState, bcFlux);
         double wallViscF[MAXEQ];
         fluxClass->ComputeBdrViscousFluxes(wallState, gradState, transip, delta, 0.0, bcFlux, wallViscF);
         for (int eq = 0; eq < num_equation; eq++) wallViscF[eq] *= std::sqrt(normN);

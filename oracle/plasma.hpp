@@ -375,6 +375,32 @@ class PerfectMixture : public GasMixture {
     for (int sp = 0; sp < numSpecies - 2; sp++) rE += n_sp[sp] * GetGasParams(sp, TPSRHS_FORMATION_ENERGY);
     stateOut[iTh] = rE;
   }
+  // Bohm fluxes of a sheath edge on a fully catalytic wall, src/equation_of_state.cpp:1909-1942
+  void computeSheathBdrFlux(const double *state, BoundaryViscousFluxData &bcFlux) const override {
+    double n_sp[MAXSP], T_h, T_e;
+    computeNumberDensities(state, n_sp);
+    computeTemperaturesBase(state, n_sp, n_sp[iElectron], n_sp[iBackground], T_h, T_e);
+    for (int sp = 0; sp < numSpecies; sp++) bcFlux.primFlux[sp] = 0.0;
+    for (int sp = 0; sp < numSpecies; sp++) {
+      const double Zsp = GetGasParams(sp, TPSRHS_SPECIES_CHARGES);
+      if (Zsp > 0.0) {
+        const double msp = GetGasParams(sp, TPSRHS_SPECIES_MW);
+        const double VB = std::sqrt((T_h + Zsp * T_e) * UNIVERSALGASCONSTANT / msp);
+        bcFlux.primFlux[sp] = VB;
+        bcFlux.primFlux[iElectron] += Zsp * n_sp[sp] * VB;
+        bcFlux.primFlux[iBackground] -= msp * n_sp[sp] * VB;
+      }
+    }
+    bcFlux.primFlux[iElectron] /= n_sp[iElectron];
+    bcFlux.primFlux[iBackground] -= GetGasParams(iElectron, TPSRHS_SPECIES_MW) * n_sp[iElectron] * bcFlux.primFlux[iElectron];
+    bcFlux.primFlux[iBackground] /= GetGasParams(iBackground, TPSRHS_SPECIES_MW) * n_sp[iBackground];
+    if (twoTemperature) {
+      const double vTe = std::sqrt(8.0 * UNIVERSALGASCONSTANT * T_e / PI_ / GetGasParams(iElectron, TPSRHS_SPECIES_MW));
+      const double gamma = -std::log(4.0 / vTe * bcFlux.primFlux[iElectron]);
+      bcFlux.primFlux[numSpecies + nvel + 1] =
+          bcFlux.primFlux[iElectron] * (gamma + 2.0) * n_sp[iElectron] * UNIVERSALGASCONSTANT * T_e;
+    }
+  }
   void computeElectronPressureGrad(double n_e, double T_e, const double *gradUp, double *gradPe) const {  // :1847-1870
     double neGrad[MAXDIM] = {0, 0, 0};
     if (ambipolar) {

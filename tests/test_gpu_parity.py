@@ -144,3 +144,22 @@ def test_plasma_axisymmetric(order, two_t, transport, wall, r_in, warp):
 def test_plasma_axisymmetric_euler():
     c = cases.argon_axisym(6, 9, 2, True, capi.CONSTANT, None, False, capi.INV, r_in=0.0, eq_system=capi.EULER)
     _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=9, amp=0.01), tol=_tol(0.01))
+
+
+# ---- viscous_general walls: prescribed heavy / electron thermal conditions and the sheath fluxes ----
+@pytest.mark.parametrize("two_t,hvy,elec", [
+    (True, capi.ISOTH, capi.ISOTH), (True, capi.ADIAB, capi.SHTH), (True, capi.ISOTH, capi.ADIAB),
+    (True, capi.ISOTH, capi.SHTH), (False, capi.ISOTH, capi.SHTH), (False, capi.ADIAB, capi.SHTH),
+])
+def test_plasma_general_wall(two_t, hvy, elec):
+    c = cases.argon_cyl3d(4, 12, 3, 2, two_t, capi.CONSTANT, "arrhenius", capi.VISC_ISOTH)
+    c.bcs[2] = capi.make_bc(3, capi.WALL, capi.VISC_GNRL, [3000.0, 9000.0, hvy, elec])
+    _boost_transport(c.physics, 100.0)
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=4, amp=0.01), tol=_tol(0.01))
+
+
+def test_plasma_general_wall_axisymmetric_sheath():
+    c = cases.argon_axisym(6, 9, 3, True, capi.ARGON_MIXTURE, "arrhenius", True, capi.VISC_ISOTH, r_in=0.0)
+    c.bcs[2] = capi.make_bc(3, capi.WALL, capi.VISC_GNRL, [3000.0, 0.0, capi.ISOTH, capi.SHTH])
+    _boost_transport(c.physics, 30.0)
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=6, amp=0.01), tol=_tol(0.01))

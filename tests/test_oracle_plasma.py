@@ -188,3 +188,34 @@ def test_mixture_transport_against_the_ternary_special_case(two_t):
             assert np.isfinite(b1).all() and b1[0] > 0
             assert not np.allclose(b1, b0, rtol=1e-6)  # the Debye lengths differ
             assert np.allclose(b1, b0, rtol=0.5)       # ... through a logarithm only
+
+
+@pytest.mark.parametrize("two_t", [False, True])
+def test_sheath_wall_flux_balances(two_t):
+    """viscous_general wall with the sheath condition (src/equation_of_state.cpp:1909-1942): ions leave at
+    the Bohm speed, electrons and neutrals carry the balancing charge and mass, so the boundary flux has
+    no net mass flux and returns ions as neutrals (fully catalytic)."""
+    mesh = meshgen.box_hex(1, 1, 1, periodic=(False,) * 3)
+    ph = capi.argon_ternary_physics(capi.NS, two_t, capi.CONSTANT, None)
+    bcs = [capi.make_bc(a + 1, capi.WALL, capi.VISC_GNRL, [3000.0, 8000.0, capi.ISOTH, capi.SHTH]) for a in range(6)]
+    o = Oracle(mesh, capi.Disc(1, 0, 0, 0, 0), ph, bcs)
+    mw = [ph.mixture.gas_params[sp] for sp in range(3)]
+    for U in sample_states(ph, 3, n=6, seed=12):
+        nor = np.array([0.3, -0.2, 0.9])
+        g = np.zeros(3 * o.neq)
+        f = o.bdr_flux(1, nor, U, g)
+        # wall state: no slip, T_h = 3000 K, species densities of the interior state
+        Up = o.prim(U)
+        Upw = Up.copy()
+        Upw[1:4] = 0.0
+        Upw[4] = 3000.0
+        Uw = o.cons(Upw)
+        lf = o.lf(U, Uw, nor)
+        visc = f - lf  # -1/2 (wall viscous flux + interior viscous flux (= 0 for zero gradients))
+        nm = np.linalg.norm(nor)
+        ni = Upw[5]
+        Te = Upw[6] if two_t else 3000.0
+        VB = np.sqrt((3000.0 + Te) * R / mw[0])
+        # species equation: -1/2 * (-rho_i V_B |n|)
+        assert visc[5] == pytest.approx(0.5 * ni * mw[0] * VB * nm, rel=1e-12)
+        assert abs(visc[0]) == 0.0 and np.abs(visc[1:4]).max() < 1e-9 * abs(lf[1:4]).max()

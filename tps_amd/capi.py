@@ -30,6 +30,7 @@ INLET, OUTLET, WALL = 0, 1, 2
 SUB_DENS_VEL = 2
 SUB_P = 0
 INV, SLIP, VISC_ADIAB, VISC_ISOTH, VISC_GNRL = 0, 1, 2, 3, 4
+ADIAB, ISOTH, SHTH, NONE_THMCND = 0, 1, 2, 3  # ThermalCondition of viscous_general walls
 
 STATUS = {0: "OK", 1: "INVALID_ARGUMENT", 2: "UNSUPPORTED", 3: "MESH", 4: "DEVICE", 5: "NO_DEVICE", 6: "HALO"}
 

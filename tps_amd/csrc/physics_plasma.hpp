@@ -740,11 +740,27 @@ struct PlasmaPhys {
   // ComputeBdrViscousFluxes (src/fluxes.cpp:344-505) -- the same with zero species diffusion fluxes
   // (`zero_species`) and zero heat fluxes (`zero_heat`).  The reference evaluates the boundary variant
   // with the unit normal and rescales by |n|; the flux is linear in n, so n is used directly.
+  // Wall prescriptions of BoundaryViscousFluxData (src/dataStructures.hpp:572-590): normal diffusion
+  // velocities of all species, heavy-species heat flux, electron heat flux -- per unit area (the caller
+  // passes |n|).
+  struct WallFlux {
+    bool species, heavy_heat, electron_heat;
+    double Vn[NSP], hf, ef, nm;
+  };
+  __device__ static inline WallFlux no_prescription() {
+    WallFlux w;
+    w.species = w.heavy_heat = w.electron_heat = false;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) w.Vn[sp] = 0.0;
+    w.hf = w.ef = 0.0;
+    w.nm = 1.0;
+    return w;
+  }
   __device__ static inline void visc_normal_flux(const Params &p, const double *U, const double *g, const double *n,
-                                                 double radius, bool zero_species, bool zero_heat, double *Fn) {
+                                                 double radius, const WallFlux &w, double *Fn) {
     const State s = make_state(p, U);
     Trans t;
-    transport(p, U, s.Th, s.Te, g, !zero_species, t);
+    transport(p, U, s.Th, s.Te, g, !w.species, t);
     double h[NSP], Vn[NSP];
     enthalpies(p, s, h);
 #pragma unroll
@@ -752,7 +768,7 @@ struct PlasmaPhys {
       double a = 0.0;
 #pragma unroll
       for (int d = 0; d < DIM; d++) a += t.V[sp + d * NSP] * n[d];
-      Vn[sp] = a;  // zero when the diffusion velocities were skipped
+      Vn[sp] = w.species ? w.Vn[sp] * w.nm : a;
     }
     const double bulk = t.bulk - 2. / 3. * t.visc;
     double divV = 0.0;
@@ -780,23 +796,106 @@ struct PlasmaPhys {
       Fn[1 + 2] = tn;
       e += tn * s.vel[2];
     }
-    double qh = 0.0, qe = 0.0;  // k grad T . n
-    if (!zero_heat) {
+    // heat fluxes in the reference's "primitive flux" sense (src/fluxes.cpp:468-482):
+    // HF = -k grad T_h . n + sum_{heavy} h V_n,  EF = -k_e grad T_e . n + h_e V_n,e  (two-temperature)
+    double HF = 0.0, EF = 0.0;
+    if (w.heavy_heat) {
+      HF = w.hf * w.nm;
+    } else {
       const double k = TWOT ? t.k : t.k + t.ke;
 #pragma unroll
-      for (int d = 0; d < DIM; d++) qh += k * g[ITH + d * NEQ] * n[d];
-      if (TWOT) {
+      for (int d = 0; d < DIM; d++) HF -= k * g[ITH + d * NEQ] * n[d];
 #pragma unroll
-        for (int d = 0; d < DIM; d++) qe += t.ke * g[ITE + d * NEQ] * n[d];
+      for (int sp = 0; sp < NSP; sp++)
+        if (!(TWOT && sp == IE)) HF += h[sp] * Vn[sp];
+    }
+    if (TWOT) {
+      if (w.electron_heat) {
+        EF = w.ef * w.nm;
+      } else {
+#pragma unroll
+        for (int d = 0; d < DIM; d++) EF -= t.ke * g[ITE + d * NEQ] * n[d];
+        EF += h[IE] * Vn[IE];
       }
     }
-    e += qh + qe;
-#pragma unroll
-    for (int sp = 0; sp < NSP; sp++) e -= h[sp] * Vn[sp];
-    Fn[ITH] = e;
+    Fn[ITH] = e - HF - EF;
 #pragma unroll
     for (int sp = 0; sp < NACTIVE; sp++) Fn[NVEL + 2 + sp] = -U[NVEL + 2 + sp] * Vn[sp];
-    if (TWOT) Fn[ITE] = qe - h[IE] * Vn[IE];
+    if (TWOT) Fn[ITE] = -EF;
+  }
+  // GetConservativesFromPrimitives, src/equation_of_state.cpp:744-783
+  __device__ static inline void cons(const Params &p, const double *Up, double *U) {
+    U[0] = Up[0];
+    double ke = 0.0;
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) {
+      U[1 + d] = Up[1 + d] * Up[0];
+      ke += Up[1 + d] * Up[1 + d];
+    }
+    ke *= 0.5 * Up[0];
+    double n[NSP], rhoB = Up[0], ne = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) n[sp] = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) {
+      n[sp] = Up[NVEL + 2 + sp];
+      U[NVEL + 2 + sp] = n[sp] * p.mw[sp];
+      rhoB -= p.mw[sp] * n[sp];
+      if (AMBI) ne += p.charge[sp] * n[sp];
+    }
+    if (AMBI) {
+      ne = fmax(ne, 0.0);
+      rhoB -= ne * p.mw[IE];
+      n[IE] = ne;
+    }
+    n[IB] = rhoB / p.mw[IB];
+    double ctot = heavies_cv(p, n);
+    if (!TWOT) ctot += n[IE] * p.cv[IE];
+    double e = ke + ctot * Up[ITH];
+    if (TWOT) {
+      U[ITE] = n[IE] * p.cv[IE] * Up[ITE];
+      e += U[ITE];
+    }
+#pragma unroll
+    for (int sp = 0; sp < NSP - 2; sp++) e += Up[NVEL + 2 + sp] * p.eform[sp];
+    U[ITH] = e;
+  }
+  // VISC_GNRL wall state: modifyStateFromPrimitive with no slip and the prescribed temperatures
+  // (src/wallBC.cpp:112-148, src/equation_of_state.cpp:131-140); data = {T_h, T_e, heavy cond, electron cond}
+  __device__ static inline void general_wall_state(const Params &p, const BcDev &bc, const double *U, double *Uw) {
+    double up[NEQ];
+    prim(p, U, up);
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) up[1 + d] = 0.0;
+    if (static_cast<int>(bc.data[2]) == TPSRHS_ISOTH) up[ITH] = bc.data[0];
+    if (static_cast<int>(bc.data[3]) == TPSRHS_ISOTH) up[NEQ - 1] = bc.data[1];
+    cons(p, up, Uw);
+  }
+  // computeSheathBdrFlux, src/equation_of_state.cpp:1909-1942: Bohm velocities of the positive ions,
+  // the electron and background fluxes that balance them, the electron energy flux through the sheath
+  __device__ static inline void sheath(const Params &p, const double *Uw, WallFlux &w) {
+    const State s = make_state(p, Uw);
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) w.Vn[sp] = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) {
+      if (sp == IE || sp == IB) continue;  // the electron is negative, the background neutral
+      const double Z = p.charge[sp];
+      if (Z > 0.0) {
+        const double VB = sqrt((s.Th + Z * s.Te) * kRgas / p.mw[sp]);
+        w.Vn[sp] = VB;
+        w.Vn[IE] += Z * s.n[sp] * VB;
+        w.Vn[IB] -= p.mw[sp] * s.n[sp] * VB;
+      }
+    }
+    w.Vn[IE] /= s.n[IE];
+    w.Vn[IB] -= p.mw[IE] * s.n[IE] * w.Vn[IE];
+    w.Vn[IB] /= p.mw[IB] * s.n[IB];
+    if (TWOT) {
+      const double vTe = sqrt(8.0 * kRgas * s.Te / kPi / p.mw[IE]);
+      const double gam = -log(4.0 / vTe * w.Vn[IE]);
+      w.ef = w.Vn[IE] * (gam + 2.0) * s.n[IE] * kRgas * s.Te;
+    }
   }
 
   // ---- boundary conditions ------------------------------------------------------------------
@@ -877,6 +976,8 @@ struct PlasmaPhys {
         Ug[1 + d] = 0.0;
       }
       Ug[ITH] = U[ITH] - ke;
+    } else if (bc.type == TPSRHS_VISC_GNRL) {  // src/wallBC.cpp:514-518
+      general_wall_state(p, bc, U, Ug);
     } else {  // VISC_ISOTH, src/wallBC.cpp:471-485
       if (p.use_bc_in_grad) {
 #pragma unroll
@@ -910,7 +1011,7 @@ struct PlasmaPhys {
       double Us[NEQ];
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) Us[eq] = U[eq];
-      bool zs = false, zh = false;
+      WallFlux w = no_prescription();
       if (pass == 1) {  // the wall-side state
         double ke = 0.0;
 #pragma unroll
@@ -928,14 +1029,26 @@ struct PlasmaPhys {
 #pragma unroll
           for (int d = 0; d < NVEL; d++) Us[1 + d] = 0.0;
           Us[ITH] = U[ITH] - ke;
-          zs = zh = true;
-        } else {
+          w.species = w.heavy_heat = w.electron_heat = true;
+        } else if (type == TPSRHS_VISC_ISOTH) {
           stagnant_with_temp(p, U, twall, Us);
-          zs = true;
+          w.species = true;
+        } else {  // VISC_GNRL, src/wallBC.cpp:512-543
+          const BcDev &bc = p.bc[-nb - 1];
+          general_wall_state(p, bc, U, Us);
+          const int hc = static_cast<int>(bc.data[2]), ec = static_cast<int>(bc.data[3]);
+          w.species = true;
+          w.heavy_heat = (hc == TPSRHS_ADIAB);
+          w.electron_heat = TWOT && (ec == TPSRHS_ADIAB || ec == TPSRHS_SHTH);
+          double nm = 0.0;
+#pragma unroll
+          for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
+          w.nm = sqrt(nm);
+          if (ec == TPSRHS_SHTH) sheath(p, Us, w);
         }
       }
       double f[NEQ];
-      visc_normal_flux(p, Us, g, n, radius, zs, zh, f);
+      visc_normal_flux(p, Us, g, n, radius, w, f);
       if (nb >= 0) {
 #pragma unroll
         for (int eq = 0; eq < NEQ; eq++) fn[eq] = f[eq];

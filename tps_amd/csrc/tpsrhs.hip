@@ -166,8 +166,22 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     const bool ok = (b.category == TPSRHS_INLET && b.type == TPSRHS_SUB_DENS_VEL) ||
                     (b.category == TPSRHS_OUTLET && b.type == TPSRHS_SUB_P) ||
                     (b.category == TPSRHS_WALL &&
-                     (b.type == TPSRHS_INV || b.type == TPSRHS_VISC_ADIAB || b.type == TPSRHS_VISC_ISOTH));
+                     (b.type == TPSRHS_INV || b.type == TPSRHS_VISC_ADIAB || b.type == TPSRHS_VISC_ISOTH ||
+                      (b.type == TPSRHS_VISC_GNRL && plasma)));
     if (!ok) throw Unsupported("boundary condition type outside the hot-path scope (attribute " + std::to_string(b.attribute) + ")");
+    if (b.category == TPSRHS_WALL && b.type == TPSRHS_VISC_GNRL) {
+      // the combinations the reference's input parser lets through (src/M2ulPhyS.cpp:3515-3582)
+      const int hc = static_cast<int>(b.data[2]), ec = static_cast<int>(b.data[3]);
+      const bool two_t = phys->mixture.two_temperature != 0;
+      const bool hvy_ok = (hc == TPSRHS_ISOTH || hc == TPSRHS_ADIAB);
+      const bool elec_ok = two_t ? (ec == TPSRHS_ISOTH || ec == TPSRHS_ADIAB || ec == TPSRHS_SHTH) : (ec == TPSRHS_SHTH);
+      if (!hvy_ok) throw std::invalid_argument("viscous_general wall: heavy thermal condition must be isothermal or adiabatic");
+      if (!elec_ok)
+        throw std::invalid_argument("viscous_general wall: electron thermal condition not understood "
+                                    "(single-temperature plasmas accept the sheath condition only)");
+      if (ec == TPSRHS_SHTH && !phys->mixture.ambipolar)
+        throw std::invalid_argument("viscous_general wall: plasma must be ambipolar for the sheath condition");
+    }
   }
   op->dim = mesh->dim;
   op->order = disc->order;
