@@ -163,3 +163,14 @@ def test_plasma_general_wall_axisymmetric_sheath():
     c.bcs[2] = capi.make_bc(3, capi.WALL, capi.VISC_GNRL, [3000.0, 0.0, capi.ISOTH, capi.SHTH])
     _boost_transport(c.physics, 30.0)
     _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=6, amp=0.01), tol=_tol(0.01))
+
+
+@pytest.mark.parametrize("order,eq,wall,r_in,warp", [
+    (3, capi.NS, capi.VISC_ISOTH, 0.0, 0.0), (2, capi.NS, capi.VISC_ADIAB, 0.01, 0.06), (1, capi.EULER, capi.INV, 0.02, 0.06),
+    (4, capi.NS, capi.INV, 0.0, 0.0),
+])
+def test_dry_air_axisymmetric(order, eq, wall, r_in, warp):
+    c = cases.dry_air_axisym(6, 9, order, eq, wall, r_in=r_in, warp=warp)
+    c.physics.dry_air.visc_mult = 200.0
+    c.physics.dry_air.bulk_visc_mult = 1.5
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=3 + order))

@@ -30,10 +30,12 @@ class Case:
             if self.disc.axisymmetric:
                 return plasma_state(X, self.physics, nvel=3, seed=seed, amp=amp, vel0=(1.0, 20.0, 3.0))
             return plasma_state(X, self.physics, nvel=X.shape[0], seed=seed, amp=amp)
+        if self.disc.axisymmetric:
+            return dry_air_state(X, seed=seed, amp=amp, vel0=(1.0, 20.0, 3.0), nvel=3)
         return dry_air_state(X, seed=seed, amp=amp)
 
 
-def dry_air_state(X, seed=12345, amp=0.05, rho0=1.2, vel0=(20.0, 0.0, 0.0), p0=101300.0, gamma=1.4):
+def dry_air_state(X, seed=12345, amp=0.05, rho0=1.2, vel0=(20.0, 0.0, 0.0), p0=101300.0, gamma=1.4, nvel=None):
     """Conserved state (neq, NDofs): free stream with `amp` smooth sinusoidal perturbations of every
     primitive (seeded phases / wave vectors, functions of the physical coordinates only)."""
     rng = np.random.Generator(np.random.MT19937(seed))
@@ -45,17 +47,18 @@ def dry_air_state(X, seed=12345, amp=0.05, rho0=1.2, vel0=(20.0, 0.0, 0.0), p0=1
         ph = rng.uniform(0.0, 2.0 * np.pi)
         return np.sin(np.tensordot(k, X, axes=(0, 0)) + ph)
 
+    nvel = nvel or dim
     rho = rho0 * (1.0 + amp * wave())
-    vref = max(abs(v) for v in vel0[:dim]) or 1.0
-    vel = [vel0[d] + amp * vref * wave() for d in range(dim)]
+    vref = max(abs(v) for v in vel0[:nvel]) or 1.0
+    vel = [vel0[d] + amp * vref * wave() for d in range(nvel)]
     p = p0 * (1.0 + amp * wave())
-    U = np.zeros((dim + 2, X.shape[1]))
+    U = np.zeros((nvel + 2, X.shape[1]))
     U[0] = rho
     ke = 0.0
-    for d in range(dim):
+    for d in range(nvel):
         U[1 + d] = rho * vel[d]
         ke = ke + 0.5 * rho * vel[d] ** 2
-    U[dim + 1] = p / (gamma - 1.0) + ke
+    U[nvel + 1] = p / (gamma - 1.0) + ke
     return U
 
 
@@ -185,6 +188,20 @@ def argon_axisym(nr, nz, order, two_temperature=True, transport=capi.CONSTANT, r
            capi.make_bc(3, capi.WALL, wall_type, [3000.0]), capi.make_bc(4, capi.WALL, capi.INV)]
     return Case(name or f"argon_axisym_{nr}x{nz}_p{order}", mesh, capi.Disc(order, 0, 0, 1, 0), ph, bcs,
                 "axisymmetric argon ternary plasma")
+
+
+def dry_air_axisym(nr, nz, order, eq_system=capi.NS, wall_type=capi.VISC_ISOTH, r_in=0.0, r_out=0.05, length=0.25,
+                   warp=0.0, name=None):
+    """Axisymmetric pipe in dry air (the shape of the reference's pipe.axisym inputs): patch 1 inlet at z = 0,
+    2 outlet, 3 outer wall, 4 axis (inviscid wall)."""
+    attrs = {(0, 0): 4, (0, 1): 3, (1, 0): 1, (1, 1): 2}
+    mesh = meshgen.box_quad(nr, nz, lengths=(r_out - r_in, length), periodic=(False, False), bdr_attr=attrs, warp=warp,
+                            origin=(r_in, 0.0))
+    bcs = [capi.make_bc(1, capi.INLET, capi.SUB_DENS_VEL, [1.2, 0.0, 20.0, 2.0]),
+           capi.make_bc(2, capi.OUTLET, capi.SUB_P, [101300.0]), capi.make_bc(3, capi.WALL, wall_type, [300.0]),
+           capi.make_bc(4, capi.WALL, capi.INV)]
+    return Case(name or f"dry_air_axisym_{nr}x{nz}_p{order}", mesh, capi.Disc(order, 0, 0, 1, 0),
+                capi.dry_air_physics(eq_system), bcs, "axisymmetric dry air")
 
 
 def cylinder_bcs(wall_type=capi.VISC_ISOTH, t_wall=300.0, dim=3):

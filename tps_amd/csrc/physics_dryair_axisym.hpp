@@ -1,0 +1,236 @@
+// Device point-wise physics: dry air in the AXISYMMETRIC formulation (dim 2, velocity components
+// r, z, theta).  Same closures as physics_dryair.hpp plus the 1/r terms; kept apart from the tuned
+// planar / 3-D class, with the "heavy" kernel interface (visc_trace, total_flux with a radius,
+// axisym_source).
+//   DryAir             src/equation_of_state.cpp:150-412
+//   DryAirTransport    src/transport_properties.cpp:205-276
+//   Fluxes             src/fluxes.cpp:135-505 (axisymmetric branches :286-313,441-466)
+//   AxisymmetricSource src/forcing_terms.cpp:293-380
+//   boundary ghosts    src/inletBC.cpp:729-757, src/outletBC.cpp:731-737, src/wallBC.cpp:277-510
+#ifndef TPSRHS_PHYSICS_DRYAIR_AXISYM_HPP_
+#define TPSRHS_PHYSICS_DRYAIR_AXISYM_HPP_
+
+#include "physics_dryair.hpp"
+
+namespace tpsrhs {
+
+struct DryAirAxiPhys {
+  static constexpr int DIM = 2, NVEL = 3, NEQ = 5, NACTIVE = 0, ITH = 4;
+  static constexpr bool HAS_SOURCE = true, HAS_FLUX_DOT = false, AXISYM = true, HEAVY = true;
+  static constexpr int MINW_GRAD = 1, MINW_FLUX = 2;
+  typedef DryAirParams Params;
+  struct State {
+    double ir, k, p;
+    double vel[NVEL];
+  };
+  __device__ static inline State make_state(const Params &p, const double *U) {
+    State s;
+    s.ir = fast_rcp(U[0]);
+    double m2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) {
+      m2 += U[1 + d] * U[1 + d];
+      s.vel[d] = U[1 + d] * s.ir;
+    }
+    s.k = m2 * s.ir;
+    s.p = (p.gamma - 1.0) * (U[ITH] - 0.5 * s.k);
+    return s;
+  }
+  __device__ static inline void prim(const Params &p, const double *U, double *Up) {
+    const State s = make_state(p, U);
+    Up[0] = U[0];
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) Up[1 + d] = s.vel[d];
+    Up[ITH] = s.p * p.inv_Rg * s.ir;
+  }
+  __device__ static inline void clamp_species(double *) {}
+  __device__ static inline double max_char_speed(const Params &p, const double *, const State &s) {
+    return fast_sqrt(s.k * s.ir) + fast_sqrt(p.gamma * s.p * s.ir);
+  }
+  __device__ static inline void conv_flux_n(const double *U, const State &s, const double *n, double *Fn) {
+    const double un = s.vel[0] * n[0] + s.vel[1] * n[1];
+    Fn[0] = U[0] * un;
+    Fn[1] = U[1] * un + s.p * n[0];
+    Fn[2] = U[2] * un + s.p * n[1];
+    Fn[3] = U[3] * un;
+    Fn[ITH] = un * (U[ITH] + s.p);
+  }
+  __device__ static inline void lax_friedrichs(const Params &p, const double *U1, const double *U2, const double *n,
+                                               double *F) {
+    const State s1 = make_state(p, U1), s2 = make_state(p, U2);
+    const double lam = fmax(max_char_speed(p, U1, s1), max_char_speed(p, U2, s2));
+    double f1[NEQ], f2[NEQ];
+    conv_flux_n(U1, s1, n, f1);
+    conv_flux_n(U2, s2, n, f2);
+    const double hl = 0.5 * lam * fast_sqrt(n[0] * n[0] + n[1] * n[1]);
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) F[eq] = 0.5 * (f1[eq] + f2[eq]) - hl * (U2[eq] - U1[eq]);
+  }
+  // Sutherland viscosity, bulk viscosity and conductivity at the temperature of a conserved state
+  __device__ static inline void transport(const Params &p, const State &s, double &visc, double &bulk, double &k) {
+    const double T = s.p * p.inv_Rg * s.ir;
+    visc = p.C1 * p.visc_mult * T * fast_sqrt(T) / (T + p.S0);
+    bulk = p.bulk_mult * visc;
+    k = p.cp_div_pr * visc;
+  }
+  // Fv(U, g) . n with the axisymmetric stresses; `zero_heat` drops the conduction term (adiabatic wall)
+  __device__ static inline void visc_normal_flux(const Params &p, const double *U, const double *g, const double *n,
+                                                 double radius, bool zero_heat, double *Fn) {
+    const State s = make_state(p, U);
+    double visc, bulkv, k;
+    transport(p, s, visc, bulkv, k);
+    const double bulk = bulkv - 2. / 3. * visc;
+    double divV = g[1 + 0 * NEQ] + g[2 + 1 * NEQ];
+    if (radius > 0) divV += s.vel[0] / radius;
+    double e = 0.0;
+    Fn[0] = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) {
+      double sn = 0.0;
+#pragma unroll
+      for (int j = 0; j < DIM; j++) {
+        double st = visc * (g[(1 + j) + i * NEQ] + g[(1 + i) + j * NEQ]);
+        if (i == j) st += bulk * divV;
+        sn += st * n[j];
+      }
+      Fn[1 + i] = sn;
+      e += sn * s.vel[i];
+    }
+    double ttr = g[3 + 0 * NEQ];
+    if (radius > 0) ttr -= s.vel[2] / radius;
+    const double tn = visc * (ttr * n[0] + g[3 + 1 * NEQ] * n[1]);
+    Fn[3] = tn;
+    e += tn * s.vel[2];
+    if (!zero_heat) e += k * (g[ITH + 0 * NEQ] * n[0] + g[ITH + 1 * NEQ] * n[1]);
+    Fn[ITH] = e;
+  }
+  __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const double *g,
+                                           double radius, double *F) {
+    const double H = U[ITH] + s.p;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      F[0 + d * NEQ] = U[1 + d];
+#pragma unroll
+      for (int i = 0; i < NVEL; i++) F[1 + i + d * NEQ] = U[1 + i] * s.vel[d] + (i == d ? s.p : 0.0);
+      F[ITH + d * NEQ] = s.vel[d] * H;
+    }
+    if (p.eq_system == TPSRHS_EULER) return;
+    // F_c - F_v: the viscous flux along each coordinate direction is its normal flux with n = e_d
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      const double nd[DIM] = {d == 0 ? 1.0 : 0.0, d == 1 ? 1.0 : 0.0};
+      double fv[NEQ];
+      visc_normal_flux(p, U, g, nd, radius, false, fv);
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) F[eq + d * NEQ] -= fv[eq];
+    }
+  }
+  __device__ static inline void bc_ghost(const Params &p, const BcDev &bc, const double *U, const double *n,
+                                         double *Ug) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) Ug[eq] = U[eq];
+    const State s = make_state(p, U);
+    if (bc.category == TPSRHS_INLET) {  // modifyEnergyForPressure with the interior pressure
+      Ug[0] = bc.data[0];
+      double ke = 0.0;
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) {
+        Ug[1 + d] = bc.data[0] * bc.data[1 + d];
+        ke += 0.5 * Ug[1 + d] * Ug[1 + d] / Ug[0];
+      }
+      Ug[ITH] = s.p / (p.gamma - 1.0) + ke;
+    } else if (bc.category == TPSRHS_OUTLET) {
+      Ug[ITH] = bc.data[0] / (p.gamma - 1.0) + 0.5 * s.k;
+    } else if (bc.type == TPSRHS_INV) {
+      const double nm = sqrt(n[0] * n[0] + n[1] * n[1]);
+      const double vn = s.vel[0] * (n[0] / nm) + s.vel[1] * (n[1] / nm);
+#pragma unroll
+      for (int d = 0; d < DIM; d++) Ug[1 + d] = U[0] * (s.vel[d] - 2.0 * vn * (n[d] / nm));
+    } else if (bc.type == TPSRHS_VISC_ADIAB) {  // computeStagnationState, src/equation_of_state.cpp:367-378
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) Ug[1 + d] = 0.0;
+      Ug[ITH] = s.p / (p.gamma - 1.0);
+    } else {  // VISC_ISOTH
+      if (p.use_bc_in_grad) {
+#pragma unroll
+        for (int d = 0; d < NVEL; d++) Ug[1 + d] = -U[1 + d];
+      } else {
+#pragma unroll
+        for (int d = 0; d < NVEL; d++) Ug[1 + d] = 0.0;
+        Ug[ITH] = p.Rg / (p.gamma - 1.0) * U[0] * bc.data[0];
+      }
+    }
+  }
+  // the viscous trace of one face quadrature point (see PlasmaPhys::visc_trace)
+  __device__ static inline void visc_trace(const Params &p, int nb, const double *U, const double *g, const double *n,
+                                           double radius, double *fn) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) fn[eq] = 0.0;
+    if (p.eq_system == TPSRHS_EULER) return;
+    if (nb >= 0) {
+      visc_normal_flux(p, U, g, n, radius, false, fn);
+      return;
+    }
+    const BcDev &bc = p.bc[-nb - 1];
+    if (bc.category != TPSRHS_WALL) return;
+    double Uw[NEQ], f[NEQ];
+    bool adiabatic = false;
+    if (bc.type == TPSRHS_INV) {
+      bc_ghost(p, bc, U, n, Uw);
+    } else {
+      const State s = make_state(p, U);
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) Uw[eq] = U[eq];
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) Uw[1 + d] = 0.0;
+      if (bc.type == TPSRHS_VISC_ADIAB) {
+        Uw[ITH] = s.p / (p.gamma - 1.0);
+        adiabatic = true;
+      } else {
+        Uw[ITH] = p.Rg / (p.gamma - 1.0) * U[0] * bc.data[0];
+      }
+    }
+    visc_normal_flux(p, Uw, g, n, radius, adiabatic, f);
+#pragma unroll
+    for (int eq = 1; eq < NEQ; eq++) fn[eq] = -0.5 * f[eq];
+    visc_normal_flux(p, U, g, n, radius, false, f);
+#pragma unroll
+    for (int eq = 1; eq < NEQ; eq++) fn[eq] -= 0.5 * f[eq];
+  }
+  __device__ static inline void bc_grad_prim(const Params &p, const BcDev &bc, const double *Up, double *UpB) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) UpB[eq] = Up[eq];
+    if (p.use_bc_in_grad && bc.category == TPSRHS_WALL && bc.type == TPSRHS_VISC_ISOTH) {
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) UpB[1 + d] = 0.0;
+      UpB[ITH] = bc.data[0];
+    }
+  }
+  __device__ static inline void source(const Params &, const double *, const double *, const double *, double *src) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) src[eq] = 0.0;
+  }
+  __device__ static inline void axisym_source(const Params &p, const double *U, const double *Up, const double *g,
+                                              double radius, double *src) {
+    const double rho = Up[0], ur = Up[1], ut = Up[3];
+    const double pres = p.Rg * Up[0] * Up[ITH];  // DryAir::ComputePressureFromPrimitives
+    double tau_tt = 0.0, tau_tr = 0.0;
+    if (p.eq_system != TPSRHS_EULER) {
+      double visc, bulkv, k;
+      transport(p, make_state(p, U), visc, bulkv, k);  // GetViscosities, src/transport_properties.cpp:268-276
+      const double bulk = bulkv - 2. / 3. * visc;
+      double divV = g[1 + 0 * NEQ] + g[2 + 1 * NEQ];
+      if (radius > 0) divV += ur / radius;
+      tau_tt = (radius > 0) ? 2.0 * ur / radius * visc : 0.0;
+      tau_tt += bulk * divV;
+      tau_tr = g[3 + 0 * NEQ];
+      if (radius > 0) tau_tr -= ut / radius;
+      tau_tr *= visc;
+    }
+    src[1] += (pres + rho * ut * ut - tau_tt) / radius;
+    src[3] += (-rho * ur * ut + tau_tr) / radius;
+  }
+};
+
+}  // namespace tpsrhs
+#endif

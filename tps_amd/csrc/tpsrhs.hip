@@ -14,6 +14,7 @@
 void pick_plasma3d(tpsrhs_operator *op, bool two_temperature, int transport);
 void pick_plasma2d(tpsrhs_operator *op, bool two_temperature, int transport);
 void pick_plasma_axisym(tpsrhs_operator *op, bool two_temperature, int transport);
+void pick_dryair_axisym(tpsrhs_operator *op);
 
 static thread_local std::string g_last_error;
 
@@ -156,8 +157,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     throw Unsupported(
         "only the collocated Gauss-Legendre basis + Gauss-Legendre rule (basisType 0, integrationRule 0) is built");
   const bool plasma = phys->working_fluid == TPSRHS_USER_DEFINED;
-  if (disc->axisymmetric && (!plasma || mesh->dim != 2))
-    throw Unsupported("the axisymmetric formulation is built for USER_DEFINED (plasma) fluids on 2-D meshes");
+  if (disc->axisymmetric && mesh->dim != 2) throw std::invalid_argument("the axisymmetric formulation needs a 2-D mesh");
   if (phys->working_fluid != TPSRHS_DRY_AIR && !plasma) throw Unsupported("WorkingFluid::LTE_FLUID is out of scope");
   if (phys->eq_system != TPSRHS_EULER && phys->eq_system != TPSRHS_NS) throw Unsupported("NS_PASSIVE is out of scope");
   if (num_bcs > (plasma ? PLASMA_MAXBC : MAXBC)) throw Unsupported("too many boundary conditions");
@@ -186,7 +186,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   op->dim = mesh->dim;
   op->order = disc->order;
   op->nvel = disc->axisymmetric ? 3 : op->dim;
-  op->neq = op->dim + 2;
+  op->neq = op->nvel + 2;
   if (plasma) {
     const tpsrhs_perfect_mixture &mx = phys->mixture;
     if (mx.num_species != 3 || !mx.is_electron_included || !mx.ambipolar)
@@ -254,6 +254,8 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     }
     if (op->dim == 3)
       pick_order<3, DryAirPhys<3>>(op);
+    else if (disc->axisymmetric)
+      pick_dryair_axisym(op);
     else
       pick_order<2, DryAirPhys<2>>(op);
   }
