@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--nz", type=int, default=16)
     ap.add_argument("--order", type=int, default=0, help="override the workload's polynomial order")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "argon_p3", "cfg5"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu rehearses the multi-rank path on a one-GPU box (traces staged via host)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="N=1 only: skip the secondary workloads reported under other_workloads")
@@ -137,11 +140,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     halo = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
         halo = HaloExchange(device=torch.device("cuda", local_rank))
 
     def barrier():
@@ -183,7 +191,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=op.device)
+            t = torch.tensor([dt], dtype=torch.float64, device=op.device if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         ktimes = op.kernel_times()  # ms, averaged over the timed Mults

@@ -35,6 +35,7 @@ class HaloExchange:
         self.host_buffers = host_buffers  # True: pointers handed to callback are HOST memory (CPU rehearsal)
         self.bytes_sent = 0
         self.calls = 0
+        self._plans = {}
 
     def _view(self, ptr, n):
         if self.host_buffers:
@@ -59,27 +60,35 @@ class HaloExchange:
             return 1
 
     def _exchange(self, send, recv, nnbr, ranks, send_off, recv_off):
-        ops, stage = [], []
-        for r in range(nnbr):
-            ns = send_off[r + 1] - send_off[r]
-            nr = recv_off[r + 1] - recv_off[r]
-            s = self._view(send + 8 * send_off[r], ns)
-            t = self._view(recv + 8 * recv_off[r], nr)
-            peer = ranks[r]
-            if self.backend == "nccl" or self.host_buffers:
-                ops.append(dist.P2POp(dist.isend, s, peer, self.group))
-                ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
-            else:  # device buffers over a CPU backend: stage through host
-                hs = s.cpu()
-                ht = torch.empty(nr, dtype=torch.float64)
-                stage.append((t, ht))
-                ops.append(dist.P2POp(dist.isend, hs, peer, self.group))
-                ops.append(dist.P2POp(dist.irecv, ht, peer, self.group))
-            self.bytes_sent += 8 * ns
+        key = (send, recv, nnbr, send_off[nnbr], recv_off[nnbr])
+        cached = self._plans.get(key)
+        if cached is None:  # the buffers of an operator never move: build the views and P2P ops once
+            ops, stage, nbytes = [], [], 0
+            for r in range(nnbr):
+                ns = send_off[r + 1] - send_off[r]
+                nr = recv_off[r + 1] - recv_off[r]
+                s = self._view(send + 8 * send_off[r], ns)
+                t = self._view(recv + 8 * recv_off[r], nr)
+                peer = ranks[r]
+                if self.backend == "nccl" or self.host_buffers:
+                    ops.append(dist.P2POp(dist.isend, s, peer, self.group))
+                    ops.append(dist.P2POp(dist.irecv, t, peer, self.group))
+                else:  # device buffers over a CPU backend: stage through pinned host copies
+                    hs = torch.empty(ns, dtype=torch.float64)
+                    ht = torch.empty(nr, dtype=torch.float64)
+                    stage.append((s, hs, t, ht))
+                    ops.append(dist.P2POp(dist.isend, hs, peer, self.group))
+                    ops.append(dist.P2POp(dist.irecv, ht, peer, self.group))
+                nbytes += 8 * ns
+            cached = self._plans[key] = (ops, stage, nbytes)
+        ops, stage, nbytes = cached
+        for s, hs, _, _ in stage:
+            hs.copy_(s)  # synchronises with the communication stream
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        for t, ht in stage:
+        for _, _, t, ht in stage:
             t.copy_(ht)
+        self.bytes_sent += nbytes
         self.calls += 1
         return 0
