@@ -371,6 +371,33 @@ __device__ inline void project2_lines(const double *RW, double *L, const Tables1
   }
 }
 // lifting of the pair's two faces to a volume node: b0(idx_D) L[pf=2le] + b1(idx_D) L[pf=2le+1]
+// area-weighted normal of face (D, s) at tangential reference coordinates (ta, tb) (tb unused in 2-D)
+template <class C, int D>
+__device__ inline void face_normal_at(const double *V, int s, double ta, double tb, double *n) {
+  if (C::DIM == 2) {
+    constexpr int a = 1 - D;
+    const int c0 = (s << D), c1 = (s << D) | (1 << a);
+    const double tx = V[c1 * 2 + 0] - V[c0 * 2 + 0], ty = V[c1 * 2 + 1] - V[c0 * 2 + 1];
+    const double sg = (s ? 1.0 : -1.0) * (D == 0 ? 1.0 : -1.0);
+    n[0] = sg * ty;
+    n[1] = -sg * tx;
+  } else {
+    constexpr int a = tan_a<C>(D), b = tan_b<C>(D);
+    const int c00 = (s << D), c10 = c00 | (1 << a), c01 = c00 | (1 << b), c11 = c10 | (1 << b);
+    double va[3], vb[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double p00 = V[c00 * 3 + i], p10 = V[c10 * 3 + i], p01 = V[c01 * 3 + i], p11 = V[c11 * 3 + i];
+      const double ea0 = p10 - p00, ea1 = p11 - p01, eb0 = p01 - p00, eb1 = p11 - p10;
+      va[i] = ea0 + tb * (ea1 - ea0);
+      vb[i] = eb0 + ta * (eb1 - eb0);
+    }
+    const double sg = (s ? 1.0 : -1.0) * (D == 1 ? -1.0 : 1.0);
+    n[0] = sg * (va[1] * vb[2] - va[2] * vb[1]);
+    n[1] = sg * (va[2] * vb[0] - va[0] * vb[2]);
+    n[2] = sg * (va[0] * vb[1] - va[1] * vb[0]);
+  }
+}
 template <class C, int D>
 __device__ inline double lift_pair(const double *Lf, const Tab<C> &tab, int le, const int *idx) {
   const int fn = (C::DIM == 2) ? idx[tan_a<C>(D)] : idx[tan_a<C>(D)] + C::N1 * idx[tan_b<C>(D)];
@@ -549,13 +576,72 @@ struct GradLds {
   static constexpr int NVF = NEQ * (1 + DIM);  // fields interpolated for the viscous traces: U, gradUp
   static constexpr int CH = 2 * NEQ;           // ... CH at a time
   // X: T (2 NEQ fields) | R (NEQ*DIM fields) | L (NEQ*DIM fields); Y: W (2 NEQ) | W2 (NEQ*DIM) | R in 2-D
+#ifdef TPSRHS_JUMP_QUADRATURE
   static constexpr int X_JUMP = cmax(cmax(2 * NEQ * C::TN, NEQ * DIM * C::TQ), NEQ * DIM * C::TN);
   static constexpr int Y = cmax(cmax(2 * NEQ * C::TW, NEQ * DIM * C::TW), (DIM == 2) ? NEQ * DIM * C::TQ : 0);
+#else
+  static constexpr int X_JUMP = DIM * 2 * NEQ * C::TN;  // own | neighbour Up traces of every direction pair
+  static constexpr int Y = CH * C::TW;                   // W chunk of the viscous phase
+#endif
   static constexpr int SG = cmax(NEQ * DIM * C::NODES, X_JUMP);  // sG, hosting X during the jump phase
   static constexpr int SUP = cmax(NEQ * C::NODES, CH * C::TN);   // sUp, hosting T during the viscous phase
   static constexpr int O_U = 0, O_UP = NEQ * C::NODES, O_G = O_UP + SUP, O_Y = O_G + SG;
   static constexpr int TOTAL = O_Y + Y;
 };
+
+// Gradient jump of one direction pair, collocated: g += M^-1 sum_faces <phi, (u^ - u) n>.
+//
+// The reference integrates this face term with the (p+2)-point face rule (src/faceGradientIntegration.cpp:
+// 40-140): sum_q w_q phi_j(q) 1/2 (Up2 - Up1)(q) N(q).  On a bilinear face the integrand is a polynomial
+// of degree <= p (phi_j) + p (the jump of two degree-p traces) + 1 (the area-weighted normal N of a
+// bilinear patch) = 2p+1 per direction, which the (p+1)-point Gauss-Legendre rule AT THE FACE NODES
+// integrates exactly as well.  There phi_j(x_k) = delta_jk, so the whole interpolate-to-quadrature /
+// project-back pipeline collapses to a product at the face nodes: L_j = w_j 1/2 (Up2_j - Up1_j) N(x_j).
+// Identical in exact arithmetic for every element this library accepts (straight-sided, order-1
+// geometry); rounding differs at the 1e-15 level.  The wall ghost of useBCinGrad is affine per component
+// (src/wallBC.cpp:241-266), so it commutes with the interpolation too.
+template <class C>
+__device__ inline void face_normal_rt(int d, const double *V, int s, double ta, double tb, double *n) {
+  if (d == 0)
+    face_normal_at<C, 0>(V, s, ta, tb, n);
+  else if (d == 1 || C::DIM == 2)
+    face_normal_at<C, 1>(V, s, ta, tb, n);
+  else
+    face_normal_at<C, (C::DIM == 3 ? 2 : 0)>(V, s, ta, tb, n);
+}
+// `D` is a run-time value and the face loop is not unrolled: one face's operands are live at a time
+// (with the six faces unrolled the kernel needs > 256 VGPRs)
+template <class C, class PH>
+__device__ inline void grad_jump_nodal(int D, const int2 *sFI, const typename PH::Params &prm, const double *Town,
+                                       const double *Tnb, const double *sV, const Tab<C> &tab, int le_n, const int *idx,
+                                       double inv_mass, double *g) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  const int da = (DIM == 2) ? 1 - D : (D == 0 ? 1 : 0), db = (D == 2) ? 1 : 2;  // tan_a, tan_b
+  const int ia = idx[da], ib = (DIM == 3) ? idx[db] : 0;
+  const int fn = (DIM == 2) ? ia : ia + C::N1 * ib;
+  const double wf = (DIM == 2) ? tab.w[ia] : tab.w[ia] * tab.w[ib];
+#pragma clang loop unroll(disable)
+  for (int s = 0; s < 2; s++) {
+    const int pf = 2 * le_n + s;
+    const int nb = sFI[le_n * C::NFACES + 2 * D + s].x;
+    double u1[NEQ], u2[NEQ];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) {
+      u1[eq] = ldsr(&Town[eq * C::TN + pf * C::NF + fn]);
+      u2[eq] = ldsr(&Tnb[eq * C::TN + pf * C::NF + fn]);
+    }
+    if (nb < 0 && prm.use_bc_in_grad) PH::bc_grad_prim(prm, prm.bc[-nb - 1], u1, u2);
+    double n[DIM];
+    face_normal_rt<C>(D, &sV[le_n * C::NV * DIM], s, tab.x[ia], (DIM == 3) ? tab.x[ib] : 0.0, n);
+    const double c = 0.5 * wf * inv_mass * (s ? tab.b1[idx[D]] : tab.b0[idx[D]]);
+#pragma unroll
+    for (int dd = 0; dd < DIM; dd++) {
+      const double cn = c * n[dd];
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) g[eq + dd * NEQ] += cn * (u2[eq] - u1[eq]);
+    }
+  }
+}
 
 // gradient jump of one direction pair: g += M^-1 sum_faces <phi, (u^ - u) n>
 template <class C, class PH, int D>
@@ -811,11 +897,32 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
 
   // ---- face part, one direction pair at a time (X lives in the sG region, not yet in use)
   if (!(TPSRHS_ABLATE & 8)) {
+#ifdef TPSRHS_JUMP_QUADRATURE  // the reference's face rule, literally (A/B and documentation)
     grad_jump_dir<C, PH, 0>(m, sFI, prm, e0, sUp, sG, sY, sV, tab, ct, ta0, node_on, le_n, idx, inv_mass, g, tid);
     grad_jump_dir<C, PH, 1>(m, sFI, prm, e0, sUp, sG, sY, sV, tab, ct, ta1, node_on, le_n, idx, inv_mass, g, tid);
     if (DIM == 3)
       grad_jump_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, sFI, prm, e0, sUp, sG, sY, sV, tab, ct, ta2, node_on, le_n, idx, inv_mass,
                                                 g, tid);
+#else
+    // own and neighbour Up traces of all direction pairs side by side in the (still unused) sG region,
+    // one synchronisation, then every node adds the collocated face terms of its three lines
+    constexpr int PER = 2 * NEQ * C::TN;
+    static_assert(DIM * PER <= L::SG, "trace staging does not fit the gradient region");
+    trace_lines<C, 0, NEQ>(sUp, sG, ct, tid);
+    trace_lines<C, 1, NEQ>(sUp, sG + PER, ct, tid);
+    if (DIM == 3) trace_lines<C, (DIM == 3 ? 2 : 0), NEQ>(sUp, sG + 2 * PER, ct, tid);
+    block_sync<C::BLOCK>();  // own traces complete (boundary faces copy them)
+    store_neighbour_traces<C, NEQ>(ta0, sG, sG + NEQ * C::TN, tid);
+    store_neighbour_traces<C, NEQ>(ta1, sG + PER, sG + PER + NEQ * C::TN, tid);
+    if (DIM == 3) store_neighbour_traces<C, NEQ>(ta2, sG + 2 * PER, sG + 2 * PER + NEQ * C::TN, tid);
+    block_sync<C::BLOCK>();
+    if (node_on) {
+#pragma clang loop unroll(disable)
+      for (int d = 0; d < DIM; d++)
+        grad_jump_nodal<C, PH>(d, sFI, prm, sG + d * PER, sG + d * PER + NEQ * C::TN, sV, tab, le_n, idx, inv_mass, g);
+    }
+    block_sync<C::BLOCK>();  // the traces are dead: sG receives the nodal gradient next
+#endif
   }
 
   if (node_on) {
