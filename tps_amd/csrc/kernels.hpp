@@ -574,19 +574,19 @@ template <class C, class PH>
 struct GradLds {
   static constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   static constexpr int NVF = NEQ * (1 + DIM);  // fields interpolated for the viscous traces: U, gradUp
-  static constexpr int CH = 2 * NEQ;           // ... CH at a time
-  // X: T (2 NEQ fields) | R (NEQ*DIM fields) | L (NEQ*DIM fields); Y: W (2 NEQ) | W2 (NEQ*DIM) | R in 2-D
-#ifdef TPSRHS_JUMP_QUADRATURE
-  static constexpr int X_JUMP = cmax(cmax(2 * NEQ * C::TN, NEQ * DIM * C::TQ), NEQ * DIM * C::TN);
-  static constexpr int Y = cmax(cmax(2 * NEQ * C::TW, NEQ * DIM * C::TW), (DIM == 2) ? NEQ * DIM * C::TQ : 0);
-#else
-  static constexpr int X_JUMP = DIM * 2 * NEQ * C::TN;  // own | neighbour Up traces of every direction pair
-  static constexpr int Y = CH * C::TW;                   // W chunk of the viscous phase
-#endif
-  static constexpr int SG = cmax(NEQ * DIM * C::NODES, X_JUMP);  // sG, hosting X during the jump phase
-  static constexpr int SUP = cmax(NEQ * C::NODES, CH * C::TN);   // sUp, hosting T during the viscous phase
-  static constexpr int O_U = 0, O_UP = NEQ * C::NODES, O_G = O_UP + SUP, O_Y = O_G + SG;
-  static constexpr int TOTAL = O_Y + Y;
+  static constexpr int CH = NEQ;               // ... NEQ at a time: U, then one gradient direction per chunk
+  // The pool is kept small on purpose: the resident workgroups per CU (LDS bytes) set how well the
+  // latencies of the line stages overlap.  [ sU | sUp (viscous phase: T chunk) | J | W ]
+  //   J: jump phase  -- own | neighbour Up traces of ONE direction pair
+  //      viscous phase -- the nodal values of one gradient direction (re-written from registers per chunk)
+  static constexpr int SUP = cmax(NEQ * C::NODES, CH * C::TN);
+  // (heavy point physics is register-bound, not LDS-bound: there the whole nodal gradient stays in J and the
+  //  node lanes' registers are released before the physics)
+  static constexpr bool G_IN_LDS = PH::HEAVY;
+  static constexpr int J = cmax(2 * NEQ * C::TN, (G_IN_LDS ? DIM : 1) * NEQ * C::NODES);
+  static constexpr int W = CH * C::TW;
+  static constexpr int O_U = 0, O_UP = NEQ * C::NODES, O_J = O_UP + SUP, O_W = O_J + J;
+  static constexpr int TOTAL = O_W + W;
 };
 
 // Gradient jump of one direction pair, collocated: g += M^-1 sum_faces <phi, (u^ - u) n>.
@@ -643,96 +643,32 @@ __device__ inline void grad_jump_nodal(int D, const int2 *sFI, const typename PH
   }
 }
 
-// gradient jump of one direction pair: g += M^-1 sum_faces <phi, (u^ - u) n>
-template <class C, class PH, int D>
-__device__ inline void grad_jump_dir(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
-                                     const double *sUp,
-                                     double *X, double *Yb, const double *sV, const Tab<C> &tab, const Tables1D &ct,
-                                     const NbTraces<C, PH::NEQ> &ta, bool node_on, int le_n, const int *idx,
-                                     double inv_mass, double *g, int tid) {
-  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-  trace_lines<C, D, NEQ>(sUp, X, ct, tid);  // own traces -> X[0..NEQ)
-  block_sync<C::BLOCK>();
-  store_neighbour_traces<C, NEQ>(ta, X, X + NEQ * C::TN, tid);
-  block_sync<C::BLOCK>();
-  interp1_lines<C, 2 * NEQ>(X, Yb, ct, tid);
-  if (DIM == 3) block_sync<C::BLOCK>();
-  // quadrature points: half jump times weighted normal, all gradient directions at once
-  double r[C::Q_ROUNDS][NEQ * DIM];
-#pragma unroll
-  for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
-    const int item = tid + rd * C::BLOCK;
-#pragma unroll
-    for (int k = 0; k < NEQ * DIM; k++) r[rd][k] = 0.0;
-    if (item < C::TQ) {
-      const int pf = item / C::NQ, q = item - pf * C::NQ;
-      const int le = pf >> 1, s = pf & 1;
-      const int e = e0 + le;
-      if (e < m.ne) {
-        const int nb = sFI[le * C::NFACES + 2 * D + s].x;
-        double bq[C::N1];
-        const int qrow = (DIM == 2) ? q : q / C::Q1;
-#pragma unroll
-        for (int a = 0; a < C::N1; a++) bq[a] = tab.B[qrow * C::N1 + a];
-        double u1[NEQ], u2[NEQ];
-#pragma unroll
-        for (int eq = 0; eq < NEQ; eq++) {
-          u1[eq] = interp2_point<C>(X + eq * C::TN, Yb + eq * C::TW, bq, pf, q);
-          u2[eq] = interp2_point<C>(X + (NEQ + eq) * C::TN, Yb + (NEQ + eq) * C::TW, bq, pf, q);
-        }
-        if (nb < 0 && prm.use_bc_in_grad) PH::bc_grad_prim(prm, prm.bc[-nb - 1], u1, u2);
-        double n[DIM], wq, Xq[DIM];
-        face_geometry<C, D>(&sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
-#pragma unroll
-        for (int dd = 0; dd < DIM; dd++) {
-          const double nw = n[dd] * wq;
-#pragma unroll
-          for (int eq = 0; eq < NEQ; eq++) r[rd][eq + dd * NEQ] = 0.5 * (u2[eq] - u1[eq]) * nw;
-        }
-      }
-    }
-  }
-  block_sync<C::BLOCK>();  // X (T) and Y (W) are dead
-  double *R = (DIM == 2) ? Yb : X;
-#pragma unroll
-  for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
-    const int item = tid + rd * C::BLOCK;
-    if (item < C::TQ) {
-#pragma unroll
-      for (int k = 0; k < NEQ * DIM; k++) R[k * C::TQ + item] = r[rd][k];
-    }
-  }
-  block_sync<C::BLOCK>();
-  project1_lines<C, NEQ * DIM>(X, Yb, ct, tid);
-  if (DIM == 3) block_sync<C::BLOCK>();
-  project2_lines<C, NEQ * DIM>(Yb, X, ct, tid);  // 3-D: W2 (Y) -> L (X); 2-D: R (Y) -> L (X)
-  block_sync<C::BLOCK>();
-  if (node_on) {
-#pragma unroll
-    for (int k = 0; k < NEQ * DIM; k++) g[k] += inv_mass * lift_pair<C, D>(X + k * C::TN, tab, le_n, idx);
-  }
-  block_sync<C::BLOCK>();
-}
-
 // viscous normal-flux traces of one direction pair: [U | gradUp] at the face quadrature points ...
+// (chunks of NEQ fields: U from sU, then one gradient direction at a time, written from the registers of
+// the node lanes into the small nodal buffer sJ)
 template <class C, class PH, int D>
-__device__ inline void visc_interp_dir(const double *sU, const double *sG, double *Tb, double *Wb, const Tab<C> &tab,
-                                       const Tables1D &ct, double (&v)[C::Q_ROUNDS][GradLds<C, PH>::NVF], int tid) {
+__device__ inline void visc_interp_dir(const double *sU, const double *g, bool node_on, double *sJ, double *Tb, double *Wb,
+                                       const Tab<C> &tab, const Tables1D &ct,
+                                       double (&v)[C::Q_ROUNDS][GradLds<C, PH>::NVF], int tid) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-  typedef GradLds<C, PH> L;
 #pragma unroll
-  for (int c0 = 0; c0 < L::NVF; c0 += L::CH) {
-    // fields c0 .. c0+CH of [U | gradUp]
+  for (int c = 0; c <= DIM; c++) {
+    const double *src = sU;
+    if (c > 0) {
+      if constexpr (GradLds<C, PH>::G_IN_LDS) {
+        src = sJ + (c - 1) * NEQ * C::NODES;
+      } else {
+        if (node_on) {
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      const int f0 = c0 + half * NEQ;
-      if (f0 < L::NVF) {
-        const double *src = (f0 < NEQ) ? sU : sG + (f0 - NEQ) * C::NODES;
-        trace_lines<C, D, NEQ>(src, Tb + half * NEQ * C::TN, ct, tid);
+          for (int eq = 0; eq < NEQ; eq++) sJ[eq * C::NODES + tid] = g[eq + (c - 1) * NEQ];
+        }
+        block_sync<C::BLOCK>();
+        src = sJ;
       }
     }
+    trace_lines<C, D, NEQ>(src, Tb, ct, tid);
     block_sync<C::BLOCK>();
-    interp1_lines<C, L::CH>(Tb, Wb, ct, tid);
+    interp1_lines<C, NEQ>(Tb, Wb, ct, tid);
     if (DIM == 3) block_sync<C::BLOCK>();
 #pragma unroll
     for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
@@ -744,8 +680,7 @@ __device__ inline void visc_interp_dir(const double *sU, const double *sG, doubl
 #pragma unroll
         for (int a = 0; a < C::N1; a++) bq[a] = tab.B[qrow * C::N1 + a];
 #pragma unroll
-        for (int k = 0; k < L::CH; k++)
-          if (c0 + k < L::NVF) v[rd][c0 + k] = interp2_point<C>(Tb + k * C::TN, Wb + k * C::TW, bq, pf, q);
+        for (int k = 0; k < NEQ; k++) v[rd][c * NEQ + k] = interp2_point<C>(Tb + k * C::TN, Wb + k * C::TW, bq, pf, q);
       }
     }
     block_sync<C::BLOCK>();
@@ -798,11 +733,11 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const type
 }
 template <class C, class PH, int D>
 __device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
-                                       const double *sU,
-                                       const double *sG, double *Tb, double *Wb, const double *sV, const Tab<C> &tab,
-                                       const Tables1D &ct, double *__restrict__ TB, int tid) {
+                                       const double *sU, const double *g, bool node_on, double *sJ, double *Tb, double *Wb,
+                                       const double *sV, const Tab<C> &tab, const Tables1D &ct, double *__restrict__ TB,
+                                       int tid) {
   double v[C::Q_ROUNDS][GradLds<C, PH>::NVF];
-  visc_interp_dir<C, PH, D>(sU, sG, Tb, Wb, tab, ct, v, tid);
+  visc_interp_dir<C, PH, D>(sU, g, node_on, sJ, Tb, Wb, tab, ct, v, tid);
   visc_points<C, PH>(m, sFI, prm, e0, D, v, sV, tab, TB, tid);
 }
 
@@ -818,8 +753,8 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
   __shared__ double pool[L::TOTAL];
   double *sU = pool + L::O_U;    // [NEQ][NODES]
   double *sUp = pool + L::O_UP;  // [NEQ][NODES]; viscous phase: T chunk
-  double *sG = pool + L::O_G;    // [NEQ*DIM][NODES]; jump phase: X
-  double *sY = pool + L::O_Y;
+  double *sJ = pool + L::O_J;    // jump phase: traces of one direction pair; viscous phase: nodal gradient chunk
+  double *sW = pool + L::O_W;    // W chunk of the viscous phase
 
   const int tid = threadIdx.x;
   const int bid = m.blocks ? m.blocks[blockIdx.x] : static_cast<int>(blockIdx.x);
@@ -895,65 +830,60 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
     }
   }
 
-  // ---- face part, one direction pair at a time (X lives in the sG region, not yet in use)
+  // ---- face part of the gradient, collocated (grad_jump_nodal), one direction pair at a time
   if (!(TPSRHS_ABLATE & 8)) {
-#ifdef TPSRHS_JUMP_QUADRATURE  // the reference's face rule, literally (A/B and documentation)
-    grad_jump_dir<C, PH, 0>(m, sFI, prm, e0, sUp, sG, sY, sV, tab, ct, ta0, node_on, le_n, idx, inv_mass, g, tid);
-    grad_jump_dir<C, PH, 1>(m, sFI, prm, e0, sUp, sG, sY, sV, tab, ct, ta1, node_on, le_n, idx, inv_mass, g, tid);
-    if (DIM == 3)
-      grad_jump_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, sFI, prm, e0, sUp, sG, sY, sV, tab, ct, ta2, node_on, le_n, idx, inv_mass,
-                                                g, tid);
-#else
-    // own and neighbour Up traces of all direction pairs side by side in the (still unused) sG region,
-    // one synchronisation, then every node adds the collocated face terms of its three lines
-    constexpr int PER = 2 * NEQ * C::TN;
-    static_assert(DIM * PER <= L::SG, "trace staging does not fit the gradient region");
-    trace_lines<C, 0, NEQ>(sUp, sG, ct, tid);
-    trace_lines<C, 1, NEQ>(sUp, sG + PER, ct, tid);
-    if (DIM == 3) trace_lines<C, (DIM == 3 ? 2 : 0), NEQ>(sUp, sG + 2 * PER, ct, tid);
+    trace_lines<C, 0, NEQ>(sUp, sJ, ct, tid);
     block_sync<C::BLOCK>();  // own traces complete (boundary faces copy them)
-    store_neighbour_traces<C, NEQ>(ta0, sG, sG + NEQ * C::TN, tid);
-    store_neighbour_traces<C, NEQ>(ta1, sG + PER, sG + PER + NEQ * C::TN, tid);
-    if (DIM == 3) store_neighbour_traces<C, NEQ>(ta2, sG + 2 * PER, sG + 2 * PER + NEQ * C::TN, tid);
+    store_neighbour_traces<C, NEQ>(ta0, sJ, sJ + NEQ * C::TN, tid);
     block_sync<C::BLOCK>();
-    if (node_on) {
-#pragma clang loop unroll(disable)
-      for (int d = 0; d < DIM; d++)
-        grad_jump_nodal<C, PH>(d, sFI, prm, sG + d * PER, sG + d * PER + NEQ * C::TN, sV, tab, le_n, idx, inv_mass, g);
+    if (node_on) grad_jump_nodal<C, PH>(0, sFI, prm, sJ, sJ + NEQ * C::TN, sV, tab, le_n, idx, inv_mass, g);
+    block_sync<C::BLOCK>();
+    trace_lines<C, 1, NEQ>(sUp, sJ, ct, tid);
+    block_sync<C::BLOCK>();
+    store_neighbour_traces<C, NEQ>(ta1, sJ, sJ + NEQ * C::TN, tid);
+    block_sync<C::BLOCK>();
+    if (node_on) grad_jump_nodal<C, PH>(1, sFI, prm, sJ, sJ + NEQ * C::TN, sV, tab, le_n, idx, inv_mass, g);
+    block_sync<C::BLOCK>();
+    if (DIM == 3) {
+      trace_lines<C, (DIM == 3 ? 2 : 0), NEQ>(sUp, sJ, ct, tid);
+      block_sync<C::BLOCK>();
+      store_neighbour_traces<C, NEQ>(ta2, sJ, sJ + NEQ * C::TN, tid);
+      block_sync<C::BLOCK>();
+      if (node_on) grad_jump_nodal<C, PH>(2, sFI, prm, sJ, sJ + NEQ * C::TN, sV, tab, le_n, idx, inv_mass, g);
+      block_sync<C::BLOCK>();
     }
-    block_sync<C::BLOCK>();  // the traces are dead: sG receives the nodal gradient next
-#endif
   }
 
   if (node_on) {
     const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
 #pragma unroll
-    for (int k = 0; k < NEQ * DIM; k++) {
-      field_ptr(gradUp, k, m.ndofs)[n] = g[k];
-      sG[k * C::NODES + tid] = g[k];
+    for (int k = 0; k < NEQ * DIM; k++) field_ptr(gradUp, k, m.ndofs)[n] = g[k];
+    if constexpr (L::G_IN_LDS) {
+#pragma unroll
+      for (int k = 0; k < NEQ * DIM; k++) sJ[k * C::NODES + tid] = g[k];
     }
   }
-  block_sync<C::BLOCK>();
+  if (L::G_IN_LDS) block_sync<C::BLOCK>();
 
-  // ---- viscous normal-flux traces (T chunk in the sUp region, W chunk in Y)
+  // ---- viscous normal-flux traces (T chunk in the sUp region: the nodal Up values are dead)
   if (!(TPSRHS_ABLATE & 16)) {
     if constexpr (PH::HEAVY) {
 #pragma clang loop unroll(disable)
       for (int d = 0; d < DIM; d++) {
         double v[C::Q_ROUNDS][L::NVF];
         if (d == 0)
-          visc_interp_dir<C, PH, 0>(sU, sG, sUp, sY, tab, ct, v, tid);
+          visc_interp_dir<C, PH, 0>(sU, g, node_on, sJ, sUp, sW, tab, ct, v, tid);
         else if (d == 1)
-          visc_interp_dir<C, PH, 1>(sU, sG, sUp, sY, tab, ct, v, tid);
+          visc_interp_dir<C, PH, 1>(sU, g, node_on, sJ, sUp, sW, tab, ct, v, tid);
         else
-          visc_interp_dir<C, PH, (DIM == 3 ? 2 : 0)>(sU, sG, sUp, sY, tab, ct, v, tid);
+          visc_interp_dir<C, PH, (DIM == 3 ? 2 : 0)>(sU, g, node_on, sJ, sUp, sW, tab, ct, v, tid);
         visc_points<C, PH>(m, sFI, prm, e0, d, v, sV, tab, TB, tid);
-        block_sync<C::BLOCK>();
       }
     } else {
-      visc_traces_dir<C, PH, 0>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
-      visc_traces_dir<C, PH, 1>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
-      if (DIM == 3) visc_traces_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, sFI, prm, e0, sU, sG, sUp, sY, sV, tab, ct, TB, tid);
+      visc_traces_dir<C, PH, 0>(m, sFI, prm, e0, sU, g, node_on, sJ, sUp, sW, sV, tab, ct, TB, tid);
+      visc_traces_dir<C, PH, 1>(m, sFI, prm, e0, sU, g, node_on, sJ, sUp, sW, sV, tab, ct, TB, tid);
+      if (DIM == 3)
+        visc_traces_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, sFI, prm, e0, sU, g, node_on, sJ, sUp, sW, sV, tab, ct, TB, tid);
     }
   }
 }
