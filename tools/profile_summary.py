@@ -22,7 +22,13 @@ def short(name):
     return name.split("<")[0].replace("void tpsrhs::", "")
 
 
-stats = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: keep the newest run of each pass"""
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+stats = newest(out + "/trace/**/*kernel_stats.csv")
 rows = []
 if stats:
     rows = [r for r in csv.DictReader(open(stats[0]))]
@@ -34,7 +40,7 @@ if stats:
                 wr.writerow([r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
-for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
+for f in [x for d in glob.glob(out + "/pmc_*/") for x in newest(d + "**/*counter_collection.csv")]:
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         if not k.startswith("k_"):
