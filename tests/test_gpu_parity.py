@@ -174,3 +174,29 @@ def test_dry_air_axisymmetric(order, eq, wall, r_in, warp):
     c.physics.dry_air.visc_mult = 200.0
     c.physics.dry_air.bulk_visc_mult = 1.5
     _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=3 + order))
+
+
+# ---- mixtures beyond the ambipolar ternary one ----
+@pytest.mark.parametrize("order,two_t,transport", [(2, False, capi.ARGON_MINIMAL), (1, True, capi.CONSTANT)])
+def test_plasma_non_ambipolar_ternary(order, two_t, transport):
+    """the electron density has its own transport equation (test/inputs/argonMinimal.binary_mixture.ini:135)"""
+    ph = capi.argon_ternary_physics(capi.NS, two_t, transport, "arrhenius", ambipolar=False)
+    _boost_transport(ph)
+    c = cases.argon_cyl3d(4, 12, 3, order, physics=ph)
+    amp = 0.005 if order == 1 else 0.01
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=7, amp=amp), tol=_tol(amp))
+
+
+@pytest.mark.parametrize("geo,order,transport", [("axisym", 3, capi.CONSTANT), ("3d", 2, capi.ARGON_MIXTURE),
+                                                  ("3d", 1, capi.CONSTANT), ("axisym", 2, capi.ARGON_MIXTURE)])
+def test_plasma_six_species(geo, order, transport):
+    """Ar, E, Ar.+1, Ar_m, Ar_r, Ar_p, two-temperature, not ambipolar: the mixture of the reference's torch
+    input (test/inputs/plasma.ini:158-275), 11 equations"""
+    ph = capi.argon_six_species_physics(capi.NS, transport, True, True, radiation=(geo == "axisym"))
+    _boost_transport(ph, 30.0)
+    if geo == "axisym":
+        c = cases.argon_axisym(6, 8, order, physics=ph, r_in=0.0)
+    else:
+        c = cases.argon_cyl3d(4, 12, 3, order, physics=ph)
+    amp = 0.005 if order == 1 else 0.01
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=9, amp=amp), tol=_tol(amp))

@@ -123,6 +123,21 @@ def plasma_conserved(physics, nvel, rho, vel, Th, n_active, Te=None):
     return U
 
 
+def _active_densities(physics, nh, ni, wave=None):
+    """number densities of the active species in mixture order for the argon mixtures of capi: the ion
+    first, then (six-species mixture) the excited neutrals at small smooth fractions, then -- when the
+    mixture is not ambipolar -- the electrons (quasi-neutral up to a smooth 1 % offset)."""
+    mx = physics.mixture
+    nsp = mx.num_species
+    w = wave if wave is not None else (lambda: 0.0)
+    n = [ni]
+    for k in range(nsp - 3):  # excited levels
+        n.append(nh * 10.0 ** (-5.5 - 0.5 * k) * (1.0 + 0.3 * w()))
+    if not mx.ambipolar:
+        n.append(ni * (1.0 + 0.01 * w()))
+    return n
+
+
 def plasma_state(X, physics, nvel, seed=12345, amp=0.05, p0=101300.0, vel0=(20.0, 0.0, 0.0)):
     """Smooth argon-plasma state: T_h in [3000, 12000] K, ionisation degree in
     [1e-6, 1e-2] (log-uniform waves), pressure p0(1 + amp wave), velocity free stream + amp waves,
@@ -142,9 +157,15 @@ def plasma_state(X, physics, nvel, seed=12345, amp=0.05, p0=101300.0, vel0=(20.0
     TeE = Th if Te is None else Te
     nh = p / (R * (Th + alpha * TeE))
     ni = alpha * nh
-    nB = nh - ni
-    rho = ni * mw[0] + ni * mw[nsp - 2] + nB * mw[nsp - 1]
-    return plasma_conserved(physics, nvel, rho, vel, Th, [ni], Te)
+    if nsp == 3 and mx.ambipolar:
+        nact = [ni]
+    else:
+        sw = wave if amp > 0 else None
+        nact = _active_densities(physics, nh, ni, sw)
+    ne = ni if mx.ambipolar else nact[nsp - 2]
+    nheavy_active = sum(nact[: nsp - 2])
+    rho = sum(nact[sp] * mw[sp] for sp in range(nsp - 2)) + ne * mw[nsp - 2] + (nh - nheavy_active) * mw[nsp - 1]
+    return plasma_conserved(physics, nvel, rho, vel, Th, nact, Te)
 
 
 def argon_inlet_state(physics, nvel, T=6000.0, alpha=1.0e-4, p0=101300.0, vel0=(20.0, 0.0, 0.0)):
@@ -155,8 +176,11 @@ def argon_inlet_state(physics, nvel, T=6000.0, alpha=1.0e-4, p0=101300.0, vel0=(
     mw = [mx.gas_params[sp + capi.SPECIES_MW * nsp] for sp in range(nsp)]
     nh = p0 / (R * T * (1.0 + alpha))
     ni = alpha * nh
-    rho = ni * mw[0] + ni * mw[nsp - 2] + (nh - ni) * mw[nsp - 1]
-    return [rho, vel0[0], vel0[1], vel0[2], ni * mw[0]]
+    nact = [ni] if (nsp == 3 and mx.ambipolar) else _active_densities(physics, nh, ni)
+    ne = ni if mx.ambipolar else nact[nsp - 2]
+    rho = sum(nact[sp] * mw[sp] for sp in range(nsp - 2)) + ne * mw[nsp - 2] + (nh - sum(nact[: nsp - 2])) * mw[nsp - 1]
+    nactive = nsp - 2 if mx.ambipolar else nsp - 1
+    return [rho, vel0[0], vel0[1], vel0[2]] + [nact[sp] * mw[sp] for sp in range(nactive)]
 
 
 def plasma_cylinder_bcs(physics, wall_type=capi.VISC_ISOTH, t_wall=3000.0):
@@ -167,22 +191,23 @@ def plasma_cylinder_bcs(physics, wall_type=capi.VISC_ISOTH, t_wall=3000.0):
 
 
 def argon_cyl3d(nr, ntheta, nz, order, two_temperature=False, transport=capi.ARGON_MINIMAL, reactions="arrhenius",
-                wall_type=capi.VISC_ISOTH, eq_system=capi.NS, radiation=False, name=None):
-    """O-grid cylinder in an argon plasma stream (ambipolar ternary mixture)."""
+                wall_type=capi.VISC_ISOTH, eq_system=capi.NS, radiation=False, name=None, physics=None):
+    """O-grid cylinder in an argon plasma stream (ambipolar ternary mixture unless `physics` is given)."""
     mesh = meshgen.ogrid_cylinder(nr, ntheta, nz)
-    ph = capi.argon_ternary_physics(eq_system, two_temperature, transport, reactions, radiation=radiation)
+    ph = physics or capi.argon_ternary_physics(eq_system, two_temperature, transport, reactions, radiation=radiation)
     return Case(name or f"argon_cyl3d_{nr}x{ntheta}x{nz}_p{order}", mesh, capi.Disc(order, 0, 0, 0, 0), ph,
                 plasma_cylinder_bcs(ph, wall_type), "O-grid cylinder, argon ternary plasma")
 
 
 def argon_axisym(nr, nz, order, two_temperature=True, transport=capi.CONSTANT, reactions="arrhenius", radiation=True,
-                 wall_type=capi.VISC_ISOTH, r_in=0.0, r_out=0.05, length=0.25, warp=0.0, eq_system=capi.NS, name=None):
+                 wall_type=capi.VISC_ISOTH, r_in=0.0, r_out=0.05, length=0.25, warp=0.0, eq_system=capi.NS, name=None,
+                 physics=None):
     """Axisymmetric (r, z) tube in an argon plasma: patch 1 inlet at z = 0 (axial flow with swirl), 2 outlet at
     z = L, 3 outer wall, 4 the axis / inner boundary (inviscid wall).  The shape of BASELINE.json configs[4]."""
     attrs = {(0, 0): 4, (0, 1): 3, (1, 0): 1, (1, 1): 2}
     mesh = meshgen.box_quad(nr, nz, lengths=(r_out - r_in, length), periodic=(False, False), bdr_attr=attrs, warp=warp,
                             origin=(r_in, 0.0))
-    ph = capi.argon_ternary_physics(eq_system, two_temperature, transport, reactions, radiation=radiation)
+    ph = physics or capi.argon_ternary_physics(eq_system, two_temperature, transport, reactions, radiation=radiation)
     inlet = argon_inlet_state(ph, 3, vel0=(0.0, 20.0, 2.0))
     bcs = [capi.make_bc(1, capi.INLET, capi.SUB_DENS_VEL, inlet), capi.make_bc(2, capi.OUTLET, capi.SUB_P, [101300.0]),
            capi.make_bc(3, capi.WALL, wall_type, [3000.0]), capi.make_bc(4, capi.WALL, capi.INV)]

@@ -1,0 +1,51 @@
+// Shared by the plasma translation units: one TU = one (dim, nvel, species count, ambipolar) family, so
+// that the families compile in parallel.  Each TU defines TPSRHS_PLASMA_FAMILY(name, DIM, NVEL, NSP, AMBI)
+// through this header and exports `void name(tpsrhs_operator *, bool two_temperature, int transport)`.
+#ifndef TPSRHS_PLASMA_FAMILY_HPP_
+#define TPSRHS_PLASMA_FAMILY_HPP_
+
+#include "operator.hpp"
+#include "physics_plasma.hpp"
+
+template <int DIM, int NVEL, int NSP, bool AMBI, bool TWOT, int TR>
+static void pick_plasma_orders(tpsrhs_operator *op) {
+  typedef PlasmaPhys<DIM, NVEL, NSP, AMBI, TWOT, TR> PH;
+  upload_tables(DIM, op->order);
+  switch (op->order) {
+    case 1: op->launch = &launch_all<DIM, 1, PH>; break;
+    case 2: op->launch = &launch_all<DIM, 2, PH>; break;
+    case 3: op->launch = &launch_all<DIM, 3, PH>; break;
+    default: throw Unsupported("plasma kernels are built for polynomial orders 1..3");
+  }
+}
+
+// which transport models a family instantiates: the ternary collision model needs three species
+template <int DIM, int NVEL, int NSP, bool AMBI>
+static void pick_plasma_family(tpsrhs_operator *op, bool two_temperature, int transport) {
+  if (transport == TRANSPORT_CONSTANT) {
+    if (two_temperature)
+      pick_plasma_orders<DIM, NVEL, NSP, AMBI, true, TRANSPORT_CONSTANT>(op);
+    else
+      pick_plasma_orders<DIM, NVEL, NSP, AMBI, false, TRANSPORT_CONSTANT>(op);
+  } else if (transport == TRANSPORT_ARGON_MIXTURE) {
+    if (two_temperature)
+      pick_plasma_orders<DIM, NVEL, NSP, AMBI, true, TRANSPORT_ARGON_MIXTURE>(op);
+    else
+      pick_plasma_orders<DIM, NVEL, NSP, AMBI, false, TRANSPORT_ARGON_MIXTURE>(op);
+  } else {
+    if constexpr (NSP == 3) {
+      if (two_temperature)
+        pick_plasma_orders<DIM, NVEL, NSP, AMBI, true, TRANSPORT_ARGON_MINIMAL>(op);
+      else
+        pick_plasma_orders<DIM, NVEL, NSP, AMBI, false, TRANSPORT_ARGON_MINIMAL>(op);
+    } else {
+      throw Unsupported("argon_minimal transport is the ternary (Ar, Ar.+1, E) model");
+    }
+  }
+}
+
+#define TPSRHS_PLASMA_FAMILY(name, DIM, NVEL, NSP, AMBI)                          \
+  void name(tpsrhs_operator *op, bool two_temperature, int transport) {           \
+    pick_plasma_family<DIM, NVEL, NSP, AMBI>(op, two_temperature, transport);     \
+  }
+#endif

@@ -10,10 +10,12 @@
 #include <cmath>
 #include <new>
 
-// kernel families instantiated in their own translation units
-void pick_plasma3d(tpsrhs_operator *op, bool two_temperature, int transport);
-void pick_plasma2d(tpsrhs_operator *op, bool two_temperature, int transport);
-void pick_plasma_axisym(tpsrhs_operator *op, bool two_temperature, int transport);
+// kernel families instantiated in their own translation units (plasma_family.hpp)
+#define DECL(name) void name(tpsrhs_operator *op, bool two_temperature, int transport)
+DECL(pick_plasma_3d_n3a); DECL(pick_plasma_3d_n3); DECL(pick_plasma_3d_n6);
+DECL(pick_plasma_2d_n3a); DECL(pick_plasma_2d_n3); DECL(pick_plasma_2d_n6);
+DECL(pick_plasma_axi_n3a); DECL(pick_plasma_axi_n3); DECL(pick_plasma_axi_n6);
+#undef DECL
 void pick_dryair_axisym(tpsrhs_operator *op);
 
 static thread_local std::string g_last_error;
@@ -47,10 +49,11 @@ TableDev upload_table(tpsrhs_operator *op, const tpsrhs_table &t) {
   return td;
 }
 
+template <int NSP>
 void fill_plasma_params(tpsrhs_operator *op, const tpsrhs_disc *disc, const tpsrhs_physics *phys, int num_bcs,
                         const tpsrhs_bc *bcs) {
-  constexpr int NSP = 3;
   const tpsrhs_perfect_mixture &mx = phys->mixture;
+  static_assert(sizeof(PlasmaParams<NSP>) <= sizeof(op->params), "parameter block too large");
   PlasmaParams<NSP> &p = *new (op->params) PlasmaParams<NSP>;
   std::memset(&p, 0, sizeof(p));
   for (int sp = 0; sp < NSP; sp++) {
@@ -78,6 +81,7 @@ void fill_plasma_params(tpsrhs_operator *op, const tpsrhs_disc *disc, const tpsr
   const tpsrhs_gas_transport &gt = phys->gas_transport;
   if (phys->transport_model == TPSRHS_ARGON_MINIMAL) {
     // GasMinimalTransport::GasMinimalTransport, src/gas_transport.cpp:43-128
+    if (NSP != 3) throw Unsupported("argon_minimal transport is the ternary (Ar, Ar.+1, E) model");
     if (gt.electron_index != NSP - 2 || gt.neutral_index != NSP - 1 || gt.ion_index != 0)
       throw std::invalid_argument("argon transport: species must be ordered (ion, electron, neutral background)");
     if (std::fabs(p.mw[gt.neutral_index] - p.mw[gt.electron_index] - p.mw[gt.ion_index]) >= 1.0e-12)
@@ -189,12 +193,16 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   op->neq = op->nvel + 2;
   if (plasma) {
     const tpsrhs_perfect_mixture &mx = phys->mixture;
-    if (mx.num_species != 3 || !mx.is_electron_included || !mx.ambipolar)
-      throw Unsupported("USER_DEFINED fluids: only the ambipolar ternary mixture (ion, electron, neutral) is built");
+    if (!mx.is_electron_included) throw Unsupported("USER_DEFINED fluids without electrons are not built");
+    const bool fam = (mx.num_species == 3) || (mx.num_species == 6 && !mx.ambipolar);
+    if (!fam)
+      throw Unsupported("USER_DEFINED fluids: built species counts are 3 (ambipolar or not) and 6 (not ambipolar)");
+    if (mx.num_species == 6 && phys->transport_model == TPSRHS_ARGON_MINIMAL)
+      throw Unsupported("argon_minimal transport is the ternary (Ar, Ar.+1, E) model");
     if (phys->transport_model != TPSRHS_CONSTANT && phys->transport_model != TPSRHS_ARGON_MINIMAL &&
         phys->transport_model != TPSRHS_ARGON_MIXTURE)
       throw Unsupported("transport model outside the built scope (constant, argon_minimal, argon_mixture)");
-    op->neq = op->nvel + 2 + (mx.num_species - 2) + (mx.two_temperature ? 1 : 0);
+    op->neq = op->nvel + 2 + (mx.ambipolar ? mx.num_species - 2 : mx.num_species - 1) + (mx.two_temperature ? 1 : 0);
   }
   op->phys = *phys;
 
@@ -223,16 +231,22 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   op->ndofs = static_cast<int64_t>(op->ne) * npe;
 
   if (plasma) {
-    fill_plasma_params(op, disc, phys, num_bcs, bcs);
+    const int nsp = phys->mixture.num_species;
+    const bool ambi = phys->mixture.ambipolar != 0, two_t = phys->mixture.two_temperature != 0;
+    if (nsp == 3)
+      fill_plasma_params<3>(op, disc, phys, num_bcs, bcs);
+    else
+      fill_plasma_params<6>(op, disc, phys, num_bcs, bcs);
     const int tr = (phys->transport_model == TPSRHS_CONSTANT)
                        ? TRANSPORT_CONSTANT
                        : (phys->transport_model == TPSRHS_ARGON_MINIMAL ? TRANSPORT_ARGON_MINIMAL : TRANSPORT_ARGON_MIXTURE);
-    if (op->dim == 3)
-      pick_plasma3d(op, phys->mixture.two_temperature != 0, tr);
-    else if (disc->axisymmetric)
-      pick_plasma_axisym(op, phys->mixture.two_temperature != 0, tr);
-    else
-      pick_plasma2d(op, phys->mixture.two_temperature != 0, tr);
+    typedef void (*pick_fn)(tpsrhs_operator *, bool, int);
+    const pick_fn table[3][3] = {{pick_plasma_3d_n3a, pick_plasma_3d_n3, pick_plasma_3d_n6},
+                                 {pick_plasma_2d_n3a, pick_plasma_2d_n3, pick_plasma_2d_n6},
+                                 {pick_plasma_axi_n3a, pick_plasma_axi_n3, pick_plasma_axi_n6}};
+    const int geo = (op->dim == 3) ? 0 : (disc->axisymmetric ? 2 : 1);
+    const int fam = (nsp == 6) ? 2 : (ambi ? 0 : 1);
+    table[geo][fam](op, two_t, tr);
   } else {
     DryAirParams &d = *new (op->params) DryAirParams;
     std::memset(&d, 0, sizeof(d));
