@@ -12,6 +12,8 @@ configs[1]/[2] per GPU.  Workloads:
                   transport, 2 Arrhenius reactions) at p=2, 6 equations
   cfg5            configs[4] on one GPU: axisymmetric 400x500 quads, p=3, two-temperature argon plasma with
                   constant transport, reactions and the NEC radiation source, 7 equations
+  torch6          the mixture of the reference's torch input (plasma.ini): six species, two temperatures, not
+                  ambipolar, 11 equations, on the axisymmetric 400x500 mesh of cfg5
   argon_p3        the metric's "3D p=3 reacting cyl" read literally: the physics of configs[2] at the
                   order of configs[1] (no entry of `configs` is both)
 At N = 1 the JSON line also carries the workloads that were not selected, under `other_workloads`.
@@ -76,6 +78,15 @@ def workload(name):
                 "2 Arrhenius reactions, NEC radiation table, inlet / outlet / isothermal wall / axis "
                 "(BASELINE.json configs[4] on one GPU)",
                 lambda order: cases.argon_axisym(40, 50, order))
+    if name == "torch6":
+        ph = capi.argon_six_species_physics(capi.NS, capi.CONSTANT, True, True, radiation=True)
+        return (3, ph, lambda p: cases.argon_axisym(2, 2, 3, physics=p).bcs,
+                lambda X, p: cases.plasma_state(X, p, nvel=3, seed=12345, amp=0.05, vel0=(1.0, 20.0, 3.0)),
+                "AXISYMMETRIC (r, z) 400x500 quads, the six-species two-temperature argon mixture of the reference's "
+                "torch input (test/inputs/plasma.ini: Ar.+1, Ar_m, Ar_r, Ar_p, E, Ar; not ambipolar; 11 equations), "
+                "constant transport, 4 reactions, NEC radiation table",
+                lambda order: cases.argon_axisym(40, 50, order, physics=capi.argon_six_species_physics(
+                    capi.NS, capi.CONSTANT, True, True, radiation=True)))
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -116,7 +127,7 @@ def main():
     ap.add_argument("--ntheta", type=int, default=112)
     ap.add_argument("--nz", type=int, default=16)
     ap.add_argument("--order", type=int, default=0, help="override the workload's polynomial order")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "argon_p3", "cfg5"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "argon_p3", "cfg5", "torch6"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the multi-rank path on a one-GPU box (traces staged via host)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses device 0")
@@ -160,11 +171,11 @@ def main():
         """-> the JSON fields of one workload (rank 0; None elsewhere)"""
         order, physics, make_bcs, make_state, description, sample_case = workload(wname)
         order = args.order or order
-        axisym = wname == "cfg5"
+        axisym = wname in ("cfg5", "torch6")
         if axisym:
             if world > 1:
-                raise SystemExit("cfg5 is benchmarked on one GPU (no partitioned generator for the (r, z) block yet)")
-            mesh = cases.argon_axisym(400, 500, order).mesh
+                raise SystemExit("the axisymmetric workloads are benchmarked on one GPU (no partitioned generator for the (r, z) block yet)")
+            mesh = cases.argon_axisym(400, 500, order).mesh  # geometry only; physics and BCs come from workload()
         else:
             mesh = meshgen.ogrid_cylinder_slab(args.nr, args.ntheta, args.nz, rank, world)
         disc = capi.Disc(order, 0, 0, 1 if axisym else 0, 0)
@@ -232,7 +243,7 @@ def main():
     r = run(args.workload, args.steps, args.warmup)
     others = {}
     if world == 1 and not args.no_other_workloads:
-        for wname in ("cfg2", "argon_p3", "cfg3", "cfg5"):
+        for wname in ("cfg2", "argon_p3", "cfg3", "cfg5", "torch6"):
             if wname != args.workload:
                 o, _ = run(wname, max(args.steps // 2, 5), min(args.warmup, 3))
                 others[wname] = {k: o[k] for k in ("value", "ms_per_step", "rhs_evals_per_s", "kernel_ms", "finite")}
