@@ -90,7 +90,7 @@ def workload(name):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(neq, order, sample_case, budget_s=20.0):
+def cpu_baseline(neq, order, sample_case, budget_s=12.0):
     """The oracle (CPU restatement, reference-faithful dense formulation) timed on this host on a
     bounded sample of the same workload: a 7x28x4 = 784-element O-grid block of the cylinder at the
     same order, physics and boundary conditions."""
@@ -107,7 +107,7 @@ def cpu_baseline(neq, order, sample_case, budget_s=20.0):
     o.mult(U)  # warm-up
     t0 = time.perf_counter()
     n = 0
-    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 50):
+    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 2000):
         o.mult(U)
         n += 1
     dt = (time.perf_counter() - t0) / n
