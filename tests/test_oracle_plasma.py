@@ -219,3 +219,36 @@ def test_sheath_wall_flux_balances(two_t):
         # species equation: -1/2 * (-rho_i V_B |n|)
         assert visc[5] == pytest.approx(0.5 * ni * mw[0] * VB * nm, rel=1e-12)
         assert abs(visc[0]) == 0.0 and np.abs(visc[1:4]).max() < 1e-9 * abs(lf[1:4]).max()
+
+
+@pytest.mark.parametrize("kind", ["ternary_2T", "six_species", "six_species_axisym"])
+def test_boundary_viscous_flux_identity_for_mixtures(kind):
+    """reference test/test_boundary_flux.cpp:88-166 (PerfectMixture + ConstantTransport, optionally
+    axisymmetric): with nothing prescribed, ComputeBdrViscousFluxes == ComputeViscousFluxes . n, rel <= 5e-13
+    per equation (the density row is skipped there too)."""
+    axisym = kind.endswith("axisym")
+    if kind == "ternary_2T":
+        ph = capi.argon_ternary_physics(capi.NS, True, capi.CONSTANT, None)
+    else:
+        ph = capi.argon_six_species_physics(capi.NS, capi.CONSTANT, True, False)
+    if axisym:
+        mesh = meshgen.box_quad(1, 1, periodic=(False, False), origin=(0.1, 0.0))
+        bcs = [capi.make_bc(a + 1, capi.WALL, capi.INV) for a in range(4)]
+    else:
+        mesh = meshgen.box_hex(1, 1, 1, periodic=(False,) * 3)
+        bcs = [capi.make_bc(a + 1, capi.WALL, capi.INV) for a in range(6)]
+    o = Oracle(mesh, capi.Disc(1, 0, 0, 1 if axisym else 0, 0), ph, bcs)
+    dim = 2 if axisym else 3
+    rng = np.random.default_rng(8)
+    X = rng.uniform(0, 1, size=(dim, 12))
+    states = cases.plasma_state(X, ph, nvel=3, seed=21).T
+    for U in states:
+        g = rng.uniform(-10.0, 10.0, size=(dim, o.neq)) * np.abs(o.prim(U))[None, :] * 1e-2
+        n = np.zeros(3)
+        n[:dim] = rng.standard_normal(dim)
+        n /= np.linalg.norm(n)
+        radius = 0.37 if axisym else -1.0
+        fv = o.viscous_flux(U, g.ravel(), radius)
+        ref = (fv[:dim] * n[:dim, None]).sum(axis=0)
+        got = o.bdr_viscous_flux(U, g.ravel(), n, radius=radius)
+        assert np.abs(got[1:] - ref[1:]).max() < 5e-13 * np.abs(ref[1:]).max()
