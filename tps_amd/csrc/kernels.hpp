@@ -25,6 +25,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "basis.hpp"
 #include "physics_dryair.hpp"
 
@@ -651,25 +653,11 @@ __device__ inline void visc_interp_dir(const double *sU, const double *g, bool n
                                        const Tab<C> &tab, const Tables1D &ct,
                                        double (&v)[C::Q_ROUNDS][GradLds<C, PH>::NVF], int tid) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-#pragma unroll
-  for (int c = 0; c <= DIM; c++) {
-    const double *src = sU;
-    if (c > 0) {
-      if constexpr (GradLds<C, PH>::G_IN_LDS) {
-        src = sJ + (c - 1) * NEQ * C::NODES;
-      } else {
-        if (node_on) {
-#pragma unroll
-          for (int eq = 0; eq < NEQ; eq++) sJ[eq * C::NODES + tid] = g[eq + (c - 1) * NEQ];
-        }
-        block_sync<C::BLOCK>();
-        src = sJ;
-      }
-    }
-    trace_lines<C, D, NEQ>(src, Tb, ct, tid);
-    block_sync<C::BLOCK>();
-    interp1_lines<C, NEQ>(Tb, Wb, ct, tid);
-    if (DIM == 3) block_sync<C::BLOCK>();
+  // gradient rows the viscous flux reads: a perfect gas never looks at grad(rho), and 4 fields x 16
+  // lines fill one 64-lane round of the line stages where 5 need two
+  constexpr int G0 = PH::VISC_USES_GRAD_RHO ? 0 : 1, NG = NEQ - G0;
+  auto point_stage = [&](auto nfld_tag, int v0, const double *T, const double *W) {
+    constexpr int NF_ = decltype(nfld_tag)::value;
 #pragma unroll
     for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
       const int item = tid + rd * C::BLOCK;
@@ -680,9 +668,40 @@ __device__ inline void visc_interp_dir(const double *sU, const double *g, bool n
 #pragma unroll
         for (int a = 0; a < C::N1; a++) bq[a] = tab.B[qrow * C::N1 + a];
 #pragma unroll
-        for (int k = 0; k < NEQ; k++) v[rd][c * NEQ + k] = interp2_point<C>(Tb + k * C::TN, Wb + k * C::TW, bq, pf, q);
+        for (int k = 0; k < NF_; k++) v[rd][v0 + k] = interp2_point<C>(T + k * C::TN, W + k * C::TW, bq, pf, q);
       }
     }
+  };
+  // chunk 0: the conserved state
+  trace_lines<C, D, NEQ>(sU, Tb, ct, tid);
+  block_sync<C::BLOCK>();
+  interp1_lines<C, NEQ>(Tb, Wb, ct, tid);
+  if (DIM == 3) block_sync<C::BLOCK>();
+  point_stage(std::integral_constant<int, NEQ>(), 0, Tb, Wb);
+  block_sync<C::BLOCK>();
+  // chunks 1..DIM: one gradient direction each
+#pragma unroll
+  for (int c = 1; c <= DIM; c++) {
+    const double *src;
+    if constexpr (GradLds<C, PH>::G_IN_LDS) {
+      src = sJ + ((c - 1) * NEQ + G0) * C::NODES;
+    } else {
+      if (node_on) {
+#pragma unroll
+        for (int eq = G0; eq < NEQ; eq++) sJ[eq * C::NODES + tid] = g[eq + (c - 1) * NEQ];
+      }
+      block_sync<C::BLOCK>();
+      src = sJ + G0 * C::NODES;
+    }
+    trace_lines<C, D, NG>(src, Tb, ct, tid);
+    block_sync<C::BLOCK>();
+    interp1_lines<C, NG>(Tb, Wb, ct, tid);
+    if (DIM == 3) block_sync<C::BLOCK>();
+    if (G0) {
+#pragma unroll
+      for (int rd = 0; rd < C::Q_ROUNDS; rd++) v[rd][c * NEQ] = 0.0;
+    }
+    point_stage(std::integral_constant<int, NG>(), c * NEQ + G0, Tb, Wb);
     block_sync<C::BLOCK>();
   }
 }

@@ -69,6 +69,7 @@ struct DryAirPhys {
   static constexpr int NACTIVE = 0;
   static constexpr bool HAS_SOURCE = false;
   static constexpr bool AXISYM = false;
+  static constexpr bool VISC_USES_GRAD_RHO = false;  // Newtonian stress + Fourier flux: grad u and grad T only
   static constexpr bool HEAVY = false;  // light point physics: inlined at every face pass
   static constexpr int MINW_GRAD = TPSRHS_MINW_GRAD, MINW_FLUX = TPSRHS_MINW_FLUX;  // launch-bound waves per SIMD
   typedef DryAirParams Params;
