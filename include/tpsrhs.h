@@ -281,6 +281,17 @@ int tpsrhs_kernel_times(tpsrhs_handle h, int capacity, const char **names, doubl
  * the order of tpsrhs_kernel_times. */
 int tpsrhs_kernel_bytes(tpsrhs_handle h, int capacity, const char **names, double *bytes);
 
+/* ---- next row of the scope table: one explicit RK4 step on the device ----
+ * Replaces M2ulPhyS::solveStep's `timeIntegrator->Step(*U, time, dt); Check_NAN(); Check_Undershoot();`
+ * (src/M2ulPhyS.cpp:2004-2008) for the RK4 integrator (time-integrator type 4, src/M2ulPhyS.cpp:721-739):
+ * the four stages of MFEM's RK4Solver::Step [third party: MFEM >= 4.4, linalg/ode.cpp] with the stage
+ * combinations fused into one streaming kernel per stage, the NaN census of Check_NAN
+ * (src/M2ulPhyS.cpp:2463-2524) and, for USER_DEFINED fluids, the species clamp of Check_Undershoot
+ * (:2526-2548) fused into the last one.  x: device vector, updated in place; *time += dt.
+ * max_char_speed (may be NULL): value left by the last stage's Mult, which the reference turns into the
+ * next dt (src/M2ulPhyS.cpp:2013-2016).  nan_count (may be NULL): number of NaN entries of the new x. */
+int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double *max_char_speed, int64_t *nan_count);
+
 /* Host-only view of the face topology tpsrhs_create derives from a mesh (the role of the
  * indirection arrays of src/M2ulPhyS.cpp:816-1486); touches no device.  Outputs (caller-allocated):
  *   face_nbr[ne*2*dim]   >= 0: trace slot (element*2*dim + local face) of the neighbour, slots

@@ -653,6 +653,48 @@ int tpsoracle_point_flux_transport(void *h, const double *state, const double *g
   op->transport->ComputeFluxTransportProperties(state, gradUp, E, -1.0, 0.0, buffer4, diffVel);
   return 0;
 }
+// One RK4 step as M2ulPhyS::solveStep takes it (src/M2ulPhyS.cpp:2004-2008): MFEM's RK4Solver::Step
+// [third party, MFEM >= 4.4 linalg/ode.cpp: k1..k4 with y = x + a dt k, z accumulating dt/6, dt/3, dt/3, dt/6],
+// then the NaN census of Check_NAN and, for mixtures, the species clamp of Check_Undershoot (:2526-2548).
+int tpsoracle_rk4_step(void *h, double *x, double *time, double dt, double *max_char_speed, int64_t *nan_count) {
+  Operator *op = static_cast<Operator *>(h);
+  const int64_t n = static_cast<int64_t>(op->neq) * op->ndofs;
+  std::vector<double> k(n), y(n), z(n);
+  try {
+    op->mult(x, k.data(), *time);
+    for (int64_t i = 0; i < n; i++) {
+      y[i] = x[i] + (dt / 2) * k[i];
+      z[i] = x[i] + (dt / 6) * k[i];
+    }
+    op->mult(y.data(), k.data(), *time + dt / 2);
+    for (int64_t i = 0; i < n; i++) {
+      y[i] = x[i] + (dt / 2) * k[i];
+      z[i] += (dt / 3) * k[i];
+    }
+    op->mult(y.data(), k.data(), *time + dt / 2);
+    for (int64_t i = 0; i < n; i++) {
+      y[i] = x[i] + dt * k[i];
+      z[i] += (dt / 3) * k[i];
+    }
+    op->mult(y.data(), k.data(), *time + dt);
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+  int64_t bad = 0;
+  const int sp0 = op->nvel + 2, sp1 = sp0 + op->mixture->numActiveSpecies;
+  for (int64_t i = 0; i < n; i++) {
+    double v = z[i] + (dt / 6) * k[i];
+    if (v != v) bad++;
+    const int64_t eq = i / op->ndofs;
+    if (eq >= sp0 && eq < sp1) v = std::max(v, 0.0);
+    x[i] = v;
+  }
+  *time += dt;
+  if (max_char_speed) *max_char_speed = op->max_char_speed;
+  if (nan_count) *nan_count = bad;
+  return 0;
+}
 // collision-integral fits by name id: 0 att11, 1 att12, 2 att13, 3 att14, 4 att15, 5 rep22, 6 rep23,
 // 7 rep24 (argument: nondimensional temperature); 8 ArAr22, 9 ArAr1P11, 10..14 eAr1r r=1..5 (argument: T in K)
 double tpsoracle_collision_integral(int id, double x) {

@@ -55,6 +55,7 @@ def lib():
         L.tpsoracle_point_bdr_flux.argtypes = [vp, C.c_int, _dp, _dp, _dp, C.c_double, _dp]
         L.tpsoracle_point_flux_transport.argtypes = [vp, _dp, _dp, _dp, _dp]
         L.tpsoracle_point_source.argtypes = [vp, _dp, _dp, _dp, _dp]
+        L.tpsoracle_rk4_step.argtypes = [vp, _dp, _dp, C.c_double, _dp, C.POINTER(C.c_int64)]
         L.tpsoracle_point_source_transport.argtypes = [vp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.tpsoracle_collision_integral.restype = C.c_double
         L.tpsoracle_collision_integral.argtypes = [C.c_int, C.c_double]
@@ -200,6 +201,17 @@ class Oracle:
         if st != 0:
             raise RuntimeError("oracle: " + lib().tpsoracle_last_error().decode())
         return out
+
+    def rk4_step(self, x, time, dt):
+        """-> (new x, new time, max_char_speed of the last stage, NaN count)"""
+        xx = np.ascontiguousarray(x, dtype=np.float64).copy()
+        t = C.c_double(time)
+        speed = C.c_double(0.0)
+        bad = C.c_int64(0)
+        st = lib().tpsoracle_rk4_step(self.h, _p(xx), C.byref(t), float(dt), C.byref(speed), C.byref(bad))
+        if st != 0:
+            raise RuntimeError("oracle: " + lib().tpsoracle_last_error().decode())
+        return xx, t.value, speed.value, bad.value
 
     def flux_transport(self, state, grad):
         """(viscosity, bulk, k_heavy, k_electron), diffusion velocities [sp + d*nsp]"""

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     lib = capi.load()
     hdr = open(os.path.join(ROOT, "include", "tpsrhs.h")).read()
-    declared = set(re.findall(r"^(?:int|int64_t|const char \*)\s*(tpsrhs_[a-z_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char \*)\s*(tpsrhs_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name

@@ -1,0 +1,64 @@
+"""One and several RK4 steps on the device (tpsrhs_rk4_step) against the oracle's
+restatement of M2ulPhyS::solveStep's integrator call + Check_NAN + Check_Undershoot."""
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle
+from parity_util import rel_maxnorm
+from tps_amd import capi, cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(c, U, dt, nsteps):
+    import torch
+    from tps_amd.rhs_operator import RHSoperator
+
+    op = RHSoperator(c.mesh, c.disc, c.physics, c.bcs)
+    x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
+    t = 0.0
+    for _ in range(nsteps):
+        t = op.rk4_step(x, t, dt, want_max_char_speed=True, want_nan_count=True)
+    torch.cuda.synchronize()
+    out = x.cpu().numpy().reshape(U.shape), t, op.max_char_speed, op.nan_count
+    op.close()
+    return out
+
+
+@pytest.mark.parametrize("kind", ["dry_air", "argon_2T"])
+def test_rk4_steps_match_oracle(kind):
+    if kind == "dry_air":
+        c = cases.cyl3d(4, 12, 3, 2, capi.NS, capi.VISC_ISOTH)
+        c.physics.dry_air.visc_mult = 100.0
+        U = c.state(seed=2)
+    else:
+        c = cases.argon_cyl3d(4, 12, 3, 2, True, capi.CONSTANT, "arrhenius", capi.VISC_ISOTH)
+        U = c.state(seed=2, amp=0.01)
+    o = Oracle(c.mesh, c.disc, c.physics, c.bcs)
+    y0 = o.mult(U)
+    # a stable explicit step: a tenth of the fastest local time scale of the residual (the electron energy
+    # exchange of the two-temperature plasma is much stiffer than the acoustic CFL limit)
+    dt = 0.1 / (np.abs(y0) / np.maximum(np.abs(U), 1e-300 + 1e-6 * np.abs(U).max(axis=1, keepdims=True))).max()
+    nsteps = 3
+    ref, t = U.copy(), 0.0
+    for _ in range(nsteps):
+        ref, t, speed, bad = o.rk4_step(ref, t, dt)
+    got, tg, gspeed, gbad = _run(c, U, dt, nsteps)
+    assert tg == pytest.approx(t, rel=1e-15) and gbad == bad == 0
+    # the state moves by O(dt |f|): measure the difference against that increment
+    incr = np.abs(ref - U).reshape(U.shape[0], -1).max(axis=1)
+    err = np.abs(got - ref).reshape(U.shape[0], -1).max(axis=1)
+    print("increment", incr, "difference", err)
+    assert (err <= 1e-9 * incr + 1e-15 * np.abs(U).reshape(U.shape[0], -1).max(axis=1)).all()
+    assert rel_maxnorm(got, ref).max() < 1e-13
+    assert gspeed == pytest.approx(speed, rel=1e-12)
+
+
+def test_rk4_counts_nans_and_clamps_species():
+    c = cases.argon_cyl3d(4, 12, 3, 1, False, capi.CONSTANT, None, capi.VISC_ISOTH)
+    U = c.state(seed=3, amp=0.005)
+    U[0, 5] = np.nan  # one bad density entry poisons its element
+    got, _, _, bad = _run(c, U, 1e-9, 1)
+    # the census (Check_NAN) runs before the clamp (Check_Undershoot), and max(NaN, 0) = 0 in the species rows
+    assert bad >= np.isnan(got).sum() > 0
+    assert not np.isnan(got[5]).any() and np.isnan(got[:5]).sum() == np.isnan(got).sum()

@@ -375,6 +375,7 @@ def load():
     lib.tpsrhs_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.tpsrhs_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_kernel_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
+    lib.tpsrhs_rk4_step.argtypes = [vp, C.c_void_p, _dp, C.c_double, _dp, C.POINTER(C.c_int64)]
     lib.tpsrhs_face_tables.restype = C.c_int
     lib.tpsrhs_face_tables.argtypes = [C.POINTER(Mesh), C.c_int, C.POINTER(BC), vp, vp, vp, vp]
     lib.tpsrhs_status_string.restype = C.c_char_p
@@ -389,7 +390,7 @@ EXPORTED_SYMBOLS = [
     "tpsrhs_create", "tpsrhs_destroy", "tpsrhs_mult", "tpsrhs_mult_host", "tpsrhs_update_gradients",
     "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
     "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_kernel_bytes", "tpsrhs_face_tables",
-    "tpsrhs_status_string",
+    "tpsrhs_rk4_step", "tpsrhs_status_string",
     "tpsrhs_last_error", "tpsrhs_version",
 ]
 

@@ -1196,6 +1196,39 @@ __global__ void k_reduce_max(int n, const double *__restrict__ v, double *__rest
 }
 
 // =============================================================================================
+// RK4 stage combinations (MFEM RK4Solver::Step) as one streaming pass per stage:
+//   stage 1: y = x + dt/2 k, z = x + dt/6 k     stage 2: y = x + dt/2 k, z += dt/3 k
+//   stage 3: y = x + dt k,   z += dt/3 k        stage 4: x = z + dt/6 k (+ NaN census, species clamp)
+// =============================================================================================
+template <int BLOCK>
+__global__ void k_rk4_stage(int stage, int64_t n, int64_t ndofs, int sp_first, int sp_last, double dt,
+                            double *__restrict__ x, const double *__restrict__ k, double *__restrict__ y,
+                            double *__restrict__ z, unsigned long long *__restrict__ nan_count) {
+  unsigned long long bad = 0;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * BLOCK) {
+    const double ki = k[i];
+    if (stage == 1) {
+      const double xi = x[i];
+      y[i] = xi + (dt / 2) * ki;
+      z[i] = xi + (dt / 6) * ki;
+    } else if (stage == 2) {
+      y[i] = x[i] + (dt / 2) * ki;
+      z[i] += (dt / 3) * ki;
+    } else if (stage == 3) {
+      y[i] = x[i] + dt * ki;
+      z[i] += (dt / 3) * ki;
+    } else {
+      double v = z[i] + (dt / 6) * ki;
+      if (v != v) bad++;
+      const int64_t eq = i / ndofs;
+      if (eq >= sp_first && eq < sp_last) v = fmax(v, 0.0);  // Check_Undershoot
+      x[i] = v;
+    }
+  }
+  if (stage == 4 && bad) atomicAdd(nan_count, bad);
+}
+
+// =============================================================================================
 // halo packing: permute the traces of the shared faces into the canonical frame both ranks agree on
 // (role of the pack kernel of initNBlockDataTransfer, src/rhs_operator.cpp:798-803)
 // =============================================================================================

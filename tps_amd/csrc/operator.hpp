@@ -72,6 +72,8 @@ struct tpsrhs_operator {
   double *d_speed = nullptr, *d_block_speed = nullptr;
   int flux_grid = 0;
   double *d_xh = nullptr, *d_yh = nullptr;  // staging for tpsrhs_mult_host
+  double *d_rk = nullptr;                   // k | y | z of tpsrhs_rk4_step
+  unsigned long long *d_nan = nullptr;
   // halo
   tpsrhs_halo_fn halo = nullptr;
   void *halo_ctx = nullptr;
@@ -111,6 +113,8 @@ struct tpsrhs_operator {
                     static_cast<void *>(d_shared_orient), static_cast<void *>(d_send)})
       if (p) (void)hipFree(p);
     if (d_chem) (void)hipFree(d_chem);
+    if (d_rk) (void)hipFree(d_rk);
+    if (d_nan) (void)hipFree(d_nan);
     if (d_blocks_halo) (void)hipFree(d_blocks_halo);
     if (d_blocks_interior) (void)hipFree(d_blocks_interior);
     for (auto &e : ev_halo)

@@ -386,6 +386,46 @@ int tpsrhs_mult_host(tpsrhs_handle h, const double *x, double *y, double time, d
   });
 }
 
+int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double *max_char_speed, int64_t *nan_count) {
+  if (!h || !x || !time) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_rk4_step: NULL argument");
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(h->device));
+    const int64_t n = static_cast<int64_t>(h->neq) * h->ndofs;
+    if (!h->d_rk) {
+      h->d_rk = dev_alloc<double>(3 * n);
+      h->d_nan = dev_alloc<unsigned long long>(1);
+    }
+    double *k = h->d_rk, *y = k + n, *z = y + n;
+    HIP_CHECK(hipMemsetAsync(h->d_nan, 0, sizeof(unsigned long long), h->stream));
+    const bool mixture = h->phys.working_fluid == TPSRHS_USER_DEFINED;
+    const int sp_first = h->nvel + 2;
+    const int sp_last = mixture ? sp_first + (h->phys.mixture.ambipolar ? h->phys.mixture.num_species - 2
+                                                                         : h->phys.mixture.num_species - 1)
+                                : sp_first;
+    const int grid = static_cast<int>(std::min<int64_t>((n + 255) / 256, 8192));
+    const double *in = x;
+    for (int stage = 1; stage <= 4; stage++) {
+      h->launch(h, in, k, false);  // k_s = f(stage input); SetTime is a no-op for this operator
+      hipLaunchKernelGGL(k_rk4_stage<256>, dim3(grid), dim3(256), 0, h->stream, stage, n, h->ndofs, sp_first, sp_last,
+                         dt, x, k, y, z, h->d_nan);
+      HIP_CHECK(hipGetLastError());
+      in = y;
+    }
+    *time += dt;
+    if (max_char_speed || nan_count) {
+      hipLaunchKernelGGL(k_reduce_max<256>, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_speed);
+      HIP_CHECK(hipGetLastError());
+      double speed = 0.0;
+      unsigned long long bad = 0;
+      HIP_CHECK(hipMemcpyAsync(&speed, h->d_speed, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIP_CHECK(hipMemcpyAsync(&bad, h->d_nan, sizeof(bad), hipMemcpyDeviceToHost, h->stream));
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      if (max_char_speed) *max_char_speed = speed;
+      if (nan_count) *nan_count = static_cast<int64_t>(bad);
+    }
+  });
+}
+
 int tpsrhs_update_gradients(tpsrhs_handle h, const double *x) {
   if (!h || !x) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_update_gradients: NULL argument");
   return guarded([&] {

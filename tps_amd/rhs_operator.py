@@ -117,6 +117,25 @@ class RHSoperator:
         n = self._lib.tpsrhs_kernel_times(self._h, 8, names, ms)
         return {names[i].decode(): ms[i] for i in range(n)}
 
+    def rk4_step(self, x: torch.Tensor, time: float, dt: float, want_max_char_speed=False, want_nan_count=False):
+        """One explicit RK4 step, ``x`` updated in place; returns the new time (the role of
+        ``timeIntegrator->Step(*U, time, dt); Check_NAN(); Check_Undershoot();`` in
+        ``M2ulPhyS::solveStep``, ``src/M2ulPhyS.cpp:2004-2008``)."""
+        self._check(x)
+        t = C.c_double(time)
+        speed = C.c_double(0.0)
+        bad = C.c_int64(0)
+        st = self._lib.tpsrhs_rk4_step(self._h, C.c_void_p(x.data_ptr()), C.byref(t), float(dt),
+                                       C.byref(speed) if want_max_char_speed else None,
+                                       C.byref(bad) if want_nan_count else None)
+        if st != 0:
+            raise RuntimeError(f"tpsrhs_rk4_step: {capi.STATUS.get(st, st)}: {self._lib.tpsrhs_last_error().decode()}")
+        if want_max_char_speed:
+            self.max_char_speed = speed.value
+        if want_nan_count:
+            self.nan_count = bad.value
+        return t.value
+
     def kernel_bytes(self):
         names = (C.c_char_p * 8)()
         b = (C.c_double * 8)()
