@@ -157,11 +157,13 @@ def main():
     halo = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        fallback = None
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            fallback = dist.new_group(backend="gloo")  # only used if the first RCCL exchange raises
         else:
             dist.init_process_group("gloo")
-        halo = HaloExchange(device=torch.device("cuda", local_rank))
+        halo = HaloExchange(device=torch.device("cuda", local_rank), fallback_group=fallback)
 
     def barrier():
         if world > 1:

@@ -28,8 +28,10 @@ class _DevPtr:
 
 
 class HaloExchange:
-    def __init__(self, group=None, device=None, host_buffers=False):
+    def __init__(self, group=None, device=None, host_buffers=False, fallback_group=None):
         self.group = group
+        self.fallback_group = fallback_group  # a gloo group: used (staged through host) if the first exchange on
+        #                                       the primary backend raises, so a run degrades instead of dying
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         self.device = device
         self.host_buffers = host_buffers  # True: pointers handed to callback are HOST memory (CPU rehearsal)
@@ -50,7 +52,21 @@ class HaloExchange:
         try:
             if not self.host_buffers and torch.cuda.is_available():
                 with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0), device=self.device)):
-                    return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
+                    try:
+                        return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
+                    except Exception:
+                        if self.fallback_group is None or self.calls > 0:
+                            raise
+                        import sys
+                        import traceback
+
+                        traceback.print_exc()
+                        print("tps_amd.halo: primary backend failed on its first exchange; staging through the "
+                              "fallback (gloo) group from now on", file=sys.stderr)
+                        self.group, self.fallback_group = self.fallback_group, None
+                        self.backend = dist.get_backend(self.group)
+                        self._plans.clear()
+                        return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
             return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
         except Exception as exc:  # never let an exception cross the C boundary
             import traceback
