@@ -498,14 +498,15 @@ __device__ inline void issue_visc_traces(const int2 *sFI, int e0, const double *
       const int2 fi = sFI[lslot];
       t.nb[r] = fi.x;
       if (fi.x != INT32_MIN && !(TPSRHS_ABLATE & 1)) {
-        const double *o = TB + (static_cast<int64_t>(e0) * C::NFACES + lslot) * (NEQ * C::NQ) + q;
+        // the records hold equations 1 .. NEQ-1: the viscous flux of the continuity equation is zero
+        const double *o = TB + (static_cast<int64_t>(e0) * C::NFACES + lslot) * ((NEQ - 1) * C::NQ) + q;
 #pragma unroll
-        for (int k = 0; k < NEQ; k++) t.own[r][k] = o[k * C::NQ];
+        for (int k = 1; k < NEQ; k++) t.own[r][k] = o[(k - 1) * C::NQ];
         if (fi.x >= 0) {
           const int pq = permute<C::DIM>(fi.y, C::Q1, q % C::Q1, q / C::Q1);
-          const double *b2 = TB + static_cast<int64_t>(fi.x) * (NEQ * C::NQ) + pq;
+          const double *b2 = TB + static_cast<int64_t>(fi.x) * ((NEQ - 1) * C::NQ) + pq;
 #pragma unroll
-          for (int k = 0; k < NEQ; k++) t.nbv[r][k] = b2[k * C::NQ];
+          for (int k = 1; k < NEQ; k++) t.nbv[r][k] = b2[(k - 1) * C::NQ];
         }
       }
     }
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Par
 
 // =============================================================================================
 // sweep 1: gradient of the primitives (BR1-type: volume derivative + face jump lifting, diagonal
-// inverse mass) and the viscous normal-flux traces TB[slot][NEQ][NQ]:
+// inverse mass) and the viscous normal-flux traces TB[slot][NEQ-1][NQ] (equations 1 .. NEQ-1):
 //   interior / shared face: F_v(U_q, gradUp_q) . n_out   (the consumer forms -1/2 (own - neighbour))
 //   boundary face:          the complete additive viscous term of the boundary flux
 // =============================================================================================
@@ -745,9 +746,9 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const type
         PH::bc_visc_term(prm, prm.bc[-nb - 1], v[rd], v[rd] + NEQ, n, fn);
       }
     }
-    double *out = TB + static_cast<int64_t>(slot) * (NEQ * C::NQ) + q;
+    double *out = TB + static_cast<int64_t>(slot) * ((NEQ - 1) * C::NQ) + q;
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) out[eq * C::NQ] = fn[eq];
+    for (int eq = 1; eq < NEQ; eq++) out[(eq - 1) * C::NQ] = fn[eq];  // fn[0] == 0 (src/fluxes.cpp:284)
   }
 }
 template <class C, class PH, int D>

@@ -223,7 +223,7 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     HIP_CHECK(hipEventRecord(op->ev_halo[2], s));
     if (ni) flux(mi, ni);
     HIP_CHECK(hipStreamWaitEvent(c, op->ev_halo[2], 0));
-    exchange(op, 1, op->d_TB, PH::NEQ, C::NQ, c);  // overlaps the interior flux launch
+    exchange(op, 1, op->d_TB, PH::NEQ - 1, C::NQ, c);  // overlaps the interior flux launch
     HIP_CHECK(hipEventRecord(op->ev_halo[3], c));
     HIP_CHECK(hipStreamWaitEvent(s, op->ev_halo[3], 0));
     flux(mh, nh);

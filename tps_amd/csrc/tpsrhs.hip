@@ -285,15 +285,15 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   op->d_Up = dev_alloc<double>(op->neq * op->ndofs);
   op->d_gradUp = dev_alloc<double>(op->dim * op->neq * op->ndofs);
   op->d_TA = dev_alloc<double>(nslots * 2 * op->neq * op->nf);
-  op->d_TB = dev_alloc<double>(nslots * op->neq * op->nq);
+  op->d_TB = dev_alloc<double>(nslots * (op->neq - 1) * op->nq);
   HIP_CHECK(hipMemset(op->d_TA, 0, nslots * 2 * op->neq * op->nf * sizeof(double)));
-  HIP_CHECK(hipMemset(op->d_TB, 0, nslots * op->neq * op->nq * sizeof(double)));
+  HIP_CHECK(hipMemset(op->d_TB, 0, nslots * (op->neq - 1) * op->nq * sizeof(double)));
   op->d_speed = dev_alloc<double>(1);
   HIP_CHECK(hipMemset(op->d_speed, 0, sizeof(double)));
   if (tp.num_shared > 0) {
     op->d_shared_slot = dev_upload(tp.shared_slot);
     op->d_shared_orient = dev_upload(tp.shared_orient);
-    const int64_t per0 = 2 * op->neq * op->nf, per1 = static_cast<int64_t>(op->neq) * op->nq;
+    const int64_t per0 = 2 * op->neq * op->nf, per1 = static_cast<int64_t>(op->neq - 1) * op->nq;
     op->d_send = dev_alloc<double>(tp.num_shared * std::max(per0, per1));
     for (size_t i = 0; i < tp.nbr_offsets.size(); i++) {
       op->send_off[0].push_back(tp.nbr_offsets[i] * per0);
@@ -483,7 +483,7 @@ int tpsrhs_kernel_bytes(tpsrhs_handle h, int capacity, const char **names, doubl
   // algorithmic HBM traffic of the three sweeps ("bytes per unit"), in bytes per Mult
   const double N = static_cast<double>(h->ndofs), neq = h->neq, dim = h->dim;
   const double slots = static_cast<double>(h->ne) * h->nfaces;
-  const double ta = slots * 2 * neq * h->nf, tb = slots * neq * h->nq;
+  const double ta = slots * 2 * neq * h->nf, tb = slots * (neq - 1) * h->nq;
   const double geo = static_cast<double>(h->ne) * (1 << h->dim) * dim;
   const double b[NKERN] = {
       8.0 * (neq * N /*U*/ + neq * N /*Up*/ + ta),
