@@ -536,7 +536,7 @@ __device__ inline void traces_dir(const MeshDev &m, int e0, const double *sF, do
 
 template <class C, class PH>
 __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
-                                                     double *__restrict__ Upout, double *__restrict__ TA) {
+                                                     double *__restrict__ TA) {
   constexpr int NEQ = PH::NEQ;
   const Tables1D &ct = c_tab[C::DIM - 2][C::P];
   __shared__ double sF[2 * NEQ * C::NODES];
@@ -557,7 +557,6 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Par
       for (int eq = 0; eq < NEQ; eq++) {
         sF[eq * C::NODES + tid] = u[eq];
         sF[(NEQ + eq) * C::NODES + tid] = up[eq];
-        field_ptr(Upout, eq, m.ndofs)[n] = up[eq];
       }
     }
   }
@@ -764,7 +763,8 @@ __device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const 
 template <class C, class PH>
 __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m, typename PH::Params prm,
                                                        const double *__restrict__ U, const double *__restrict__ TA,
-                                                       double *__restrict__ gradUp, double *__restrict__ TB) {
+                                                       double *__restrict__ Upout, double *__restrict__ gradUp,
+                                                       double *__restrict__ TB) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   typedef GradLds<C, PH> L;
   const Tables1D &ct = c_tab[DIM - 2][C::P];
@@ -802,6 +802,9 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
     for (int eq = 0; eq < NEQ; eq++) {
       sU[eq * C::NODES + tid] = u[eq];
       sUp[eq * C::NODES + tid] = up[eq];
+      // the Up grid function (a side effect Mult owns, src/rhs_operator.cpp:623-651) is written here: this
+      // sweep is not bandwidth-bound, k_traces is
+      field_ptr(Upout, eq, m.ndofs)[n] = up[eq];
     }
   }
   block_sync<C::BLOCK>();

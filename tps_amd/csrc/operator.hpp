@@ -160,11 +160,12 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     op->flux_grid = nblocks;
   }
   auto traces = [&](const MeshDev &m, int grid) {
-    hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_Up, op->d_TA);
+    hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_TA);
     HIP_CHECK(hipGetLastError());
   };
   auto gradient = [&](const MeshDev &m, int grid) {
-    hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_TA, op->d_gradUp, op->d_TB);
+    hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_TA, op->d_Up, op->d_gradUp,
+                       op->d_TB);
     HIP_CHECK(hipGetLastError());
   };
   auto flux = [&](const MeshDev &m, int grid) {

@@ -486,8 +486,8 @@ int tpsrhs_kernel_bytes(tpsrhs_handle h, int capacity, const char **names, doubl
   const double ta = slots * 2 * neq * h->nf, tb = slots * (neq - 1) * h->nq;
   const double geo = static_cast<double>(h->ne) * (1 << h->dim) * dim;
   const double b[NKERN] = {
-      8.0 * (neq * N /*U*/ + neq * N /*Up*/ + ta),
-      8.0 * (neq * N + 0.5 * ta /*neighbour Up traces*/ + dim * neq * N /*gradUp*/ + tb + geo),
+      8.0 * (neq * N /*U*/ + ta),
+      8.0 * (neq * N + 0.5 * ta /*neighbour Up traces*/ + neq * N /*Up*/ + dim * neq * N /*gradUp*/ + tb + geo),
       8.0 * (neq * N + dim * neq * N + 0.5 * ta /*neighbour U traces*/ + 2.0 * tb + neq * N /*y*/ + geo)};
   int n = 0;
   for (int k = 0; k < NKERN && n < capacity; k++, n++) {
