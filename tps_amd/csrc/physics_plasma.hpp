@@ -169,7 +169,7 @@ struct PlasmaPhys {
   static constexpr bool HAS_FLUX_DOT = false;
   static constexpr bool VISC_USES_GRAD_RHO = true;  // mole-fraction gradients need grad(rho)
   static constexpr bool AXISYM = NVEL_ > DIM_;  // dim 2 with (r, z, theta) velocity components
-  static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : 2, MINW_FLUX = (NSP_ > 3) ? 1 : 2;  // waves per SIMD asked of the allocator
+  static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : 2, MINW_FLUX = 2;  // waves per SIMD asked of the allocator
   typedef PlasmaParams<NSP_> Params;
   struct Transport {};
 
