@@ -204,37 +204,6 @@ struct DryAirPhys {
     visc_flux(p, U, make_state(p, U), g, F);
   }
 
-  // (F_c - F_v)(U, g) . a for an arbitrary vector a (a row of the metric adjugate at a node, or a
-  // normal): the register-lean form of ComputeConvectiveFluxes minus ComputeViscousFluxes
-  // (src/rhs_operator.cpp:532-541) -- no flux tensor is materialised.
-  __device__ static inline void total_flux_dot(const Params &p, const double *U, const State &s, const Transport &t,
-                                               double divV, const double *g, const double *a, double *Fa) {
-    double ua = 0.0;
-#pragma unroll
-    for (int d = 0; d < DIM; d++) ua += s.vel[d] * a[d];
-    Fa[0] = U[0] * ua;
-    double e = ua * (U[1 + NVEL] + s.p);
-    if (p.eq_system == TPSRHS_EULER) {
-#pragma unroll
-      for (int i = 0; i < NVEL; i++) Fa[1 + i] = U[1 + i] * ua + (i < DIM ? s.p * a[i] : 0.0);
-      Fa[1 + NVEL] = e;
-      return;
-    }
-    double qa = 0.0;
-#pragma unroll
-    for (int i = 0; i < DIM; i++) {
-      double sa = 0.0;  // sum_d a_d (d_d u_i + d_i u_d)
-#pragma unroll
-      for (int d = 0; d < DIM; d++) sa += (g[(1 + i) + d * NEQ] + g[(1 + d) + i * NEQ]) * a[d];
-      sa = t.visc * sa + t.bulk * divV * a[i];
-      Fa[1 + i] = U[1 + i] * ua + s.p * a[i] - sa;
-      e -= sa * s.vel[i];
-      qa += g[(1 + NVEL) + i * NEQ] * a[i];
-    }
-    Fa[1 + NVEL] = e - t.k * qa;
-  }
-  static constexpr bool HAS_FLUX_DOT = true;
-
   // F_c - F_v as one tensor F[eq + d*NEQ] (src/rhs_operator.cpp:532-541)
   __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const double *g,
                                            double *F) {

@@ -16,7 +16,7 @@ namespace tpsrhs {
 
 struct DryAirAxiPhys {
   static constexpr int DIM = 2, NVEL = 3, NEQ = 5, NACTIVE = 0, ITH = 4;
-  static constexpr bool HAS_SOURCE = true, HAS_FLUX_DOT = false, AXISYM = true, HEAVY = true;
+  static constexpr bool HAS_SOURCE = true, AXISYM = true, HEAVY = true;
   static constexpr bool VISC_USES_GRAD_RHO = false;
   static constexpr int MINW_GRAD = 1, MINW_FLUX = 2;
   typedef DryAirParams Params;

@@ -166,7 +166,6 @@ struct PlasmaPhys {
   static constexpr int IE = NSP_ - 2, IB = NSP_ - 1;  // electron, background
   static constexpr int ITH = NVEL_ + 1, ITE = NEQ - 1;
   static constexpr bool HAS_SOURCE = true;
-  static constexpr bool HAS_FLUX_DOT = false;
   static constexpr bool VISC_USES_GRAD_RHO = true;  // mole-fraction gradients need grad(rho)
   static constexpr bool AXISYM = NVEL_ > DIM_;  // dim 2 with (r, z, theta) velocity components
   static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : 2, MINW_FLUX = 2;  // waves per SIMD asked of the allocator
