@@ -30,6 +30,11 @@ def _case(world, kind):
         bcs = cases.cylinder_bcs(capi.VISC_ISOTH)
         Ug = cases.dry_air_state(node_coordinates(full, order), seed=5)
         return full, "slab", order, ph, bcs, Ug
+    if kind == "axisym_2T":  # 2-D shared edges, axisymmetric two-temperature plasma, three contiguous parts
+        c = cases.argon_axisym(6, 9, 2, True, capi.CONSTANT, "arrhenius", True, capi.VISC_ISOTH, r_in=0.0)
+        full = meshgen.scramble_orientations(c.mesh, 5)
+        Ug = cases.plasma_state(node_coordinates(full, 2), c.physics, nvel=3, seed=6, amp=0.01, vel0=(1.0, 20.0, 3.0))
+        return full, None, 2, c.physics, c.bcs, Ug
     full = meshgen.scramble_orientations(meshgen.ogrid_cylinder(4, 12, 4), 21)
     if kind == "dry_air":
         owner = (np.arange(full.num_elements) * 7 // 5) % world  # irregular partition: every block is a halo block
@@ -62,8 +67,8 @@ def _worker(rank, world, port, q, kind):
         else:
             part = meshgen.partition(full, world, owner)[rank]
             gel = part.global_elements
-        disc = capi.Disc(order, 0, 0, 0, 0)
-        npe = (order + 1) ** 3
+        disc = capi.Disc(order, 0, 0, 1 if kind == "axisym_2T" else 0, 0)
+        npe = (order + 1) ** full.dim
         idx = (gel[:, None] * npe + np.arange(npe)[None, :]).ravel()
         U = Ug[:, idx]  # the rank's rows of ONE global field
         halo = HaloExchange(device=torch.device("cuda", 0))
@@ -84,10 +89,10 @@ def _worker(rank, world, port, q, kind):
         q.put((rank, traceback.format_exc(), None, None, None, None))
 
 
-@pytest.mark.parametrize("world,kind", [(2, "dry_air"), (3, "argon_2T"), (2, "slab"), (4, "slab")])
+@pytest.mark.parametrize("world,kind", [(2, "dry_air"), (3, "argon_2T"), (2, "slab"), (4, "slab"), (3, "axisym_2T")])
 def test_ranks_match_serial_oracle(world, kind):
     full, owner, order, ph, bcs, Ug = _case(world, kind)
-    ref = oracle_mult(full, capi.Disc(order, 0, 0, 0, 0), ph, bcs, Ug)
+    ref = oracle_mult(full, capi.Disc(order, 0, 0, 1 if kind == "axisym_2T" else 0, 0), ph, bcs, Ug)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -107,6 +112,6 @@ def test_ranks_match_serial_oracle(world, kind):
         mcs = max(mcs, speed)
     err = rel_maxnorm(y, ref["y"])
     print(world, "ranks: rel err", err)
-    assert err.max() < (5 * RHS_RTOL if kind == "argon_2T" else RHS_RTOL)  # plasma state: 1 % perturbations
+    assert err.max() < (5 * RHS_RTOL if kind in ("argon_2T", "axisym_2T") else RHS_RTOL)  # plasma: 1 % perturbations
     assert np.abs(g - ref["gradUp"]).max() < RHS_RTOL * np.abs(ref["gradUp"]).max()
     assert abs(mcs - ref["max_char_speed"]) < 1e-12 * mcs
