@@ -94,6 +94,10 @@ struct Cfg {
   static constexpr int TQ = PF * NQ;
   static constexpr int LN = EPB * NF;
   static constexpr int Q_ROUNDS = (TQ + BLOCK - 1) / BLOCK;
+  // 2-D: the quadrature points of BOTH direction pairs of a block are worked on together (at p = 3 they
+  // are 2 x 32 = one full 64-lane round; one pair at a time leaves half of the lanes idle in the physics)
+  static constexpr int TQ2 = 2 * TQ;
+  static constexpr int Q2_ROUNDS = (TQ2 + BLOCK - 1) / BLOCK;
 };
 
 // LDS copy of the tables that are indexed per lane
@@ -581,7 +585,7 @@ struct GradLds {
   // latencies of the line stages overlap.  [ sU | sUp (viscous phase: T chunk) | J | W ]
   //   J: jump phase  -- own | neighbour Up traces of ONE direction pair
   //      viscous phase -- the nodal values of one gradient direction (re-written from registers per chunk)
-  static constexpr int SUP = cmax(NEQ * C::NODES, CH * C::TN);
+  static constexpr int SUP = cmax(NEQ * C::NODES, (DIM == 2 ? 2 : 1) * CH * C::TN);  // 2-D: T chunks of both directions
   // (heavy point physics is register-bound, not LDS-bound: there the whole nodal gradient stays in J and the
   //  node lanes' registers are released before the physics)
   static constexpr bool G_IN_LDS = PH::HEAVY;
@@ -717,15 +721,20 @@ __device__ inline void face_geometry_rt(int d, const double *verts, const Tab<C>
 }
 // ... and the point physics on them.  `d` is a run-time value here so that physics with a large body
 // (PH::HEAVY: plasma transport) is instantiated once per kernel, not once per direction pair.
-template <class C, class PH>
+template <class C, class PH, bool BOTH = false>
 __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0, int d,
-                                   double (&v)[C::Q_ROUNDS][GradLds<C, PH>::NVF], const double *sV, const Tab<C> &tab,
-                                   double *__restrict__ TB, int tid) {
+                                   double (&v)[BOTH ? C::Q2_ROUNDS : C::Q_ROUNDS][GradLds<C, PH>::NVF], const double *sV,
+                                   const Tab<C> &tab, double *__restrict__ TB, int tid) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  constexpr int ROUNDS = BOTH ? C::Q2_ROUNDS : C::Q_ROUNDS, ITEMS = BOTH ? C::TQ2 : C::TQ;
 #pragma unroll
-  for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
-    const int item = tid + rd * C::BLOCK;
-    if (item >= C::TQ) continue;
+  for (int rd = 0; rd < ROUNDS; rd++) {
+    int item = tid + rd * C::BLOCK;
+    if (item >= ITEMS) continue;
+    if (BOTH) {  // items of direction pair 0, then of direction pair 1
+      d = item / C::TQ;
+      item -= d * C::TQ;
+    }
     const int pf = item / C::NQ, q = item - pf * C::NQ;
     const int le = pf >> 1, s = pf & 1;
     const int e = e0 + le;
@@ -749,6 +758,61 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const type
 #pragma unroll
     for (int eq = 1; eq < NEQ; eq++) out[(eq - 1) * C::NQ] = fn[eq];  // fn[0] == 0 (src/fluxes.cpp:284)
   }
+}
+// 2-D viscous phase: both direction pairs at once (see Cfg::TQ2)
+template <class C, class PH>
+__device__ inline void visc_phase_2d(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
+                                     const double *sU, const double *g, bool node_on, double *sJ, double *Tb,
+                                     const double *sV, const Tab<C> &tab, const Tables1D &ct, double *__restrict__ TB,
+                                     int tid) {
+  static_assert(C::DIM == 2, "2-D only");
+  constexpr int NEQ = PH::NEQ;
+  typedef GradLds<C, PH> L;
+  constexpr int G0 = PH::VISC_USES_GRAD_RHO ? 0 : 1, NG = NEQ - G0;
+  double v[C::Q2_ROUNDS][L::NVF];
+  auto chunk = [&](auto nfld_tag, const double *src, int v0) {
+    constexpr int NF_ = decltype(nfld_tag)::value;
+    trace_lines<C, 0, NF_>(src, Tb, ct, tid);
+    trace_lines<C, 1, NF_>(src, Tb + L::CH * C::TN, ct, tid);
+    block_sync<C::BLOCK>();
+#pragma unroll
+    for (int rd = 0; rd < C::Q2_ROUNDS; rd++) {
+      int item = tid + rd * C::BLOCK;
+      if (item < C::TQ2) {
+        const int d = item / C::TQ;
+        item -= d * C::TQ;
+        const int pf = item / C::NQ, q = item - pf * C::NQ;
+        const double *T = Tb + d * (L::CH * C::TN);
+        double bq[C::N1];
+#pragma unroll
+        for (int a = 0; a < C::N1; a++) bq[a] = tab.B[q * C::N1 + a];
+#pragma unroll
+        for (int k = 0; k < NF_; k++) v[rd][v0 + k] = interp2_point<C>(T + k * C::TN, nullptr, bq, pf, q);
+      }
+    }
+    block_sync<C::BLOCK>();
+  };
+  chunk(std::integral_constant<int, NEQ>(), sU, 0);
+#pragma unroll
+  for (int c = 1; c <= 2; c++) {
+    const double *src;
+    if constexpr (L::G_IN_LDS) {
+      src = sJ + ((c - 1) * NEQ + G0) * C::NODES;
+    } else {
+      if (node_on) {
+#pragma unroll
+        for (int eq = G0; eq < NEQ; eq++) sJ[eq * C::NODES + tid] = g[eq + (c - 1) * NEQ];
+      }
+      block_sync<C::BLOCK>();
+      src = sJ + G0 * C::NODES;
+    }
+    if (G0) {
+#pragma unroll
+      for (int rd = 0; rd < C::Q2_ROUNDS; rd++) v[rd][c * NEQ] = 0.0;
+    }
+    chunk(std::integral_constant<int, NG>(), src, c * NEQ + G0);
+  }
+  visc_points<C, PH, true>(m, sFI, prm, e0, 0, v, sV, tab, TB, tid);
 }
 template <class C, class PH, int D>
 __device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
@@ -890,7 +954,9 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
 
   // ---- viscous normal-flux traces (T chunk in the sUp region: the nodal Up values are dead)
   if (!(TPSRHS_ABLATE & 16)) {
-    if constexpr (PH::HEAVY) {
+    if constexpr (DIM == 2) {
+      visc_phase_2d<C, PH>(m, sFI, prm, e0, sU, g, node_on, sJ, sUp, sV, tab, ct, TB, tid);
+    } else if constexpr (PH::HEAVY) {
 #pragma clang loop unroll(disable)
       for (int d = 0; d < DIM; d++) {
         double v[C::Q_ROUNDS][L::NVF];
