@@ -983,8 +983,14 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
 template <class C, class PH>
 struct FluxLds {
   static constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-  static constexpr int X = cmax(cmax(2 * NEQ * C::TN, NEQ * C::TQ), NEQ * C::TN);  // T | R (3-D) | L
-  static constexpr int Y = cmax(cmax(2 * NEQ * C::TW, NEQ * C::TW), (DIM == 2) ? NEQ * C::TQ : 0);
+  // One direction pair at a time: X = T | R (3-D) | L, Y = W | W2 (3-D) or R (2-D).  2-D with few equations:
+  // both direction pairs at once (Cfg::TQ2): X = (own | neighbour traces, later L) x 2, Y = R x 2.  (With the
+  // 11 equations of the six-species mixture the second set of prefetched traces costs more registers than
+  // the fuller rounds give back: measured 0.84 -> 1.04 ms.)
+  static constexpr bool BOTH_2D = (DIM == 2) && (NEQ <= 8);
+  static constexpr int X = BOTH_2D ? 4 * NEQ * C::TN : cmax(cmax(2 * NEQ * C::TN, NEQ * C::TQ), NEQ * C::TN);
+  static constexpr int Y = BOTH_2D ? 2 * NEQ * C::TQ
+                                   : cmax(cmax(2 * NEQ * C::TW, NEQ * C::TW), (DIM == 2) ? NEQ * C::TQ : 0);
   static constexpr int GF = cmax(NEQ * DIM * C::NODES, X + Y);  // sGf, then X and Y
   static constexpr int TOTAL = NEQ * C::NODES + GF;
 };
@@ -1065,6 +1071,121 @@ __device__ inline void face_flux_dir(const MeshDev &m, const typename PH::Params
   block_sync<C::BLOCK>();
 }
 
+// ---- 2-D: the face term of both direction pairs at once (full rounds of quadrature points, see Cfg::TQ2)
+template <class C, int NEQ>
+struct NbFlux2 {
+  double own[C::Q2_ROUNDS][NEQ], nbv[C::Q2_ROUNDS][NEQ];
+  int nb[C::Q2_ROUNDS];
+};
+template <class C, int NEQ>
+__device__ inline void issue_visc_traces_2d(const int2 *sFI, int e0, const double *__restrict__ TB, NbFlux2<C, NEQ> &t,
+                                            int tid) {
+#pragma unroll
+  for (int r = 0; r < C::Q2_ROUNDS; r++) {
+    int item = tid + r * C::BLOCK;
+    t.nb[r] = INT32_MIN;
+#pragma unroll
+    for (int k = 0; k < NEQ; k++) t.own[r][k] = t.nbv[r][k] = 0.0;
+    if (item < C::TQ2) {
+      const int d = item / C::TQ;
+      item -= d * C::TQ;
+      const int pf = item / C::NQ, q = item - pf * C::NQ;
+      const int lslot = (pf >> 1) * C::NFACES + 2 * d + (pf & 1);
+      const int2 fi = sFI[lslot];
+      t.nb[r] = fi.x;
+      if (fi.x != INT32_MIN && !(TPSRHS_ABLATE & 1)) {
+        const double *o = TB + (static_cast<int64_t>(e0) * C::NFACES + lslot) * ((NEQ - 1) * C::NQ) + q;
+#pragma unroll
+        for (int k = 1; k < NEQ; k++) t.own[r][k] = o[(k - 1) * C::NQ];
+        if (fi.x >= 0) {
+          const int pq = permute<2>(fi.y, C::Q1, q, 0);
+          const double *b2 = TB + static_cast<int64_t>(fi.x) * ((NEQ - 1) * C::NQ) + pq;
+#pragma unroll
+          for (int k = 1; k < NEQ; k++) t.nbv[r][k] = b2[(k - 1) * C::NQ];
+        }
+      }
+    }
+  }
+}
+template <class C, class PH>
+__device__ inline void face_flux_2d(const MeshDev &m, const typename PH::Params &prm, int e0, const double *sU, double *X,
+                                    double *Yb, const double *sV, const Tab<C> &tab, const Tables1D &ct,
+                                    const NbTraces<C, PH::NEQ> &ta0, const NbTraces<C, PH::NEQ> &ta1,
+                                    const NbFlux2<C, PH::NEQ> &tb, bool node_on, int le_n, const int *idx, double *z,
+                                    int tid) {
+  static_assert(C::DIM == 2, "2-D only");
+  constexpr int NEQ = PH::NEQ, DIM = 2;
+  constexpr int XS = 2 * NEQ * C::TN;  // own | neighbour traces of one direction pair
+  trace_lines<C, 0, NEQ>(sU, X, ct, tid);
+  trace_lines<C, 1, NEQ>(sU, X + XS, ct, tid);
+  block_sync<C::BLOCK>();
+  store_neighbour_traces<C, NEQ>(ta0, X, X + NEQ * C::TN, tid);
+  store_neighbour_traces<C, NEQ>(ta1, X + XS, X + XS + NEQ * C::TN, tid);
+  block_sync<C::BLOCK>();
+  double fh[C::Q2_ROUNDS][NEQ];
+#pragma unroll
+  for (int rd = 0; rd < C::Q2_ROUNDS; rd++) {
+    int item = tid + rd * C::BLOCK;
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] = 0.0;
+    const int nb = tb.nb[rd];
+    if (nb == INT32_MIN) continue;
+    const int d = item / C::TQ;
+    item -= d * C::TQ;
+    const int pf = item / C::NQ, q = item - pf * C::NQ;
+    const int le = pf >> 1, s = pf & 1;
+    const double *T = X + d * XS;
+    double bq[C::N1];
+#pragma unroll
+    for (int a = 0; a < C::N1; a++) bq[a] = tab.B[q * C::N1 + a];
+    double u1[NEQ], u2[NEQ];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) {
+      u1[eq] = interp2_point<C>(T + eq * C::TN, nullptr, bq, pf, q);
+      u2[eq] = interp2_point<C>(T + (NEQ + eq) * C::TN, nullptr, bq, pf, q);
+    }
+    PH::clamp_species(u1);
+    double n[DIM], wq, Xq[DIM];
+    face_geometry_rt<C>(d, &sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
+    if (nb >= 0) {
+      PH::clamp_species(u2);
+      PH::lax_friedrichs(prm, u1, u2, n, fh[rd]);
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] -= 0.5 * (tb.own[rd][eq] - tb.nbv[rd][eq]);
+    } else {
+      double ug[NEQ];
+      PH::bc_ghost(prm, prm.bc[-nb - 1], u1, n, ug);
+      PH::lax_friedrichs(prm, u1, ug, n, fh[rd]);
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] += tb.own[rd][eq];
+    }
+    if (PH::AXISYM) wq *= Xq[0];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] *= wq;
+  }
+  // R of direction pair d in Yb + d*NEQ*TQ (the traces are read, the region beyond them is free)
+#pragma unroll
+  for (int rd = 0; rd < C::Q2_ROUNDS; rd++) {
+    int item = tid + rd * C::BLOCK;
+    if (item < C::TQ2) {
+      const int d = item / C::TQ;
+      item -= d * C::TQ;
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) Yb[(d * NEQ + eq) * C::TQ + item] = fh[rd][eq];
+    }
+  }
+  block_sync<C::BLOCK>();  // R complete; every read of the traces in X is done
+  project2_lines<C, NEQ>(Yb, X, ct, tid);
+  project2_lines<C, NEQ>(Yb + NEQ * C::TQ, X + XS, ct, tid);
+  block_sync<C::BLOCK>();
+  if (node_on) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++)
+      z[eq] -= lift_pair<C, 0>(X + eq * C::TN, tab, le_n, idx) + lift_pair<C, 1>(X + XS + eq * C::TN, tab, le_n, idx);
+  }
+  block_sync<C::BLOCK>();
+}
+
 template <class C, class PH>
 __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
                                                    const double *__restrict__ gradUp, const double *__restrict__ TA,
@@ -1091,7 +1212,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
   NbTraces<C, NEQ> ta0;
   NbFlux<C, NEQ> tb0;
   issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta0, tid);
-  issue_visc_traces<C, 0, NEQ>(sFI, e0, TB, tb0, tid);
+  if (!L::BOTH_2D) issue_visc_traces<C, 0, NEQ>(sFI, e0, TB, tb0, tid);
   const bool node_on = tid < C::NODES && (e0 + tid / C::NPE) < m.ne;
   const int le_n = tid / C::NPE, nd = tid - le_n * C::NPE;
   int idx[3] = {nd % C::N1, (nd / C::N1) % C::N1, nd / (C::N1 * C::N1)};
@@ -1225,8 +1346,16 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
   }
   block_sync<C::BLOCK>();  // sGf dead: its region becomes X | Y
 
-  // ---- face term, one direction pair at a time
-  if (!(TPSRHS_ABLATE & 8)) {
+  // ---- face term
+  if constexpr (L::BOTH_2D) {
+    if (!(TPSRHS_ABLATE & 8)) {
+      NbTraces<C, NEQ> ta1;
+      NbFlux2<C, NEQ> tb;
+      issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta1, tid);
+      issue_visc_traces_2d<C, NEQ>(sFI, e0, TB, tb, tid);
+      face_flux_2d<C, PH>(m, prm, e0, sU, sX, sY, sV, tab, ct, ta0, ta1, tb, node_on, le_n, idx, z, tid);
+    }
+  } else if (!(TPSRHS_ABLATE & 8)) {  // one direction pair at a time
     // software pipeline over the direction pairs: the traces of pair d+1 are in flight while pair d runs
     NbTraces<C, NEQ> ta1, ta2;
     NbFlux<C, NEQ> tb1, tb2;
