@@ -292,6 +292,50 @@ int tpsrhs_kernel_bytes(tpsrhs_handle h, int capacity, const char **names, doubl
  * next dt (src/M2ulPhyS.cpp:2013-2016).  nan_count (may be NULL): number of NaN entries of the new x. */
 int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double *max_char_speed, int64_t *nan_count);
 
+/* ---- next row of the scope table: the other ForcingTerms of RHSoperator ----
+ * RHSoperator appends these to its `forcing` array (src/rhs_operator.cpp:101-166) and adds them to y
+ * after the inverse mass (src/rhs_operator.cpp:451-461).  SourceTerm and AxisymmetricSource follow from
+ * tpsrhs_physics / tpsrhs_disc; the ones below are configured here, after tpsrhs_create. */
+#define TPSRHS_MAXHEATSOURCES 4
+#define TPSRHS_MAXSPONGEZONES 2
+
+typedef struct tpsrhs_heat_source { /* heatSourceData, type "cylinder" (src/dataStructures.hpp:528-535) */
+  double value;                      /* added to y[(dim+1)*NDofs + node] (src/forcing_terms.cpp:923-936) */
+  double radius, point1[3], point2[3];
+} tpsrhs_heat_source;
+
+enum tpsrhs_sponge_type { TPSRHS_SPONGE_PLANAR = 0, TPSRHS_SPONGE_ANNULUS = 1 };  /* SpongeZoneType */
+
+typedef struct tpsrhs_sponge_zone { /* SpongeZoneData with szSolType USERDEF (src/dataStructures.hpp:260-287) */
+  int type;                          /* tpsrhs_sponge_type */
+  double normal[3], point0[3], point_init[3]; /* normal is normalised by the library (forcing_terms.cpp:528-532) */
+  double r1, r2;                     /* annulus radii */
+  double mult_factor;
+  /* SpongeZone::targetU, the CONSERVED target state the constructor derives from targetUp with the
+   * mixture's modifyEnergyForPressure (src/forcing_terms.cpp:486-517); the adapter copies it from there.
+   * Its speed of sound (forcing_terms.cpp:653-656) is evaluated by the library. */
+  double target_U[TPSRHS_MAXEQUATIONS];
+} tpsrhs_sponge_zone;
+
+typedef struct tpsrhs_forcing {
+  int has_pressure_gradient;         /* config.thereIsForcing(): ConstantPressureGradient, forcing_terms.cpp:115-171 */
+  double pressure_gradient[3];
+  int num_heat_sources;              /* enabled HeatSource entries only */
+  tpsrhs_heat_source heat_sources[TPSRHS_MAXHEATSOURCES];
+  int num_sponge_zones;              /* SpongeZone, USERDEF target (MIXEDOUT: TPSRHS_ERR_UNSUPPORTED) */
+  tpsrhs_sponge_zone sponge_zones[TPSRHS_MAXSPONGEZONES];
+} tpsrhs_forcing;
+
+/* Replaces the forcing.Append(...) calls of the RHSoperator constructor for ConstantPressureGradient,
+ * SpongeZone and HeatSource.  NULL removes them. */
+int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *forcing);
+
+/* JouleHeating (src/forcing_terms.cpp:443-471): `joule_heating` is the DEVICE array of the
+ * `joule_heating_` grid function (NDofs doubles, owned by the caller, read at every Mult; the EM solver
+ * refreshes it between steps).  Positive entries are added to the total-energy equation and, for a
+ * two-temperature mixture, to the electron-energy equation.  NULL disables the term. */
+int tpsrhs_set_joule_heating(tpsrhs_handle h, const double *joule_heating);
+
 /* Host-only view of the face topology tpsrhs_create derives from a mesh (the role of the
  * indirection arrays of src/M2ulPhyS.cpp:816-1486); touches no device.  Outputs (caller-allocated):
  *   face_nbr[ne*2*dim]   >= 0: trace slot (element*2*dim + local face) of the neighbour, slots

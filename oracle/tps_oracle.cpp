@@ -39,6 +39,13 @@ struct Operator {
   std::unique_ptr<RiemannSolver> rsolver;
   std::unique_ptr<SourceTerm> source;
   std::map<int, std::unique_ptr<BoundaryCondition>> bcs;
+  // ConstantPressureGradient / SpongeZone / HeatSource / JouleHeating (src/rhs_operator.cpp:101-166)
+  bool has_forcing = false;
+  tpsrhs_forcing forcing_in;
+  std::vector<std::vector<double>> spongeSigma;        // sigma grid function of each zone (:553-606)
+  std::vector<std::vector<double>> spongeRadial;       // unit radial vector per node (annulus)
+  std::vector<std::vector<int64_t>> heatNodes;         // nodeList_ of each HeatSource (:890-917)
+  std::vector<double> joule;                           // joule_heating_ grid function (empty: none)
 
   RuleND volRule;   // order 2p
   RuleND faceRule;  // order OrderW + 2p on the reference segment/square
@@ -448,8 +455,176 @@ struct Operator {
         }
     }
     // forcing terms (src/rhs_operator.cpp:451-461)
+    // order of the forcing array: ConstantPressureGradient, SpongeZone(s), HeatSource(s), SourceTerm,
+    // AxisymmetricSource, JouleHeating (src/rhs_operator.cpp:101-166)
+    if (has_forcing && forcing_in.has_pressure_gradient) constantPressureGradient(y);
+    if (has_forcing)
+      for (size_t zn = 0; zn < spongeSigma.size(); zn++) spongeZone(static_cast<int>(zn), y);
+    if (has_forcing)
+      for (size_t hs = 0; hs < heatNodes.size(); hs++)  // HeatSource::updateTerms, src/forcing_terms.cpp:923-936
+        for (int64_t node : heatNodes[hs]) y[node + (dim + 1) * N] += forcing_in.heat_sources[hs].value;
     if (source) source->updateTerms(x, Up.data(), gradUp.data(), ndofs, y);
     if (axisym) axisymmetricSource(x, y);
+    if (!joule.empty()) {  // JouleHeating::updateTerms, src/forcing_terms.cpp:443-471
+      if (nvel != 3) throw std::runtime_error("JouleHeating asserts nvel == 3");
+      const bool twoT = phys.working_fluid != TPSRHS_DRY_AIR && phys.mixture.two_temperature;
+      for (int64_t n = 0; n < N; n++) {
+        const double heating = joule[n];
+        if (heating > 0.) {
+          y[n + (nvel + 1) * N] += heating;
+          if (twoT) y[n + (neq - 1) * N] += heating;
+        }
+      }
+    }
+  }
+
+  // constructors of SpongeZone (src/forcing_terms.cpp:475-627, USERDEF target) and HeatSource (:873-921)
+  void setForcing(const tpsrhs_forcing *f) {
+    spongeSigma.clear();
+    spongeRadial.clear();
+    heatNodes.clear();
+    has_forcing = f != nullptr;
+    if (!f) return;
+    forcing_in = *f;
+    const int64_t N = ndofs;
+    for (int zn = 0; zn < f->num_sponge_zones; zn++) {
+      tpsrhs_sponge_zone &sz = forcing_in.sponge_zones[zn];
+      double mod = 0.;
+      for (int d = 0; d < dim; d++) mod += sz.normal[d] * sz.normal[d];
+      mod = std::sqrt(mod);
+      for (int d = 0; d < dim; d++) sz.normal[d] /= mod;
+      std::vector<double> sigma(N, 0.0), radial;
+      if (sz.type == TPSRHS_SPONGE_ANNULUS) radial.assign(static_cast<size_t>(N) * 3, 0.0);
+      for (int64_t n = 0; n < N; n++) {
+        double Xn[3] = {0, 0, 0};
+        for (int d = 0; d < dim; d++) Xn[d] = coords[n + d * N];
+        double distInit = 0.;
+        for (int d = 0; d < dim; d++) distInit -= sz.normal[d] * (Xn[d] - sz.point_init[d]);
+        double distF = 0.;
+        for (int d = 0; d < dim; d++) distF += sz.normal[d] * (Xn[d] - sz.point0[d]);
+        if (sz.type == TPSRHS_SPONGE_PLANAR) {
+          if (distInit > 0. && distF > 0.) {
+            const double planeDistance = distF + distInit;
+            sigma[n] = distInit / planeDistance / planeDistance;
+          }
+        } else {
+          double R = 0., tmp[3];
+          for (int d = 0; d < dim; d++) tmp[d] = Xn[d] - sz.point_init[d] + distInit * sz.normal[d];
+          for (int d = 0; d < dim; d++) R += tmp[d] * tmp[d];
+          R = std::sqrt(R);
+          if (distInit > 0. && distF > 0. && R - sz.r1 > 0.) {
+            const double planeDistance = sz.r2 - sz.r1;
+            sigma[n] = (R - sz.r1) / planeDistance / planeDistance;
+            for (int d = 0; d < dim; d++) radial[3 * n + d] = tmp[d] / R;
+          }
+        }
+      }
+      spongeSigma.push_back(sigma);
+      spongeRadial.push_back(radial);
+    }
+    for (int hs = 0; hs < f->num_heat_sources; hs++) {
+      const tpsrhs_heat_source &h = f->heat_sources[hs];
+      double norm[3] = {0, 0, 0}, mod = 0.;
+      for (int d = 0; d < dim; d++) norm[d] = h.point2[d] - h.point1[d];
+      for (int d = 0; d < dim; d++) mod += norm[d] * norm[d];
+      mod = std::sqrt(mod);
+      for (int d = 0; d < dim; d++) norm[d] /= mod;
+      std::vector<int64_t> nodes;
+      for (int64_t n = 0; n < N; n++) {
+        double X[3], proj = 0, normR = 0.;
+        for (int d = 0; d < dim; d++) X[d] = coords[n + d * N] - h.point1[d];
+        for (int d = 0; d < dim; d++) proj += X[d] * norm[d];
+        for (int d = 0; d < dim; d++) {
+          const double r = X[d] - proj * norm[d];
+          normR += r * r;
+        }
+        normR = std::sqrt(normR);
+        if (normR < h.radius && proj > 0 && proj < mod) nodes.push_back(n);
+      }
+      heatNodes.push_back(nodes);
+    }
+  }
+
+  // ConstantPressureGradient::updateTerms (CPU branch), src/forcing_terms.cpp:132-171
+  void constantPressureGradient(double *y) {
+    const int64_t N = ndofs;
+    const double *pressGrad = forcing_in.pressure_gradient;
+    for (int64_t index = 0; index < N; index++) {
+      double primi[MAXEQ];
+      for (int eq = 0; eq < neq; eq++) primi[eq] = Up[index + eq * N];
+      double p;
+      if (phys.working_fluid == TPSRHS_DRY_AIR)
+        p = mixture->GetGasConstant() * primi[0] * primi[nvel + 1];  // DryAir::ComputePressureFromPrimitives :361
+      else
+        p = static_cast<PerfectMixture *>(mixture.get())->ComputePressureFromPrimitives(primi);
+      double grad_pV = 0.;
+      for (int d = 0; d < dim; d++) {
+        const double vel = Up[index + (d + 1) * N];
+        y[index + (d + 1) * N] -= pressGrad[d];
+        grad_pV -= vel * pressGrad[d];
+        grad_pV -= p * gradUp[index + (d + 1) * N + d * N * neq];
+      }
+      y[index + (1 + nvel) * N] += grad_pV;
+    }
+  }
+
+  // SpongeZone::addSpongeZoneForcing, src/forcing_terms.cpp:637-711
+  void spongeZone(int zn, double *y) {
+    const int64_t N = ndofs;
+    const tpsrhs_sponge_zone &sz = forcing_in.sponge_zones[zn];
+    const double *targetU = sz.target_U;
+    double Upt[MAXEQ], targetCyl[MAXEQ];
+    for (int eq = 0; eq < neq; eq++) targetCyl[eq] = targetU[eq];
+    mixture->GetPrimitivesFromConservatives(targetU, Upt);
+    double speedSound;  // mixture->ComputeSpeedOfSound(Up, true)
+    if (phys.working_fluid == TPSRHS_DRY_AIR)
+      speedSound = std::sqrt(mixture->GetSpecificHeatRatio() * mixture->GetGasConstant() * Upt[nvel + 1]);  // :337-348
+    else  // the primitive branch (:1406-1419) rebuilds exactly the quantities of the conserved one
+      speedSound = static_cast<PerfectMixture *>(mixture.get())->ComputeSpeedOfSound(targetU);
+    for (int64_t n = 0; n < N; n++) {
+      double s = spongeSigma[zn][n];
+      if (s > 0.) {
+        s *= sz.mult_factor;
+        double Upn[MAXEQ], Un[MAXEQ];
+        for (int eq = 0; eq < neq; eq++) Upn[eq] = Up[n + eq * N];
+        mixture->GetConservativesFromPrimitives(Upn, Un);
+        if (sz.type == TPSRHS_SPONGE_ANNULUS) {  // :686-705; the block at :667-683 is overwritten by this one
+          double ur[3], uz[3], uth[3], MM[9], inv[9];
+          for (int d = 0; d < 3; d++) {
+            ur[d] = spongeRadial[zn][3 * n + d];
+            uz[d] = sz.normal[d];
+          }
+          uth[0] = uz[1] * ur[2] - ur[1] * uz[2];
+          uth[1] = uz[2] * ur[0] - uz[0] * ur[2];
+          uth[2] = uz[0] * ur[1] - ur[0] * uz[1];
+          for (int d = 0; d < 3; d++) {  // MM(i, d), column-major as DenseMatrix
+            MM[0 + 3 * d] = ur[d];
+            MM[1 + 3 * d] = uth[d];
+            MM[2 + 3 * d] = uz[d];
+          }
+          invert3(MM, inv);
+          for (int i = 0; i < 3; i++) {
+            double v = 0.0;
+            for (int j = 0; j < 3; j++) v += inv[i + 3 * j] * targetU[1 + j];
+            targetCyl[1 + i] = v;
+          }
+        }
+        for (int eq = 0; eq < neq; eq++) y[n + eq * N] -= speedSound * s * (Un[eq] - targetCyl[eq]);
+      }
+    }
+  }
+  static void invert3(const double *A, double *B) {  // column-major 3x3 inverse (DenseMatrix::Invert)
+    const double c00 = A[4] * A[8] - A[7] * A[5], c10 = A[7] * A[2] - A[1] * A[8], c20 = A[1] * A[5] - A[4] * A[2];
+    const double det = A[0] * c00 + A[3] * c10 + A[6] * c20;
+    B[0] = c00 / det;
+    B[1] = c10 / det;
+    B[2] = c20 / det;
+    B[3] = (A[6] * A[5] - A[3] * A[8]) / det;
+    B[4] = (A[0] * A[8] - A[6] * A[2]) / det;
+    B[5] = (A[3] * A[2] - A[0] * A[5]) / det;
+    B[6] = (A[3] * A[7] - A[6] * A[4]) / det;
+    B[7] = (A[6] * A[1] - A[0] * A[7]) / det;
+    B[8] = (A[0] * A[4] - A[3] * A[1]) / det;
   }
 
   // AxisymmetricSource::updateTerms, src/forcing_terms.cpp:255-382 (CPU branch)
@@ -521,6 +696,23 @@ int tpsoracle_create(const tpsrhs_mesh *mesh, const tpsrhs_disc *disc, const tps
 }
 int tpsoracle_destroy(void *h) {
   delete static_cast<Operator *>(h);
+  return 0;
+}
+int tpsoracle_set_forcing(void *h, const tpsrhs_forcing *f) {
+  try {
+    static_cast<Operator *>(h)->setForcing(f);
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+int tpsoracle_set_joule_heating(void *h, const double *jh) {  // HOST array, copied; NULL disables
+  Operator *op = static_cast<Operator *>(h);
+  if (jh)
+    op->joule.assign(jh, jh + op->ndofs);
+  else
+    op->joule.clear();
   return 0;
 }
 int64_t tpsoracle_num_dofs(void *h) { return static_cast<Operator *>(h)->ndofs; }

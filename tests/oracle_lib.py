@@ -39,6 +39,8 @@ def lib():
         L.tpsoracle_get_primitives.argtypes = [vp, _dp]
         L.tpsoracle_get_gradients.argtypes = [vp, _dp]
         L.tpsoracle_node_coords.argtypes = [vp, _dp]
+        L.tpsoracle_set_forcing.argtypes = [vp, C.POINTER(capi.Forcing)]
+        L.tpsoracle_set_joule_heating.argtypes = [vp, _dp]
         L.tpsoracle_l2_norm.restype = C.c_double
         L.tpsoracle_l2_norm.argtypes = [vp, _dp, _dp]
         L.tpsoracle_integral.restype = C.c_double
@@ -96,6 +98,19 @@ class Oracle:
         out = np.zeros((self.dim, self.ndofs))
         lib().tpsoracle_node_coords(self.h, _p(out))
         return out
+
+    def set_forcing(self, forcing):
+        st = lib().tpsoracle_set_forcing(self.h, C.byref(forcing) if forcing is not None else None)
+        if st != 0:
+            raise RuntimeError("oracle: " + lib().tpsoracle_last_error().decode())
+
+    def set_joule_heating(self, jh):
+        if jh is None:
+            lib().tpsoracle_set_joule_heating(self.h, None)
+        else:
+            jh = np.ascontiguousarray(jh, dtype=np.float64)
+            assert jh.size == self.ndofs
+            lib().tpsoracle_set_joule_heating(self.h, _p(jh))
 
     def mult(self, x, time=0.0):
         x = np.ascontiguousarray(x, dtype=np.float64)

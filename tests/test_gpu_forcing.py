@@ -1,0 +1,133 @@
+"""The optional forcing terms (ConstantPressureGradient, SpongeZone, HeatSource, JouleHeating;
+``src/forcing_terms.cpp``) of the HIP path vs the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from parity_util import RHS_RTOL, rel_maxnorm
+from tps_amd import capi, cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(case, U, forcing, joule, tol):
+    import torch
+    from oracle_lib import Oracle
+    from tps_amd.rhs_operator import RHSoperator
+
+    o = Oracle(case.mesh, case.disc, case.physics, case.bcs)
+    y_plain = o.mult(U)
+    o.set_forcing(forcing)
+    o.set_joule_heating(joule)
+    y_ref = o.mult(U)
+
+    op = RHSoperator(case.mesh, case.disc, case.physics, case.bcs)
+    x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
+    y = torch.empty_like(x)
+    op.setForcing(forcing)
+    jh = None if joule is None else torch.tensor(joule, dtype=torch.float64, device=op.device)
+    op.setJouleHeating(jh)
+    op.Mult(x, y)
+    got = y.cpu().numpy().reshape(U.shape)
+    # ... and switching everything off again gives the plain residual back
+    op.setForcing(None)
+    op.setJouleHeating(None)
+    op.Mult(x, y)
+    got_plain = y.cpu().numpy().reshape(U.shape)
+    op.close()
+
+    changed = np.abs(y_ref - y_plain).max(axis=1)
+    err = rel_maxnorm(got, y_ref)
+    print("forcing contribution (max per equation)", changed, "rel err", err)
+    assert err.max() < tol
+    assert rel_maxnorm(got_plain, y_plain).max() < tol
+    # the forcing is compared on its own too: (y_forced - y_plain) of both sides
+    d_ref, d_got = y_ref - y_plain, got - got_plain
+    scale = np.abs(y_ref).max(axis=1, keepdims=True)
+    assert (np.abs(d_got - d_ref) / scale).max() < tol
+    return changed, o
+
+
+def _dry_air_target(rho, vel, p, gamma=1.4):
+    """SpongeZone constructor for dry air: modifyEnergyForPressure (src/forcing_terms.cpp:486-517)."""
+    return [rho] + [rho * v for v in vel] + [p / (gamma - 1.0) + 0.5 * rho * sum(v * v for v in vel)]
+
+
+def test_dry_air_cylinder_all_terms():
+    c = cases.cyl3d(5, 12, 4, 3, capi.NS, capi.VISC_ISOTH)
+    c.physics.dry_air.visc_mult = 2000.0
+    U = c.state(seed=21)
+    forcing = capi.make_forcing(
+        pressure_gradient=(3.0, -1.5, 0.7),
+        # wake heater as in test/inputs/input.dtconst.cyl.heatSource.ini (a cylinder along z behind the body)
+        heat_sources=[dict(value=7.5e4, radius=1.3, point1=(2.0, 0.1, -0.1), point2=(2.1, 0.0, 2.3)),
+                      dict(value=-2.0e4, radius=0.8, point1=(-3.0, 1.0, 0.4), point2=(-1.0, 2.0, 1.1))],
+        # the normal of a zone points from its end plane (p0) back to its start plane (pInit)
+        sponge_zones=[dict(type=capi.SPONGE_PLANAR, normal=(-2.0, -0.2, 0.0), point0=(9.7, 0.0, 0.0),
+                           point_init=(5.2, 0.0, 0.0), mult_factor=0.6,
+                           target_U=_dry_air_target(1.15, (18.0, 1.0, -0.5), 100900.0)),
+                      dict(type=capi.SPONGE_ANNULUS, normal=(0.0, 0.0, -1.0), point0=(0.0, 0.0, 1.9),
+                           point_init=(0.0, 0.0, 0.05), r1=6.1, r2=10.0, mult_factor=1.3,
+                           target_U=_dry_air_target(1.22, (0.4, 2.0, 15.0), 101500.0))])
+    rng = np.random.default_rng(5)
+    joule = rng.uniform(-2.0e4, 6.0e4, U.shape[1])  # negative entries are ignored by the term
+    changed, o = _run(c, U, forcing, joule, RHS_RTOL)
+    assert np.all(changed > 0.0)  # every equation is touched by some term
+    # both heaters and both zones select a non-trivial part of the mesh
+    X = o.node_coords()
+    assert 0 < np.count_nonzero(np.hypot(X[0] - 2.05, X[1] - 0.05) < 1.0) < X.shape[1]
+
+
+def test_dry_air_periodic_box_pressure_gradient_only():
+    from tps_amd import meshgen
+    from tps_amd.rhs_operator import node_coordinates
+
+    mesh = meshgen.scramble_orientations(meshgen.box_hex(4, 3, 3, lengths=(1.0, 0.8, 1.2), warp=0.1), 4)
+    c = cases.Case("box", mesh, capi.Disc(2, 0, 0, 0, 0), capi.dry_air_physics(capi.NS, visc_mult=300.0), [], None)
+    U = cases.dry_air_state(node_coordinates(mesh, 2), seed=8)
+    _run(c, U, capi.make_forcing(pressure_gradient=(0.0, 12.0, -4.0)), None, RHS_RTOL)
+
+
+@pytest.mark.parametrize("two_t", [False, True])
+def test_plasma_cylinder_sponge_heat_joule(two_t):
+    c = cases.argon_cyl3d(4, 12, 3, 2, two_t, capi.ARGON_MINIMAL, "arrhenius", capi.VISC_ISOTH)
+    amp = 0.01
+    U = c.state(seed=3, amp=amp)
+    forcing = capi.make_forcing(
+        heat_sources=[dict(value=3.0e5, radius=2.0, point1=(2.0, 0.0, -0.1), point2=(2.0, 0.0, 2.2))],
+        sponge_zones=[dict(type=capi.SPONGE_PLANAR, normal=(-1.0, 0.0, 0.0), point0=(9.5, 0.0, 0.0),
+                           point_init=(4.0, 0.0, 0.0), mult_factor=0.8, target_U=list(U[:, 17]))])
+    joule = np.random.default_rng(9).uniform(-1.0e5, 4.0e5, U.shape[1])
+    changed, _ = _run(c, U, forcing, joule, max(RHS_RTOL, 1.5e-13 / amp))
+    assert changed[4] > 0.0 and (not two_t or changed[-1] > 0.0)
+
+
+def test_dry_air_axisymmetric_sponge_heat_joule():
+    c = cases.dry_air_axisym(6, 9, 3, capi.NS, capi.VISC_ISOTH, r_in=0.0)
+    c.physics.dry_air.visc_mult = 200.0
+    U = c.state(seed=12)
+    forcing = capi.make_forcing(
+        pressure_gradient=(0.0, 40.0, 0.0),
+        # the reference adds the heat to equation dim+1 = 3 here (rho u_theta), not to the energy
+        heat_sources=[dict(value=1.0e3, radius=0.02, point1=(0.0, 0.05), point2=(0.0, 0.2))],
+        sponge_zones=[dict(type=capi.SPONGE_PLANAR, normal=(0.0, -1.0, 0.0), point0=(0.0, 0.249),
+                           point_init=(0.0, 0.18), target_U=_dry_air_target(1.19, (0.3, 19.0, 0.8), 101200.0))])
+    joule = np.random.default_rng(2).uniform(0.0, 5.0e4, U.shape[1])
+    changed, _ = _run(c, U, forcing, joule, RHS_RTOL)
+    assert changed[3] > 0.0 and changed[4] > 0.0
+
+
+def test_forcing_argument_checks():
+    from tps_amd.rhs_operator import RHSoperator, TpsRhsError
+
+    c = cases.dry_air_axisym(4, 4, 2, capi.NS, capi.VISC_ISOTH)
+    op = RHSoperator(c.mesh, c.disc, c.physics, c.bcs)
+    bad = capi.make_forcing(sponge_zones=[dict(type=capi.SPONGE_ANNULUS, normal=(0, 1, 0), point0=(0, 1), point_init=(0, 0),
+                                              r1=0.1, r2=0.2, target_U=_dry_air_target(1.2, (0, 1, 0), 1e5))])
+    with pytest.raises(TpsRhsError) as e:
+        op.setForcing(bad)
+    assert "UNSUPPORTED" in str(e.value)
+    f = capi.make_forcing()
+    f.num_heat_sources = 9
+    with pytest.raises(TpsRhsError):
+        op.setForcing(f)
+    op.close()

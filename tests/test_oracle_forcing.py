@@ -1,0 +1,92 @@
+"""Known answers for the oracle's restatement of the optional forcing terms (src/forcing_terms.cpp):
+closed forms evaluated with numpy on the node coordinates."""
+import numpy as np
+
+from oracle_lib import Oracle
+from tps_amd import capi, cases, meshgen
+from tps_amd.rhs_operator import node_coordinates
+
+GAMMA = 1.4
+
+
+def _box(order=2):
+    mesh = meshgen.box_hex(3, 3, 3, lengths=(1.0, 0.8, 1.2), warp=0.1)
+    ph = capi.dry_air_physics(capi.NS, visc_mult=100.0)
+    o = Oracle(mesh, capi.Disc(order, 0, 0, 0, 0), ph, [])
+    return mesh, o, node_coordinates(mesh, order)
+
+
+def test_pressure_gradient_on_uniform_flow():
+    # ConstantPressureGradient::updateTerms (forcing_terms.cpp:150-170): momentum -= pg, energy -= u.pg + p div u
+    mesh, o, X = _box()
+    rho, vel, p = 1.2, (20.0, -3.0, 5.0), 101300.0
+    U = np.zeros((5, X.shape[1]))
+    U[0] = rho
+    for d in range(3):
+        U[1 + d] = rho * vel[d]
+    U[4] = p / (GAMMA - 1) + 0.5 * rho * sum(v * v for v in vel)
+    y0 = o.mult(U)
+    assert np.abs(y0).max() < 1e-6  # free-stream preservation
+    pg = (3.0, -1.0, 0.5)
+    o.set_forcing(capi.make_forcing(pressure_gradient=pg))
+    y = o.mult(U) - y0
+    assert np.abs(y[0]).max() == 0.0
+    for d in range(3):
+        np.testing.assert_allclose(y[1 + d], -pg[d], rtol=1e-12)
+    np.testing.assert_allclose(y[4], -sum(v * g for v, g in zip(vel, pg)), rtol=1e-9)
+
+
+def test_heat_source_node_list_and_value():
+    # HeatSource constructor (forcing_terms.cpp:890-917) and updateTerms (:923-936)
+    mesh, o, X = _box()
+    U = cases.dry_air_state(X, seed=1)
+    y0 = o.mult(U)
+    p1, p2, radius, value = np.array([0.1, 0.2, 0.3]), np.array([0.9, 0.5, 0.8]), 0.25, 4.0e3
+    o.set_forcing(capi.make_forcing(heat_sources=[dict(value=value, radius=radius, point1=p1, point2=p2)]))
+    d = o.mult(U) - y0
+    axis = (p2 - p1) / np.linalg.norm(p2 - p1)
+    rel = X - p1[:, None]
+    proj = axis @ rel
+    r = np.linalg.norm(rel - np.outer(axis, proj), axis=0)
+    inside = (r < radius) & (proj > 0) & (proj < np.linalg.norm(p2 - p1))
+    assert 0 < inside.sum() < X.shape[1]
+    np.testing.assert_allclose(d[4], np.where(inside, value, 0.0), atol=1e-9 * value)
+    assert np.abs(d[:4]).max() == 0.0
+
+
+def test_planar_sponge_profile():
+    # sigma = d_init / (d_init + d_f)^2 between the planes (forcing_terms.cpp:553-572), forcing
+    # -c* sigma mult (U - U*) with c* the speed of sound of the target (:637-711)
+    mesh, o, X = _box()
+    U = cases.dry_air_state(X, seed=2)
+    y0 = o.mult(U)
+    n = np.array([-2.0, 0.0, -1.0])  # points from the end plane (p0) to the start plane (pInit)
+    p_init, p_end, mult = np.array([0.45, 0.0, 0.1]), np.array([1.3, 0.0, 0.9]), 0.7
+    rho_t, vel_t, p_t = 1.1, (15.0, 2.0, 1.0), 99000.0
+    tgt = np.array([rho_t] + [rho_t * v for v in vel_t] + [p_t / (GAMMA - 1) + 0.5 * rho_t * sum(v * v for v in vel_t)])
+    o.set_forcing(capi.make_forcing(sponge_zones=[dict(type=capi.SPONGE_PLANAR, normal=n, point0=p_end, point_init=p_init,
+                                                       mult_factor=mult, target_U=tgt)]))
+    d = o.mult(U) - y0
+    nu = n / np.linalg.norm(n)
+    d_init = -(nu @ (X - p_init[:, None]))
+    d_f = nu @ (X - p_end[:, None])
+    sigma = np.where((d_init > 0) & (d_f > 0), d_init / (d_init + d_f) ** 2, 0.0)
+    assert 0 < np.count_nonzero(sigma) < X.shape[1]
+    cs = np.sqrt(GAMMA * p_t / rho_t)
+    expect = -cs * sigma * mult * (U - tgt[:, None])
+    scale = np.abs(expect).max(axis=1, keepdims=True)
+    assert (np.abs(d - expect) / scale).max() < 1e-10
+
+
+def test_joule_heating_only_positive_entries():
+    # JouleHeating::updateTerms (forcing_terms.cpp:443-471)
+    mesh, o, X = _box()
+    U = cases.dry_air_state(X, seed=3)
+    y0 = o.mult(U)
+    jh = np.random.default_rng(0).uniform(-1.0, 1.0, X.shape[1]) * 1e4
+    o.set_joule_heating(jh)
+    d = o.mult(U) - y0
+    np.testing.assert_allclose(d[4], np.maximum(jh, 0.0), atol=1e-6)
+    assert np.abs(d[:4]).max() == 0.0
+    o.set_joule_heating(None)
+    assert np.abs(o.mult(U) - y0).max() == 0.0

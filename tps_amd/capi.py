@@ -116,6 +116,56 @@ class Runtime(C.Structure):
     _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("halo", HALO_FN), ("halo_ctx", C.c_void_p)]
 
 
+MAXHEATSOURCES, MAXSPONGEZONES = 4, 2
+SPONGE_PLANAR, SPONGE_ANNULUS = 0, 1
+
+
+class HeatSource(C.Structure):  # heatSourceData (src/dataStructures.hpp:528-535)
+    _fields_ = [("value", C.c_double), ("radius", C.c_double), ("point1", C.c_double * 3), ("point2", C.c_double * 3)]
+
+
+class SpongeZone(C.Structure):  # SpongeZoneData, USERDEF target (src/dataStructures.hpp:260-287)
+    _fields_ = [("type", C.c_int), ("normal", C.c_double * 3), ("point0", C.c_double * 3),
+                ("point_init", C.c_double * 3), ("r1", C.c_double), ("r2", C.c_double), ("mult_factor", C.c_double),
+                ("target_U", C.c_double * MAXEQUATIONS)]
+
+
+class Forcing(C.Structure):
+    _fields_ = [("has_pressure_gradient", C.c_int), ("pressure_gradient", C.c_double * 3),
+                ("num_heat_sources", C.c_int), ("heat_sources", HeatSource * MAXHEATSOURCES),
+                ("num_sponge_zones", C.c_int), ("sponge_zones", SpongeZone * MAXSPONGEZONES)]
+
+
+def make_forcing(pressure_gradient=None, heat_sources=(), sponge_zones=()) -> Forcing:
+    """heat_sources: dicts(value, radius, point1, point2); sponge_zones: dicts(type, normal, point0, point_init,
+    target_U[, r1, r2, mult_factor]) -- the [heatSource*] / [spongezone*] input sections
+    (src/M2ulPhyS.cpp:2752-2785, 3680-3755) with the target already in conserved variables."""
+    f = Forcing()
+    if pressure_gradient is not None:
+        f.has_pressure_gradient = 1
+        for d, v in enumerate(pressure_gradient):
+            f.pressure_gradient[d] = float(v)
+    f.num_heat_sources = len(heat_sources)
+    for i, h in enumerate(heat_sources):
+        f.heat_sources[i].value = float(h["value"])
+        f.heat_sources[i].radius = float(h["radius"])
+        for d in range(3):
+            f.heat_sources[i].point1[d] = float(h["point1"][d]) if d < len(h["point1"]) else 0.0
+            f.heat_sources[i].point2[d] = float(h["point2"][d]) if d < len(h["point2"]) else 0.0
+    f.num_sponge_zones = len(sponge_zones)
+    for i, z in enumerate(sponge_zones):
+        sz = f.sponge_zones[i]
+        sz.type = int(z.get("type", SPONGE_PLANAR))
+        for name, key in (("normal", "normal"), ("point0", "point0"), ("point_init", "point_init")):
+            for d in range(3):
+                getattr(sz, name)[d] = float(z[key][d]) if d < len(z[key]) else 0.0
+        sz.r1, sz.r2 = float(z.get("r1", 0.0)), float(z.get("r2", 0.0))
+        sz.mult_factor = float(z.get("mult_factor", 1.0))
+        for eq, v in enumerate(z["target_U"]):
+            sz.target_U[eq] = float(v)
+    return f
+
+
 # ------------------------------------------------------------------------------------------
 def dry_air_physics(eq_system=NS, visc_mult=1.0, bulk_visc_mult=0.0, gamma=1.4, gas_constant=287.058) -> Physics:
     """[flow] fluid = dry_air with the reference's defaults (src/M2ulPhyS.cpp:2716-2718,2882-2883)."""
@@ -376,6 +426,8 @@ def load():
     lib.tpsrhs_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_kernel_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_rk4_step.argtypes = [vp, C.c_void_p, _dp, C.c_double, _dp, C.POINTER(C.c_int64)]
+    lib.tpsrhs_set_forcing.argtypes = [vp, C.POINTER(Forcing)]
+    lib.tpsrhs_set_joule_heating.argtypes = [vp, C.c_void_p]
     lib.tpsrhs_face_tables.restype = C.c_int
     lib.tpsrhs_face_tables.argtypes = [C.POINTER(Mesh), C.c_int, C.POINTER(BC), vp, vp, vp, vp]
     lib.tpsrhs_status_string.restype = C.c_char_p
@@ -390,7 +442,7 @@ EXPORTED_SYMBOLS = [
     "tpsrhs_create", "tpsrhs_destroy", "tpsrhs_mult", "tpsrhs_mult_host", "tpsrhs_update_gradients",
     "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
     "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_kernel_bytes", "tpsrhs_face_tables",
-    "tpsrhs_rk4_step", "tpsrhs_status_string",
+    "tpsrhs_rk4_step", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_status_string",
     "tpsrhs_last_error", "tpsrhs_version",
 ]
 

@@ -107,6 +107,25 @@ struct Tab {
   double xq[C::Q1], wq[C::Q1], B[C::Q1 * C::N1];
 };
 
+// ConstantPressureGradient / HeatSource / SpongeZone / JouleHeating of RHSoperator's forcing array
+// (src/rhs_operator.cpp:101-166), evaluated per node in k_flux next to the point sources.  One block in
+// device memory; the address is wave-uniform, so its fields arrive through scalar loads.
+struct ForcingDev {
+  int has_pg, nheat, nsponge, pad;
+  double pg[3];
+  struct Heat {
+    double value, radius, len;  // len = |point2 - point1|
+    double p1[3], axis[3];      // axis = unit vector point1 -> point2
+  } heat[TPSRHS_MAXHEATSOURCES];
+  struct Sponge {
+    int type, pad;
+    double normal[3], p0[3], pinit[3];
+    double r1, r2, mult;
+    double target[TPSRHS_MAXEQUATIONS];
+  } sponge[TPSRHS_MAXSPONGEZONES];
+  const double *joule;  // [ndofs] or NULL
+};
+
 struct MeshDev {
   const int *blocks;           // workgroup -> block of EPB consecutive elements (NULL: identity); lets one
                                // launch cover the interior and another the blocks that touch shared faces
@@ -180,15 +199,27 @@ __device__ inline void jacobian(const double *V, const double *xi, double *J) {
     }
   }
 }
-// physical coordinates of reference point xi (2-D; used for the radius of the axisymmetric formulation)
+// physical coordinates of reference point xi (radius of the axisymmetric formulation; node positions of
+// the optional forcing terms)
 template <int DIM>
 __device__ inline void position(const double *V, const double *xi, double *X) {
-  static_assert(DIM == 2, "only the axisymmetric (2-D) path needs nodal coordinates");
   const double x = xi[0], y = xi[1];
+  if constexpr (DIM == 2) {
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const double v00 = V[0 * 2 + i], v10 = V[1 * 2 + i], v01 = V[2 * 2 + i], v11 = V[3 * 2 + i];
-    X[i] = (v00 * (1.0 - x) + v10 * x) * (1.0 - y) + (v01 * (1.0 - x) + v11 * x) * y;
+    for (int i = 0; i < 2; i++) {
+      const double v00 = V[0 * 2 + i], v10 = V[1 * 2 + i], v01 = V[2 * 2 + i], v11 = V[3 * 2 + i];
+      X[i] = (v00 * (1.0 - x) + v10 * x) * (1.0 - y) + (v01 * (1.0 - x) + v11 * x) * y;
+    }
+  } else {
+    const double z = xi[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double v000 = V[0 * 3 + i], v100 = V[1 * 3 + i], v010 = V[2 * 3 + i], v110 = V[3 * 3 + i];
+      const double v001 = V[4 * 3 + i], v101 = V[5 * 3 + i], v011 = V[6 * 3 + i], v111 = V[7 * 3 + i];
+      const double lo = (v000 * (1.0 - x) + v100 * x) * (1.0 - y) + (v010 * (1.0 - x) + v110 * x) * y;
+      const double hi = (v001 * (1.0 - x) + v101 * x) * (1.0 - y) + (v011 * (1.0 - x) + v111 * x) * y;
+      X[i] = lo * (1.0 - z) + hi * z;
+    }
   }
 }
 // adjugate A[m + i*DIM] = det(J) * dxi_m/dx_i and determinant
@@ -980,6 +1011,144 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
 // =============================================================================================
 // sweep 2: y = M^-1 [ (grad phi, F_c - F_v)  -  <phi, F^ . n> ]  (+ point sources)
 // =============================================================================================
+// The optional forcing terms at one node (added to y after the inverse mass, src/rhs_operator.cpp:451-461).
+//   X: node position; u, st: conserved state and its closure; gr: gradUp[eq + d*NEQ]
+template <class C, class PH>
+__device__ inline void apply_forcing(const ForcingDev &f, const typename PH::Params &prm, int64_t node, const double *X,
+                                     const double *u, const typename PH::State &st, const double *gr, double *src) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM, NVEL = PH::NVEL;
+  // ConstantPressureGradient::updateTerms, src/forcing_terms.cpp:150-170 (dim, not nvel: no pressure
+  // gradient in the theta direction)
+  if (f.has_pg) {
+    double gpv = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      src[1 + d] -= f.pg[d];
+      gpv -= st.vel[d] * f.pg[d];
+      gpv -= st.p * gr[(1 + d) + d * NEQ];
+    }
+    src[1 + NVEL] += gpv;
+  }
+  // SpongeZone::addSpongeZoneForcing, src/forcing_terms.cpp:637-711; sigma of the constructor, :553-606
+  for (int z = 0; z < f.nsponge; z++) {
+    const ForcingDev::Sponge &sz = f.sponge[z];
+    double dist_init = 0.0, dist_f = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      dist_init -= sz.normal[d] * (X[d] - sz.pinit[d]);
+      dist_f += sz.normal[d] * (X[d] - sz.p0[d]);
+    }
+    double sigma = 0.0;
+    double tgt[NEQ];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) tgt[eq] = sz.target[eq];
+    if (sz.type == TPSRHS_SPONGE_PLANAR) {
+      if (dist_init > 0.0 && dist_f > 0.0) {
+        const double len = dist_f + dist_init;
+        sigma = dist_init / len / len;
+      }
+    } else if constexpr (DIM == 3) {  // annulus: radial distance to the axis through pinit along normal
+      double t[3], R = 0.0;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        t[d] = X[d] - sz.pinit[d] + dist_init * sz.normal[d];
+        R += t[d] * t[d];
+      }
+      R = sqrt(R);
+      if (dist_init > 0.0 && dist_f > 0.0 && R - sz.r1 > 0.0) {
+        const double len = sz.r2 - sz.r1;
+        sigma = (R - sz.r1) / len / len;
+        // target momentum given as (radial, azimuthal, axial): rows of MM are ur, uth = uz x ur, uz;
+        // targetCyl(1..3) = MM^-1 targetU(1..3)  (:686-705)
+        double ur[3], uz[3], ut[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          ur[d] = t[d] / R;
+          uz[d] = sz.normal[d];
+        }
+        ut[0] = uz[1] * ur[2] - ur[1] * uz[2];
+        ut[1] = uz[2] * ur[0] - uz[0] * ur[2];
+        ut[2] = uz[0] * ur[1] - ur[0] * uz[1];
+        const double M[9] = {ur[0], ur[1], ur[2], ut[0], ut[1], ut[2], uz[0], uz[1], uz[2]};  // row-major
+        const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+        const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+        const double inv[9] = {c00, M[2] * M[7] - M[1] * M[8], M[1] * M[5] - M[2] * M[4],
+                               c01, M[0] * M[8] - M[2] * M[6], M[2] * M[3] - M[0] * M[5],
+                               c02, M[1] * M[6] - M[0] * M[7], M[0] * M[4] - M[1] * M[3]};
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+          tgt[1 + i] = (inv[3 * i] * sz.target[1] + inv[3 * i + 1] * sz.target[2] + inv[3 * i + 2] * sz.target[3]) / det;
+      }
+    }
+    if (sigma > 0.0) {
+      const double cs = PH::sound_speed(prm, sz.target);
+      const double s = sigma * sz.mult;
+      // Un = GetConservativesFromPrimitives(Up) of the reference is the node's conserved state again
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) src[eq] -= cs * s * (u[eq] - tgt[eq]);
+    }
+  }
+  // HeatSource (type "cylinder"): node list of the constructor :890-917, updateTerms :923-936.
+  // The reference indexes equation dim+1 (not nvel+1).
+  for (int h = 0; h < f.nheat; h++) {
+    const ForcingDev::Heat &hs = f.heat[h];
+    double proj = 0.0, Xr[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      Xr[d] = X[d] - hs.p1[d];
+      proj += Xr[d] * hs.axis[d];
+    }
+    double r2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      const double r = Xr[d] - proj * hs.axis[d];
+      r2 += r * r;
+    }
+    if (sqrt(r2) < hs.radius && proj > 0.0 && proj < hs.len) src[DIM + 1] += hs.value;
+  }
+  // JouleHeating::updateTerms, src/forcing_terms.cpp:443-471
+  if (f.joule) {
+    const double heating = f.joule[node];
+    if (heating > 0.0) {
+      src[NVEL + 1] += heating;
+      if (PH::TWO_TEMPERATURE) src[NEQ - 1] += heating;
+    }
+  }
+}
+
+// y += optional forcing terms: a streaming pass of its own (one lane per node), launched after k_flux
+// only when such a term is configured -- the hot sweeps carry neither its registers nor a branch.
+template <class C, class PH>
+__global__ __launch_bounds__(256) void k_forcing(MeshDev m, typename PH::Params prm, const ForcingDev *__restrict__ fd,
+                                                 const double *__restrict__ U, const double *__restrict__ gradUp,
+                                                 double *__restrict__ Y) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  const Tables1D &ct = c_tab[DIM - 2][C::P];
+  const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (n >= m.ndofs) return;
+  const int e = static_cast<int>(n / C::NPE), nd = static_cast<int>(n - static_cast<int64_t>(e) * C::NPE);
+  const int idx[3] = {nd % C::N1, (nd / C::N1) % C::N1, nd / (C::N1 * C::N1)};
+  double xi[DIM], X[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; d++) xi[d] = ct.x[idx[d]];
+  position<DIM>(m.verts + static_cast<int64_t>(e) * C::NV * DIM, xi, X);
+  double u[NEQ], gr[NEQ * DIM], src[NEQ];
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) {
+    u[eq] = field_ptr(U, eq, m.ndofs)[n];
+    src[eq] = 0.0;
+  }
+  if (fd->has_pg) {  // the only term that reads the gradient: div u
+#pragma unroll
+    for (int d = 0; d < DIM; d++) gr[(1 + d) + d * NEQ] = field_ptr(gradUp, (1 + d) + d * NEQ, m.ndofs)[n];
+  }
+  const typename PH::State st = PH::make_state(prm, u);  // the reference reads Up of the unclamped state
+  apply_forcing<C, PH>(*fd, prm, n, X, u, st, gr, src);
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++)
+    if (src[eq] != 0.0) field_ptr(Y, eq, m.ndofs)[n] += src[eq];
+}
+
 template <class C, class PH>
 struct FluxLds {
   static constexpr int NEQ = PH::NEQ, DIM = C::DIM;
@@ -1259,6 +1428,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
         PH::source(prm, u, up, gr, src);
         if constexpr (PH::AXISYM) PH::axisym_source(prm, u, up, gr, radius, src);
       }
+
       if (TPSRHS_ABLATE & 2) {
 #pragma unroll
         for (int k = 0; k < NEQ * DIM; k++) F[k] = uc[k % NEQ] + gr[k];

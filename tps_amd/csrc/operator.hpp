@@ -74,6 +74,9 @@ struct tpsrhs_operator {
   double *d_xh = nullptr, *d_yh = nullptr;  // staging for tpsrhs_mult_host
   double *d_rk = nullptr;                   // k | y | z of tpsrhs_rk4_step
   unsigned long long *d_nan = nullptr;
+  ForcingDev forcing = {};                  // host copy of the optional forcing terms (tpsrhs_set_forcing / _joule_heating)
+  ForcingDev *d_forcing = nullptr;
+  bool forcing_active = false;
   // halo
   tpsrhs_halo_fn halo = nullptr;
   void *halo_ctx = nullptr;
@@ -115,6 +118,7 @@ struct tpsrhs_operator {
     if (d_chem) (void)hipFree(d_chem);
     if (d_rk) (void)hipFree(d_rk);
     if (d_nan) (void)hipFree(d_nan);
+    if (d_forcing) (void)hipFree(d_forcing);
     if (d_blocks_halo) (void)hipFree(d_blocks_halo);
     if (d_blocks_interior) (void)hipFree(d_blocks_interior);
     for (auto &e : ev_halo)
@@ -173,6 +177,13 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
                        op->d_block_speed);
     HIP_CHECK(hipGetLastError());
   };
+  // ConstantPressureGradient / SpongeZone / HeatSource / JouleHeating, after the last k_flux launch
+  auto forcing = [&](const MeshDev &m) {
+    if (!op->forcing_active) return;
+    const int grid = static_cast<int>((op->ndofs + 255) / 256);
+    hipLaunchKernelGGL((k_forcing<C, PH>), dim3(grid), dim3(256), 0, s, m, prm, op->d_forcing, x, op->d_gradUp, y);
+    HIP_CHECK(hipGetLastError());
+  };
   if (op->timing) {
     op->ev = op->evs[op->sets_recorded % tpsrhs_operator::MAXSETS];
     HIP_CHECK(hipEventRecord(op->ev[0], s));
@@ -229,6 +240,7 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     HIP_CHECK(hipStreamWaitEvent(s, op->ev_halo[3], 0));
     flux(mh, nh);
   }
+  forcing(all);
   if (op->timing) {
     HIP_CHECK(hipEventRecord(op->ev[3], s));
     op->sets_recorded++;

@@ -68,6 +68,7 @@ struct DryAirPhys {
   static constexpr int NEQ = DIM_ + 2;
   static constexpr int NACTIVE = 0;
   static constexpr bool HAS_SOURCE = false;
+  static constexpr bool TWO_TEMPERATURE = false;
   static constexpr bool AXISYM = false;
   static constexpr bool VISC_USES_GRAD_RHO = false;  // Newtonian stress + Fourier flux: grad u and grad T only
   static constexpr bool HEAVY = false;  // light point physics: inlined at every face pass
@@ -115,6 +116,11 @@ struct DryAirPhys {
   }
   __device__ static inline double max_char_speed(const Params &p, const double *U) {
     return max_char_speed(p, U, make_state(p, U));
+  }
+  // DryAir::ComputeSpeedOfSound, src/equation_of_state.cpp:337-348
+  __device__ static inline double sound_speed(const Params &p, const double *U) {
+    const State s = make_state(p, U);
+    return sqrt(p.gamma * s.p * s.ir);
   }
 
   // F(U).n, src/fluxes.cpp:135-170 contracted with n as in RiemannSolverTPS::ComputeFluxDotN

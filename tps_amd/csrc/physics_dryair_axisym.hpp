@@ -16,7 +16,7 @@ namespace tpsrhs {
 
 struct DryAirAxiPhys {
   static constexpr int DIM = 2, NVEL = 3, NEQ = 5, NACTIVE = 0, ITH = 4;
-  static constexpr bool HAS_SOURCE = true, AXISYM = true, HEAVY = true;
+  static constexpr bool HAS_SOURCE = true, AXISYM = true, HEAVY = true, TWO_TEMPERATURE = false;
   static constexpr bool VISC_USES_GRAD_RHO = false;
   static constexpr int MINW_GRAD = 1, MINW_FLUX = 2;
   typedef DryAirParams Params;
@@ -47,6 +47,10 @@ struct DryAirAxiPhys {
   __device__ static inline void clamp_species(double *) {}
   __device__ static inline double max_char_speed(const Params &p, const double *, const State &s) {
     return fast_sqrt(s.k * s.ir) + fast_sqrt(p.gamma * s.p * s.ir);
+  }
+  __device__ static inline double sound_speed(const Params &p, const double *U) {  // src/equation_of_state.cpp:337-348
+    const State s = make_state(p, U);
+    return sqrt(p.gamma * s.p * s.ir);
   }
   __device__ static inline void conv_flux_n(const double *U, const State &s, const double *n, double *Fn) {
     const double un = s.vel[0] * n[0] + s.vel[1] * n[1];

@@ -166,6 +166,7 @@ struct PlasmaPhys {
   static constexpr int IE = NSP_ - 2, IB = NSP_ - 1;  // electron, background
   static constexpr int ITH = NVEL_ + 1, ITE = NEQ - 1;
   static constexpr bool HAS_SOURCE = true;
+  static constexpr bool TWO_TEMPERATURE = TWOT;
   static constexpr bool VISC_USES_GRAD_RHO = true;  // mole-fraction gradients need grad(rho)
   static constexpr bool AXISYM = NVEL_ > DIM_;  // dim 2 with (r, z, theta) velocity components
   static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : 2, MINW_FLUX = 2;  // waves per SIMD asked of the allocator
@@ -265,6 +266,9 @@ struct PlasmaPhys {
   }
   __device__ static inline double max_char_speed(const Params &p, const double *U) {
     return max_char_speed(p, U, make_state(p, U));
+  }
+  __device__ static inline double sound_speed(const Params &p, const double *U) {  // :1405-1432
+    return make_state(p, U).c;
   }
 
   // F(U).n, src/fluxes.cpp:135-170

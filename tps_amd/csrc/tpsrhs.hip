@@ -426,6 +426,86 @@ int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double 
   });
 }
 
+namespace {
+void upload_forcing(tpsrhs_operator *h) {
+  const ForcingDev &f = h->forcing;
+  h->forcing_active = f.has_pg || f.nheat > 0 || f.nsponge > 0 || f.joule != nullptr;
+  if (!h->forcing_active) return;
+  HIP_CHECK(hipSetDevice(h->device));
+  if (!h->d_forcing) h->d_forcing = dev_alloc<ForcingDev>(1);
+  HIP_CHECK(hipStreamSynchronize(h->stream));  // an earlier Mult may still read the block
+  HIP_CHECK(hipMemcpy(h->d_forcing, &h->forcing, sizeof(ForcingDev), hipMemcpyHostToDevice));
+}
+}  // namespace
+
+int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *in) {
+  if (!h) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_set_forcing: NULL handle");
+  return guarded([&] {
+    ForcingDev f = {};
+    f.joule = h->forcing.joule;
+    if (in) {
+      if (in->num_heat_sources < 0 || in->num_heat_sources > TPSRHS_MAXHEATSOURCES || in->num_sponge_zones < 0 ||
+          in->num_sponge_zones > TPSRHS_MAXSPONGEZONES)
+        throw std::invalid_argument("tpsrhs_set_forcing: heat source / sponge zone count out of range");
+      const int dim = h->dim;
+      f.has_pg = in->has_pressure_gradient ? 1 : 0;
+      for (int d = 0; d < 3; d++) f.pg[d] = in->pressure_gradient[d];
+      f.nheat = in->num_heat_sources;
+      for (int i = 0; i < f.nheat; i++) {  // HeatSource constructor, src/forcing_terms.cpp:890-899
+        const tpsrhs_heat_source &s = in->heat_sources[i];
+        ForcingDev::Heat &d = f.heat[i];
+        d.value = s.value;
+        d.radius = s.radius;
+        double mod = 0.0;
+        for (int k = 0; k < dim; k++) mod += (s.point2[k] - s.point1[k]) * (s.point2[k] - s.point1[k]);
+        mod = std::sqrt(mod);
+        if (!(mod > 0.0)) throw std::invalid_argument("tpsrhs_set_forcing: heat source with point1 == point2");
+        d.len = mod;
+        for (int k = 0; k < 3; k++) {
+          d.p1[k] = s.point1[k];
+          d.axis[k] = k < dim ? (s.point2[k] - s.point1[k]) / mod : 0.0;
+        }
+      }
+      f.nsponge = in->num_sponge_zones;
+      for (int i = 0; i < f.nsponge; i++) {
+        const tpsrhs_sponge_zone &s = in->sponge_zones[i];
+        ForcingDev::Sponge &d = f.sponge[i];
+        if (s.type != TPSRHS_SPONGE_PLANAR && s.type != TPSRHS_SPONGE_ANNULUS)
+          throw std::invalid_argument("tpsrhs_set_forcing: unknown sponge zone type");
+        if (s.type == TPSRHS_SPONGE_ANNULUS && dim != 3)
+          throw Unsupported("annular sponge zone needs dim == 3 (the reference's transform indexes 3 components)");
+        d.type = s.type;
+        double mod = 0.0;  // "make sure normal is unitary", src/forcing_terms.cpp:528-532
+        for (int k = 0; k < dim; k++) mod += s.normal[k] * s.normal[k];
+        mod = std::sqrt(mod);
+        if (!(mod > 0.0)) throw std::invalid_argument("tpsrhs_set_forcing: sponge zone with a zero normal");
+        for (int k = 0; k < 3; k++) {
+          d.normal[k] = k < dim ? s.normal[k] / mod : 0.0;
+          d.p0[k] = s.point0[k];
+          d.pinit[k] = s.point_init[k];
+        }
+        d.r1 = s.r1;
+        d.r2 = s.r2;
+        d.mult = s.mult_factor;
+        for (int eq = 0; eq < TPSRHS_MAXEQUATIONS; eq++) d.target[eq] = eq < h->neq ? s.target_U[eq] : 0.0;
+        if (!(d.target[0] > 0.0)) throw std::invalid_argument("tpsrhs_set_forcing: sponge target density must be positive");
+      }
+    }
+    h->forcing = f;
+    upload_forcing(h);
+  });
+}
+
+int tpsrhs_set_joule_heating(tpsrhs_handle h, const double *joule_heating) {
+  if (!h) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_set_joule_heating: NULL handle");
+  return guarded([&] {
+    // JouleHeating::updateTerms asserts nvel == 3 (src/forcing_terms.cpp:444)
+    if (joule_heating && h->nvel != 3) throw Unsupported("JouleHeating needs three velocity components (3-D or axisymmetric)");
+    h->forcing.joule = joule_heating;
+    upload_forcing(h);
+  });
+}
+
 int tpsrhs_update_gradients(tpsrhs_handle h, const double *x) {
   if (!h || !x) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_update_gradients: NULL argument");
   return guarded([&] {

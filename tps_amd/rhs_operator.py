@@ -136,6 +136,26 @@ class RHSoperator:
             self.nan_count = bad.value
         return t.value
 
+    def setForcing(self, forcing):
+        """ConstantPressureGradient / SpongeZone / HeatSource of the reference's ``forcing`` array
+        (``src/rhs_operator.cpp:101-123``); ``forcing``: :class:`tps_amd.capi.Forcing` or ``None``."""
+        st = self._lib.tpsrhs_set_forcing(self._h, C.byref(forcing) if forcing is not None else None)
+        if st != 0:
+            raise TpsRhsError(st, "tpsrhs_set_forcing")
+
+    def setJouleHeating(self, joule_heating):
+        """The ``joule_heating_`` grid function of ``JouleHeating`` (``src/forcing_terms.cpp:443-471``): a
+        float64 CUDA tensor of NDofs entries the operator reads at every ``Mult`` (kept alive here), or ``None``."""
+        if joule_heating is not None:
+            if (joule_heating.dtype != torch.float64 or not joule_heating.is_cuda or not joule_heating.is_contiguous()
+                    or joule_heating.numel() != self.NDofs):
+                raise ValueError("expected a contiguous float64 CUDA tensor of NDofs entries")
+        self._joule = joule_heating
+        st = self._lib.tpsrhs_set_joule_heating(
+            self._h, C.c_void_p(joule_heating.data_ptr()) if joule_heating is not None else None)
+        if st != 0:
+            raise TpsRhsError(st, "tpsrhs_set_joule_heating")
+
     def kernel_bytes(self):
         names = (C.c_char_p * 8)()
         b = (C.c_double * 8)()
