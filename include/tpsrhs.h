@@ -118,6 +118,9 @@ typedef struct tpsrhs_disc {
   int int_rule_type;     /* 0 Gauss-Legendre, 1 Gauss-Lobatto (reference integrationRule) */
   int axisymmetric;      /* dim must be 2; nvel = 3 */
   int use_bc_in_grad;    /* boundaryConditions/useBCinGrad (src/M2ulPhyS.cpp:3480) */
+  int use_roe;           /* flow/useRoe (src/M2ulPhyS.cpp:2676): RiemannSolverTPS::Eval_Roe on interior faces and
+                          * inviscid walls (src/riemann_solver.cpp:66-72,117-206); the reference's formula is
+                          * 2-D, single-species, not axisymmetric -- anything else: TPSRHS_ERR_UNSUPPORTED */
 } tpsrhs_disc;
 
 /* ---- physics parameter blocks: the PODs of src/dataStructures.hpp:537-729 -------------------- */

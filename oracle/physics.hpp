@@ -515,7 +515,75 @@ class RiemannSolver {
   int num_equation;
   GasMixture *mixture;
   Fluxes *fluxClass;
-  RiemannSolver(int neq, GasMixture *m, Fluxes *f) : num_equation(neq), mixture(m), fluxClass(f) {}
+  bool useRoe = false;
+  RiemannSolver(int neq, GasMixture *m, Fluxes *f, bool roe = false)
+      : num_equation(neq), mixture(m), fluxClass(f), useRoe(roe) {}
+  // src/riemann_solver.cpp:66-72
+  void Eval(const double *state1, const double *state2, const double *nor, double *flux, bool LF = false) const {
+    if (useRoe && !LF)
+      Eval_Roe(state1, state2, nor, flux);
+    else
+      Eval_LF(state1, state2, nor, flux);
+  }
+  // src/riemann_solver.cpp:117-206 (Roe, Lohner); as there: 2-D velocity components, gamma - 1 = 0.4
+  void Eval_Roe(const double *state1, const double *state2, const double *nor, double *flux) const {
+    const int dim = mixture->dim;
+    const int NS_eq = 2 + dim;
+    double normag = 0;
+    for (int i = 0; i < dim; i++) normag += nor[i] * nor[i];
+    normag = std::sqrt(normag);
+    double unitN[3];
+    for (int d = 0; d < dim; d++) unitN[d] = nor[d] / normag;
+    double fluxes1[MAXEQ * MAXDIM], fluxes2[MAXEQ * MAXDIM], meanFlux[MAXEQ];
+    fluxClass->ComputeConvectiveFluxes(state1, fluxes1);
+    fluxClass->ComputeConvectiveFluxes(state2, fluxes2);
+    for (int eq = 0; eq < NS_eq; eq++) {
+      meanFlux[eq] = 0.;
+      for (int d = 0; d < dim; d++)
+        meanFlux[eq] += (fluxes1[eq + d * num_equation] + fluxes2[eq + d * num_equation]) * unitN[d];
+    }
+    const double r = std::sqrt(state1[0] * state2[0]);
+    double vel[3];
+    for (int i = 0; i < dim; i++) {
+      vel[i] = state1[i + 1] / std::sqrt(state1[0]) + state2[i + 1] / std::sqrt(state2[0]);
+      vel[i] /= std::sqrt(state1[0]) + std::sqrt(state2[0]);
+    }
+    double qk = 0.;
+    for (int d = 0; d < dim; d++) qk += vel[d] * unitN[d];
+    const double p1 = mixture->ComputePressure(state1);
+    const double p2 = mixture->ComputePressure(state2);
+    double H = (state1[1 + dim] + p1) / std::sqrt(state1[0]) + (state2[1 + dim] + p2) / std::sqrt(state2[0]);
+    H /= std::sqrt(state1[0]) + std::sqrt(state2[0]);
+    const double a2 = 0.4 * (H - 0.5 * (vel[0] * vel[0] + vel[1] * vel[1]));
+    const double a = std::sqrt(a2);
+    double lamb[3] = {qk, qk + a, qk - a};
+    if (std::fabs(lamb[0]) < 1e-4) lamb[0] = 1e-4;
+    const double deltaP = p2 - p1;
+    const double deltaU = state2[1] / state2[0] - state1[1] / state1[0];
+    const double deltaV = state2[2] / state2[0] - state1[2] / state1[0];
+    const double deltaQk = deltaU * unitN[0] + deltaV * unitN[1];
+    double DF1[4], DF4[4], DF5[4];
+    DF1[0] = 1.;
+    DF1[1] = vel[0];
+    DF1[2] = vel[1];
+    DF1[3] = 0.5 * (vel[0] * vel[0] + vel[1] * vel[1]);
+    for (int i = 0; i < 4; i++) DF1[i] *= state2[0] - state1[0] - deltaP / a2;
+    DF1[1] += r * (deltaU - unitN[0] * deltaQk);
+    DF1[2] += r * (deltaV - unitN[1] * deltaQk);
+    DF1[3] += r * (vel[0] * deltaU + vel[1] * deltaV - qk * deltaQk);
+    for (int i = 0; i < 4; i++) DF1[i] *= std::fabs(lamb[0]);
+    DF4[0] = 1.;
+    DF4[1] = vel[0] + unitN[0] * a;
+    DF4[2] = vel[1] + unitN[1] * a;
+    DF4[3] = H + qk * a;
+    for (int i = 0; i < 4; i++) DF4[i] *= std::fabs(lamb[1]) * (deltaP + r * a * deltaQk) * 0.5 / a2;
+    DF5[0] = 1.;
+    DF5[1] = vel[0] - unitN[0] * a;
+    DF5[2] = vel[1] - unitN[1] * a;
+    DF5[3] = H - qk * a;
+    for (int i = 0; i < 4; i++) DF5[i] *= std::fabs(lamb[2]) * (deltaP - r * a * deltaQk) * 0.5 / a2;
+    for (int i = 0; i < NS_eq; i++) flux[i] = (meanFlux[i] - (DF1[i] + DF4[i] + DF5[i])) * 0.5 * normag;
+  }
   void ComputeFluxDotN(const double *state, const double *nor, double *fluxN) const {
     const int dim = mixture->dim;
     double fluxes[MAXEQ * MAXDIM];
@@ -676,7 +744,7 @@ class BoundaryCondition {
         stateMirror[2] = stateIn[0] * (vel[1] - 2. * vn * unitN[1]);
         if (dim == 3) stateMirror[3] = stateIn[0] * (vel[2] - 2. * vn * unitN[2]);
         if ((nvel == 3) && (dim == 2)) stateMirror[3] = stateIn[0] * vel[2];
-        rsolver->Eval_LF(stateIn, stateMirror, normal, bdrFlux);
+        rsolver->Eval(stateIn, stateMirror, normal, bdrFlux);  // LF = false: Roe when flow/useRoe
         double wallViscF[MAXEQ], viscF[MAXEQ * MAXDIM], viscFw[MAXEQ * MAXDIM];
         fluxClass->ComputeViscousFluxes(stateMirror, gradState, transip, delta, distance, viscFw);
         for (int eq = 0; eq < num_equation; eq++) {

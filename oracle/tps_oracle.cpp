@@ -82,7 +82,9 @@ struct Operator {
     }
     neq = mixture->num_equation;
     fluxes.reset(new Fluxes(mixture.get(), p->eq_system, transport.get(), neq, dim, axisym));
-    rsolver.reset(new RiemannSolver(neq, mixture.get(), fluxes.get()));
+    if (d->use_roe && (dim != 2 || axisym || p->working_fluid != TPSRHS_DRY_AIR))
+      throw std::runtime_error("Eval_Roe: 2-D, single species, not axisymmetric (src/riemann_solver.cpp:117-206)");
+    rsolver.reset(new RiemannSolver(neq, mixture.get(), fluxes.get(), d->use_roe != 0));
     if (p->working_fluid != TPSRHS_DRY_AIR) {  // src/rhs_operator.cpp:125-129
       source.reset(new SourceTerm(dim, neq, static_cast<PerfectMixture *>(mixture.get()), transport.get(), *p));
     }
@@ -358,7 +360,7 @@ struct Operator {
           }
           for (int sp = 0; sp < nAct; sp++) u2[nvel + 2 + sp] = std::max(u2[nvel + 2 + sp], 0.0);
           interpGrad(F.e2, shape2.data(), g2);
-          rsolver->Eval_LF(u1, u2, fp.nor, fluxN);
+          rsolver->Eval(u1, u2, fp.nor, fluxN);  // src/face_integrator.cpp:324
           double v1[MAXEQ * MAXDIM], v2[MAXEQ * MAXDIM];
           fluxes->ComputeViscousFluxes(u1, g1, transip, 0.0, 0.0, v1);
           fluxes->ComputeViscousFluxes(u2, g2, transip, 0.0, 0.0, v2);
@@ -825,6 +827,10 @@ int tpsoracle_point_bdr_viscous_flux(void *h, const double *state, const double 
 }
 int tpsoracle_point_lf(void *h, const double *s1, const double *s2, const double *nor, double *flux) {
   static_cast<Operator *>(h)->rsolver->Eval_LF(s1, s2, nor, flux);
+  return 0;
+}
+int tpsoracle_point_roe(void *h, const double *s1, const double *s2, const double *nor, double *flux) {
+  static_cast<Operator *>(h)->rsolver->Eval_Roe(s1, s2, nor, flux);
   return 0;
 }
 int tpsoracle_point_bdr_flux(void *h, int attr, const double *nor, const double *state, const double *gradUp,

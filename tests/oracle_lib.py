@@ -54,6 +54,7 @@ def lib():
         L.tpsoracle_point_viscous_flux.argtypes = [vp, _dp, _dp, C.c_double, _dp]
         L.tpsoracle_point_bdr_viscous_flux.argtypes = [vp, _dp, _dp, C.c_double, _dp, _dp, C.POINTER(C.c_int), _dp]
         L.tpsoracle_point_lf.argtypes = [vp, _dp, _dp, _dp, _dp]
+        L.tpsoracle_point_roe.argtypes = [vp, _dp, _dp, _dp, _dp]
         L.tpsoracle_point_bdr_flux.argtypes = [vp, C.c_int, _dp, _dp, _dp, C.c_double, _dp]
         L.tpsoracle_point_flux_transport.argtypes = [vp, _dp, _dp, _dp, _dp]
         L.tpsoracle_point_source.argtypes = [vp, _dp, _dp, _dp, _dp]
@@ -204,6 +205,15 @@ class Oracle:
         n[: len(nor)] = nor
         out = np.zeros(self.neq)
         lib().tpsoracle_point_lf(self.h, _p(s1), _p(s2), _p(n), _p(out))
+        return out
+
+    def roe(self, s1, s2, nor):
+        s1 = np.ascontiguousarray(s1, dtype=np.float64)
+        s2 = np.ascontiguousarray(s2, dtype=np.float64)
+        n = np.zeros(3)
+        n[: len(nor)] = nor
+        out = np.zeros(self.neq)
+        lib().tpsoracle_point_roe(self.h, _p(s1), _p(s2), _p(n), _p(out))
         return out
 
     def bdr_flux(self, attr, nor, state, grad, radius=-1.0):

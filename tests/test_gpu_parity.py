@@ -200,3 +200,31 @@ def test_plasma_six_species(geo, order, transport):
         c = cases.argon_cyl3d(4, 12, 3, order, physics=ph)
     amp = 0.005 if order == 1 else 0.01
     _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=9, amp=amp), tol=_tol(amp))
+
+
+# ---- flow/useRoe: RiemannSolverTPS::Eval_Roe on interior faces and inviscid walls (2-D dry air) ----
+@pytest.mark.parametrize("order,eq", [(1, capi.EULER), (3, capi.NS)])
+def test_roe_flux_2d(order, eq):
+    attrs = {(0, 0): 1, (0, 1): 2, (1, 0): 3, (1, 1): 3}
+    mesh = meshgen.scramble_orientations(
+        meshgen.box_quad(7, 5, lengths=(1.0, 0.7), periodic=(False, False), bdr_attr=attrs, warp=0.08), 3)
+    disc = capi.Disc(order, 0, 0, 0, 0, 1)
+    ph = capi.dry_air_physics(eq, visc_mult=300.0)
+    bcs = [capi.make_bc(1, capi.INLET, capi.SUB_DENS_VEL, [1.2, 20.0, 0.0, 0.0]),
+           capi.make_bc(2, capi.OUTLET, capi.SUB_P, [101300.0]), capi.make_bc(3, capi.WALL, capi.INV)]
+    U = cases.dry_air_state(node_coordinates(mesh, order), seed=14)
+    _compare(mesh, disc, ph, bcs, U)
+    # the flag changes the residual (the test is not comparing two Lax-Friedrichs runs)
+    lf = oracle_mult(mesh, capi.Disc(order, 0, 0, 0, 0, 0), ph, bcs, U)["y"]
+    roe = oracle_mult(mesh, disc, ph, bcs, U)["y"]
+    assert rel_maxnorm(roe, lf).max() > 1e-3
+
+
+def test_roe_flux_unsupported_in_3d():
+    from tps_amd.rhs_operator import RHSoperator, TpsRhsError
+
+    c = cases.cyl3d(4, 12, 3, 1, capi.EULER, capi.INV)
+    c.disc.use_roe = 1
+    with pytest.raises(TpsRhsError) as e:
+        RHSoperator(c.mesh, c.disc, c.physics, c.bcs)
+    assert "UNSUPPORTED" in str(e.value)

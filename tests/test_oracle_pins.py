@@ -112,3 +112,30 @@ def test_lax_friedrichs_consistency_and_wall_ghosts():
     # subsonic outlet keeps density and momentum of the interior state in the ghost
     fo = o.bdr_flux(2, n, U, np.zeros((3, 5)))
     assert np.all(np.isfinite(fo))
+
+
+def test_roe_flux_known_answers():
+    """RiemannSolverTPS::Eval_Roe (src/riemann_solver.cpp:117-206): consistency F^(U, U, n) = F(U).n, and pure
+    upwinding when every characteristic speed has the sign of the normal velocity (supersonic): F^ = F(U_left).n."""
+    from tps_amd import meshgen
+
+    mesh = meshgen.box_quad(3, 3)
+    o = Oracle(mesh, capi.Disc(1, 0, 0, 0, 0, 1), capi.dry_air_physics(capi.EULER), [])
+    n = np.array([0.6, -0.35])
+    U = o.cons(np.array([1.1, 30.0, -4.0, 310.0]))
+    fn = (o.convective_flux(U) * n[:, None]).sum(axis=0)
+    assert np.abs(o.roe(U, U, n) - fn).max() < 1e-9 * np.abs(fn).max()
+    # Mach 3 along the normal
+    un = n / np.linalg.norm(n)
+    c = np.sqrt(1.4 * 287.058 * 300.0)
+    UL = o.cons(np.array([1.0, 3.0 * c * un[0], 3.0 * c * un[1], 300.0]))
+    UR = o.cons(np.array([1.3, 3.2 * c * un[0] + 5.0, 3.2 * c * un[1] - 2.0, 340.0]))
+    fl = (o.convective_flux(UL) * n[:, None]).sum(axis=0)
+    assert np.abs(o.roe(UL, UR, n) - fl).max() < 1e-9 * np.abs(fl).max()
+    # and the solver is only offered where the reference's formula is valid
+    import pytest
+
+    c3 = cases.cyl3d(3, 8, 3, 1, capi.EULER, capi.INV)
+    c3.disc.use_roe = 1
+    with pytest.raises(RuntimeError):
+        Oracle(c3.mesh, c3.disc, c3.physics, c3.bcs)

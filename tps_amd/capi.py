@@ -49,7 +49,7 @@ class Mesh(C.Structure):
 
 class Disc(C.Structure):
     _fields_ = [("order", C.c_int), ("basis_type", C.c_int), ("int_rule_type", C.c_int),
-                ("axisymmetric", C.c_int), ("use_bc_in_grad", C.c_int)]
+                ("axisymmetric", C.c_int), ("use_bc_in_grad", C.c_int), ("use_roe", C.c_int)]
 
 
 class DryAir(C.Structure):

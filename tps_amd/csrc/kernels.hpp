@@ -1204,13 +1204,13 @@ __device__ inline void face_flux_dir(const MeshDev &m, const typename PH::Params
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] = u1[eq] + u2[eq] * n[0];
     } else if (nb >= 0) {
       PH::clamp_species(u2);
-      PH::lax_friedrichs(prm, u1, u2, n, fh[rd]);
+      PH::riemann(prm, u1, u2, n, fh[rd]);
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] -= 0.5 * (tb.own[rd][eq] - tb.nbv[rd][eq]);
     } else {
       double ug[NEQ];
       PH::bc_ghost(prm, prm.bc[-nb - 1], u1, n, ug);
-      PH::lax_friedrichs(prm, u1, ug, n, fh[rd]);
+      PH::riemann_bc(prm, prm.bc[-nb - 1], u1, ug, n, fh[rd]);
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] += tb.own[rd][eq];
     }
@@ -1318,13 +1318,13 @@ __device__ inline void face_flux_2d(const MeshDev &m, const typename PH::Params 
     face_geometry_rt<C>(d, &sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
     if (nb >= 0) {
       PH::clamp_species(u2);
-      PH::lax_friedrichs(prm, u1, u2, n, fh[rd]);
+      PH::riemann(prm, u1, u2, n, fh[rd]);
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] -= 0.5 * (tb.own[rd][eq] - tb.nbv[rd][eq]);
     } else {
       double ug[NEQ];
       PH::bc_ghost(prm, prm.bc[-nb - 1], u1, n, ug);
-      PH::lax_friedrichs(prm, u1, ug, n, fh[rd]);
+      PH::riemann_bc(prm, prm.bc[-nb - 1], u1, ug, n, fh[rd]);
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] += tb.own[rd][eq];
     }

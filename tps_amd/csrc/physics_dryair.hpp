@@ -58,6 +58,7 @@ struct DryAirParams {
   int eq_system;  // tpsrhs_equations
   int use_bc_in_grad;
   int num_bcs;
+  int use_roe;  // flow/useRoe: Roe flux on interior faces and inviscid walls (2-D only)
   BcDev bc[MAXBC];
 };
 
@@ -162,6 +163,66 @@ struct DryAirPhys {
     const double hl = 0.5 * lam * fast_sqrt(nm);
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) F[eq] = 0.5 * (f1[eq] + f2[eq]) - hl * (U2[eq] - U1[eq]);
+  }
+
+  // RiemannSolverTPS::Eval_Roe, src/riemann_solver.cpp:117-206 (Roe, Lohner): the reference's formula knows two
+  // velocity components and gamma - 1 = 0.4
+  __device__ static inline void roe(const Params &p, const double *U1, const double *U2, const double *n, double *F) {
+    static_assert(DIM == 2, "Eval_Roe is 2-D");
+    const State s1 = make_state(p, U1), s2 = make_state(p, U2);
+    const double normag = sqrt(n[0] * n[0] + n[1] * n[1]);
+    const double un[2] = {n[0] / normag, n[1] / normag};
+    double f1[NEQ], f2[NEQ], mean[NEQ];
+    conv_flux_n(p, U1, s1, un, f1);
+    conv_flux_n(p, U2, s2, un, f2);
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) mean[eq] = f1[eq] + f2[eq];
+    const double sr1 = sqrt(U1[0]), sr2 = sqrt(U2[0]);
+    const double r = sqrt(U1[0] * U2[0]);
+    const double vel[2] = {(U1[1] / sr1 + U2[1] / sr2) / (sr1 + sr2), (U1[2] / sr1 + U2[2] / sr2) / (sr1 + sr2)};
+    const double qk = vel[0] * un[0] + vel[1] * un[1];
+    const double H = ((U1[3] + s1.p) / sr1 + (U2[3] + s2.p) / sr2) / (sr1 + sr2);
+    const double v2h = 0.5 * (vel[0] * vel[0] + vel[1] * vel[1]);
+    const double a2 = 0.4 * (H - v2h);
+    const double a = sqrt(a2);
+    double l0 = qk;
+    if (fabs(l0) < 1e-4) l0 = 1e-4;
+    const double dP = s2.p - s1.p;
+    const double dU = U2[1] / U2[0] - U1[1] / U1[0];
+    const double dV = U2[2] / U2[0] - U1[2] / U1[0];
+    const double dQ = dU * un[0] + dV * un[1];
+    const double drho = U2[0] - U1[0] - dP / a2;
+    double DF1[4] = {drho, vel[0] * drho, vel[1] * drho, v2h * drho};
+    DF1[1] += r * (dU - un[0] * dQ);
+    DF1[2] += r * (dV - un[1] * dQ);
+    DF1[3] += r * (vel[0] * dU + vel[1] * dV - qk * dQ);
+    const double c4 = fabs(qk + a) * (dP + r * a * dQ) * 0.5 / a2;
+    const double c5 = fabs(qk - a) * (dP - r * a * dQ) * 0.5 / a2;
+    const double DF4[4] = {c4, (vel[0] + un[0] * a) * c4, (vel[1] + un[1] * a) * c4, (H + qk * a) * c4};
+    const double DF5[4] = {c5, (vel[0] - un[0] * a) * c5, (vel[1] - un[1] * a) * c5, (H - qk * a) * c5};
+#pragma unroll
+    for (int i = 0; i < 4; i++) F[i] = (mean[i] - (DF1[i] * fabs(l0) + DF4[i] + DF5[i])) * 0.5 * normag;
+  }
+  // RiemannSolverTPS::Eval (src/riemann_solver.cpp:66-72): interior faces ask with LF = false ...
+  __device__ static inline void riemann(const Params &p, const double *U1, const double *U2, const double *n, double *F) {
+    if constexpr (DIM == 2) {
+      if (p.use_roe) {
+        roe(p, U1, U2, n, F);
+        return;
+      }
+    }
+    lax_friedrichs(p, U1, U2, n, F);
+  }
+  // ... and so does the inviscid wall (src/wallBC.cpp:301); every other boundary type passes LF = true
+  __device__ static inline void riemann_bc(const Params &p, const BcDev &bc, const double *U1, const double *Ug,
+                                           const double *n, double *F) {
+    if constexpr (DIM == 2) {
+      if (p.use_roe && bc.category == TPSRHS_WALL && bc.type == TPSRHS_INV) {
+        roe(p, U1, Ug, n, F);
+        return;
+      }
+    }
+    lax_friedrichs(p, U1, Ug, n, F);
   }
 
   struct Transport {

@@ -71,6 +71,14 @@ struct DryAirAxiPhys {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) F[eq] = 0.5 * (f1[eq] + f2[eq]) - hl * (U2[eq] - U1[eq]);
   }
+  // RiemannSolverTPS::Eval: Lax-Friedrichs only here (Eval_Roe is 2-D single-species, not axisymmetric)
+  __device__ static inline void riemann(const Params &p, const double *U1, const double *U2, const double *n, double *F) {
+    lax_friedrichs(p, U1, U2, n, F);
+  }
+  __device__ static inline void riemann_bc(const Params &p, const BcDev &, const double *U1, const double *Ug,
+                                           const double *n, double *F) {
+    lax_friedrichs(p, U1, Ug, n, F);
+  }
   // Sutherland viscosity, bulk viscosity and conductivity at the temperature of a conserved state
   __device__ static inline void transport(const Params &p, const State &s, double &visc, double &bulk, double &k) {
     const double T = s.p * p.inv_Rg * s.ir;

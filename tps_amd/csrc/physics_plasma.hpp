@@ -300,6 +300,14 @@ struct PlasmaPhys {
     for (int eq = 0; eq < NEQ; eq++) F[eq] = 0.5 * (f1[eq] + f2[eq]) - hl * (U2[eq] - U1[eq]);
   }
 
+  // RiemannSolverTPS::Eval: Lax-Friedrichs only here (Eval_Roe is 2-D single-species, not axisymmetric)
+  __device__ static inline void riemann(const Params &p, const double *U1, const double *U2, const double *n, double *F) {
+    lax_friedrichs(p, U1, U2, n, F);
+  }
+  __device__ static inline void riemann_bc(const Params &p, const BcDev &, const double *U1, const double *Ug,
+                                           const double *n, double *F) {
+    lax_friedrichs(p, U1, Ug, n, F);
+  }
   // ---- species primitives and mole-fraction gradient --------------------------------------
   struct Species {
     double X[NSP], Y[NSP], n[NSP], ntot;

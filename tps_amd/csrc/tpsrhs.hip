@@ -163,6 +163,9 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   const bool plasma = phys->working_fluid == TPSRHS_USER_DEFINED;
   if (disc->axisymmetric && mesh->dim != 2) throw std::invalid_argument("the axisymmetric formulation needs a 2-D mesh");
   if (phys->working_fluid != TPSRHS_DRY_AIR && !plasma) throw Unsupported("WorkingFluid::LTE_FLUID is out of scope");
+  if (disc->use_roe && (mesh->dim != 2 || disc->axisymmetric || plasma))
+    throw Unsupported("flow/useRoe: Eval_Roe of the reference is 2-D, single-species, not axisymmetric "
+                      "(src/riemann_solver.cpp:117-206)");
   if (phys->eq_system != TPSRHS_EULER && phys->eq_system != TPSRHS_NS) throw Unsupported("NS_PASSIVE is out of scope");
   if (num_bcs > (plasma ? PLASMA_MAXBC : MAXBC)) throw Unsupported("too many boundary conditions");
   for (int i = 0; i < num_bcs; i++) {
@@ -260,6 +263,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     d.cp_div_pr = d.gamma * d.Rg / (phys->dry_air.sutherland_Pr * (d.gamma - 1.0));
     d.eq_system = phys->eq_system;
     d.use_bc_in_grad = disc->use_bc_in_grad;
+    d.use_roe = disc->use_roe ? 1 : 0;
     d.num_bcs = num_bcs;
     for (int i = 0; i < num_bcs; i++) {
       d.bc[i].category = bcs[i].category;
