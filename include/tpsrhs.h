@@ -78,8 +78,19 @@ enum tpsrhs_gas_coll {
   TPSRHS_NONE_ARGCOLL = 5
 };
 enum tpsrhs_bc_category { TPSRHS_INLET = 0, TPSRHS_OUTLET = 1, TPSRHS_WALL = 2 };
-enum tpsrhs_inlet_type { TPSRHS_UNI_DENS_VEL = 0, TPSRHS_INTERPOLATE = 1, TPSRHS_SUB_DENS_VEL = 2 };
-enum tpsrhs_outlet_type { TPSRHS_SUB_P = 0 };
+enum tpsrhs_inlet_type {
+  TPSRHS_UNI_DENS_VEL = 0,
+  TPSRHS_INTERPOLATE = 1,
+  TPSRHS_SUB_DENS_VEL = 2,
+  TPSRHS_SUB_DENS_VEL_NR = 6,   /* non-reflecting, density and velocity (src/inletBC.cpp:576-727) */
+  TPSRHS_SUB_VEL_CONST_ENT = 7  /* non-reflecting, velocity, constant entropy (same routine, L2 = 0) */
+};
+enum tpsrhs_outlet_type {
+  TPSRHS_SUB_P = 0,
+  TPSRHS_SUB_P_NR = 2,     /* non-reflecting pressure outlet (src/outletBC.cpp:573-728) */
+  TPSRHS_SUB_MF_NR = 3,    /* non-reflecting mass-flow outlet (src/outletBC.cpp:739-892) */
+  TPSRHS_SUB_MF_NR_PW = 4  /* point-wise variant (src/outletBC.cpp:894-1027) */
+};
 enum tpsrhs_wall_type {
   TPSRHS_INV = 0,
   TPSRHS_SLIP = 1,
@@ -121,6 +132,8 @@ typedef struct tpsrhs_disc {
   int use_roe;           /* flow/useRoe (src/M2ulPhyS.cpp:2676): RiemannSolverTPS::Eval_Roe on interior faces and
                           * inviscid walls (src/riemann_solver.cpp:66-72,117-206); the reference's formula is
                           * 2-D, single-species, not axisymmetric -- anything else: TPSRHS_ERR_UNSUPPORTED */
+  double ref_length;     /* flow/refLength (src/M2ulPhyS.cpp:2677), relaxation length of the non-reflecting
+                          * boundary conditions; 0 = the reference's default 1.0 */
 } tpsrhs_disc;
 
 /* ---- physics parameter blocks: the PODs of src/dataStructures.hpp:537-729 -------------------- */
@@ -212,6 +225,12 @@ typedef struct tpsrhs_bc {
   int type;      /* tpsrhs_inlet_type | tpsrhs_outlet_type | tpsrhs_wall_type */
   /* inlet SUB_DENS_VEL: rho, u, v, w, then active species (src/inletBC.cpp:729-757)
    * outlet SUB_P:       p                                  (src/outletBC.cpp:731-737)
+   * non-reflecting types (perfect gas only, as the reference's characteristic algebra):
+   *   inlet SUB_DENS_VEL_NR / SUB_VEL_CONST_ENT: rho, u, v, w;  outlet SUB_P_NR: p;  SUB_MF_NR(_PW): mass flow;
+   *   for all of them data[4..6] = the patch tangent `tangent1` the reference takes from its first boundary
+   *   face (src/outletBC.cpp:160-172; all zero: the library takes an edge of its own first face of the patch --
+   *   the boundary term does not depend on the choice for a planar patch) and data[7] = the total patch area
+   *   `area_` over all ranks (src/outletBC.cpp:329-343; mass-flow types only).
    * wall VISC_ISOTH:    T_wall                             (src/wallBC.cpp:96-111)
    * wall VISC_GNRL:     T_h, T_e, heavy thermal condition, electron thermal condition (WallData,
    *                     src/dataStructures.hpp:564-570; tpsrhs_thermal_condition)  (src/wallBC.cpp:112-148) */
@@ -229,11 +248,20 @@ typedef int (*tpsrhs_halo_fn)(void *ctx, int phase, const double *send, double *
                               int num_neighbors, const int *neighbor_ranks,
                               const int64_t *send_offsets, const int64_t *recv_offsets, void *stream);
 
+/* Sum over the ranks of the job, in place, of `count` doubles in DEVICE memory, ordered on `stream`: the
+ * MPI_Allreduce(SUM) of the boundary means of the non-reflecting inlet/outlet conditions
+ * (src/outletBC.cpp:533-540, src/inletBC.cpp:548-555; one call per Mult for all such patches together --
+ * ranks without faces on a patch contribute zeros, so the job-wide sum equals the reference's
+ * per-patch communicator).  Return 0 on success. */
+typedef int (*tpsrhs_reduce_fn)(void *ctx, double *values, int count, void *stream);
+
 typedef struct tpsrhs_runtime {
   int device;            /* HIP device ordinal (reference: rank % numGpusPerRank, src/tps.cpp:196) */
   void *stream;          /* hipStream_t for all work of this operator, NULL = default stream */
   tpsrhs_halo_fn halo;   /* required when mesh.num_shared_faces > 0 */
   void *halo_ctx;
+  tpsrhs_reduce_fn reduce; /* required when mesh.num_shared_faces > 0 and a non-reflecting patch exists */
+  void *reduce_ctx;
 } tpsrhs_runtime;
 
 typedef struct tpsrhs_operator *tpsrhs_handle;
@@ -294,6 +322,11 @@ int tpsrhs_kernel_bytes(tpsrhs_handle h, int capacity, const char **names, doubl
  * max_char_speed (may be NULL): value left by the last stage's Mult, which the reference turns into the
  * next dt (src/M2ulPhyS.cpp:2013-2016).  nan_count (may be NULL): number of NaN entries of the new x. */
 int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double *max_char_speed, int64_t *nan_count);
+
+/* The time step the non-reflecting boundary conditions integrate their boundary state with: the reference's
+ * BoundaryCondition holds a reference to M2ulPhyS::dt (src/BoundaryCondition.hpp:54) and advances `boundaryU`
+ * by dt in EVERY Mult (src/outletBC.cpp:712-724).  tpsrhs_rk4_step sets it itself. */
+int tpsrhs_set_dt(tpsrhs_handle h, double dt);
 
 /* ---- next row of the scope table: the other ForcingTerms of RHSoperator ----
  * RHSoperator appends these to its `forcing` array (src/rhs_operator.cpp:101-166) and adds them to y

@@ -625,6 +625,14 @@ class BoundaryCondition {
   int hvyCond = -1, elecCond = -1;
   BoundaryViscousFluxData bcFlux;
   BoundaryPrimitiveData bcState;
+  // state of the non-reflecting inlet / outlet types (src/inletBC.cpp:60-160, src/outletBC.cpp:60-210)
+  bool nonReflecting = false;
+  double tangent1[3] = {0, 0, 0};
+  double area_ = 0.0, refLength = 1.0;
+  const double *dt = nullptr;            // the reference member `double &dt` (src/BoundaryCondition.hpp:54)
+  mutable std::vector<double> boundaryU; // [point][eq], advanced by every flux evaluation
+  double meanUp[MAXEQ];
+  bool bdrUInit = false;
 
   BoundaryCondition(const tpsrhs_bc &bc, GasMixture *m, Fluxes *f, RiemannSolver *r, bool axisym, bool bcInGrad)
       : category(bc.category), type(bc.type), mixture(m), fluxClass(f), rsolver(r), useBCinGrad(bcInGrad) {
@@ -688,10 +696,165 @@ class BoundaryCondition {
           throw std::runtime_error("wall type outside the hot-path scope");
       }
     } else if (category == TPSRHS_INLET) {
-      if (type != TPSRHS_SUB_DENS_VEL) throw std::runtime_error("inlet type outside the hot-path scope");
+      if (type == TPSRHS_SUB_DENS_VEL_NR || type == TPSRHS_SUB_VEL_CONST_ENT)
+        nonReflecting = true;
+      else if (type != TPSRHS_SUB_DENS_VEL)
+        throw std::runtime_error("inlet type outside the hot-path scope");
     } else if (category == TPSRHS_OUTLET) {
-      if (type != TPSRHS_SUB_P) throw std::runtime_error("outlet type outside the hot-path scope");
+      if (type == TPSRHS_SUB_P_NR || type == TPSRHS_SUB_MF_NR || type == TPSRHS_SUB_MF_NR_PW)
+        nonReflecting = true;
+      else if (type != TPSRHS_SUB_P)
+        throw std::runtime_error("outlet type outside the hot-path scope");
     }
+    if (nonReflecting) {
+      if (m->numSpecies > 1 || axisym)
+        throw std::runtime_error("non-reflecting boundary conditions: perfect gas, not axisymmetric");
+      for (int d = 0; d < 3; d++) tangent1[d] = bc.data[4 + d];
+      area_ = bc.data[7];
+      for (int eq = 0; eq < MAXEQ; eq++) meanUp[eq] = 0.0;
+    }
+  }
+
+  // Non-reflecting inlet (src/inletBC.cpp:576-727) and outlets (src/outletBC.cpp:573-728, 739-892, 894-1027):
+  // characteristic estimate of d(U)/dt at the boundary point from the patch mean `meanUp`, the normal gradient
+  // and the target; the boundary state boundaryU[bdrN] is advanced by dt with it; the Riemann solver sees the
+  // state BEFORE the update.
+  void computeNonReflectingFlux(const double *normal, const double *stateIn, const double *gradState, int bdrN,
+                                double *bdrFlux) const {
+    const double gamma = mixture->GetSpecificHeatRatio();
+    const bool inlet = category == TPSRHS_INLET;
+    double unitNorm[3] = {0, 0, 0}, tangent2[3] = {0, 0, 0};
+    {
+      double mod = 0.;
+      for (int d = 0; d < dim; d++) mod += normal[d] * normal[d];
+      for (int d = 0; d < dim; d++) unitNorm[d] = normal[d] * ((inlet ? -1. : 1.) / std::sqrt(mod));  // inlet: into the domain
+    }
+    double meanVel[3] = {0, 0, 0};
+    for (int d = 0; d < dim; d++) {
+      meanVel[0] += unitNorm[d] * meanUp[d + 1];
+      meanVel[1] += tangent1[d] * meanUp[d + 1];
+    }
+    if (dim == 3) {
+      tangent2[0] = unitNorm[1] * tangent1[2] - unitNorm[2] * tangent1[1];
+      tangent2[1] = unitNorm[2] * tangent1[0] - unitNorm[0] * tangent1[2];
+      tangent2[2] = unitNorm[0] * tangent1[1] - unitNorm[1] * tangent1[0];
+      for (int d = 0; d < dim; d++) meanVel[2] += tangent2[d] * meanUp[d + 1];
+    }
+    double normGrad[MAXEQ];
+    for (int eq = 0; eq < num_equation; eq++) {
+      normGrad[eq] = 0.;
+      for (int d = 0; d < dim; d++) normGrad[eq] += unitNorm[d] * gradState[eq + d * num_equation];
+    }
+    // DryAir::ComputePressureDerivative(normGrad, stateIn, false), src/equation_of_state.cpp:350-359
+    const double Rg = mixture->GetGasConstant();
+    const double dpdn = Rg * (mixture->ComputeTemperature(stateIn) * normGrad[0] + stateIn[0] * normGrad[nvel + 1]);
+    const double meanP = Rg * meanUp[0] * meanUp[nvel + 1];                      // ComputePressureFromPrimitives :361
+    const double speedSound = std::sqrt(gamma * Rg * meanUp[nvel + 1]);          // ComputeSpeedOfSound(meanUp) :337-348
+    double meanK = 0.;
+    for (int d = 0; d < dim; d++) meanK += meanUp[1 + d] * meanUp[1 + d];
+    meanK *= 0.5;
+    const double sigma = speedSound / refLength;
+    double L1, L2, L3 = 0., L4 = 0., L5;
+    if (inlet) {  // src/inletBC.cpp:601-648
+      double meanDV[3] = {0, 0, 0};
+      for (int d = 0; d < nvel; d++) meanDV[d] = meanUp[1 + d] - inputState[1 + d];
+      L1 = 0.;
+      for (int d = 0; d < dim; d++) L1 += unitNorm[d] * normGrad[1 + d];
+      L1 = dpdn - meanUp[0] * speedSound * L1;
+      L1 *= meanVel[0] - speedSound;
+      L5 = 0.;
+      for (int d = 0; d < dim; d++) L5 += meanDV[d] * unitNorm[d];
+      L5 *= sigma * 2. * meanUp[0] * speedSound;
+      for (int d = 0; d < dim; d++) L3 += meanDV[d] * tangent1[d];
+      L3 *= sigma;
+      if (dim == 3) {
+        for (int d = 0; d < dim; d++) L4 += meanDV[d] * tangent2[d];
+        L4 *= sigma;
+      }
+      L2 = sigma * speedSound * speedSound * (meanUp[0] - inputState[0]) - 0.5 * L5;
+      if (type == TPSRHS_SUB_VEL_CONST_ENT) L2 = 0.;
+    } else {  // src/outletBC.cpp:617-646, 781-807, 939-968
+      L2 = speedSound * speedSound * normGrad[0] - dpdn;
+      L2 *= meanVel[0];
+      for (int d = 0; d < dim; d++) L3 += tangent1[d] * normGrad[1 + d];
+      L3 *= meanVel[0];
+      if (dim == 3) {
+        for (int d = 0; d < dim; d++) L4 += tangent2[d] * normGrad[1 + d];
+        L4 *= meanVel[0];
+      }
+      L5 = 0.;
+      for (int d = 0; d < dim; d++) L5 += unitNorm[d] * normGrad[1 + d];
+      L5 = dpdn + meanUp[0] * speedSound * L5;
+      L5 *= meanVel[0] + speedSound;
+      if (type == TPSRHS_SUB_P_NR) {
+        L1 = sigma * (meanP - inputState[0]);
+      } else {
+        double vn = meanVel[0];
+        if (type == TPSRHS_SUB_MF_NR_PW) {
+          vn = 0.;
+          for (int d = 0; d < dim; d++) vn += stateIn[1 + d] * unitNorm[d];
+          vn /= stateIn[0];
+        }
+        L1 = -sigma * (vn - inputState[0] / meanUp[0] / area_);
+        L1 *= meanUp[0] * speedSound;
+      }
+    }
+    const double d1 = (L2 + 0.5 * (L5 + L1)) / speedSound / speedSound;
+    const double d2 = 0.5 * (L5 - L1) / meanUp[0] / speedSound;
+    const double d3 = L3, d4 = L4;
+    const double d5 = 0.5 * (L5 + L1);
+    bdrFlux[0] = d1;
+    bdrFlux[1] = meanVel[0] * d1 + meanUp[0] * d2;
+    bdrFlux[2] = meanVel[1] * d1 + meanUp[0] * d3;
+    if (dim == 3) bdrFlux[3] = meanVel[2] * d1 + meanUp[0] * d4;
+    bdrFlux[1 + dim] = meanUp[0] * meanVel[0] * d2;
+    bdrFlux[1 + dim] += meanUp[0] * meanVel[1] * d3;
+    if (dim == 3) bdrFlux[1 + dim] += meanUp[0] * meanVel[2] * d4;
+    bdrFlux[1 + dim] += meanK * d1 + d5 / (gamma - 1.);
+
+    double state2[MAXEQ], stateN[MAXEQ], newU[MAXEQ];
+    for (int eq = 0; eq < num_equation; eq++) state2[eq] = boundaryU[eq + bdrN * num_equation];
+    for (int eq = 0; eq < num_equation; eq++) stateN[eq] = state2[eq];
+    for (int d = 0; d < dim; d++) stateN[1 + d] = 0.;
+    for (int d = 0; d < dim; d++) {
+      stateN[1] += state2[1 + d] * unitNorm[d];
+      stateN[2] += state2[1 + d] * tangent1[d];
+      if (dim == 3) stateN[3] += state2[1 + d] * tangent2[d];
+    }
+    for (int i = 0; i < num_equation; i++) newU[i] = stateN[i] - (*dt) * bdrFlux[i];
+    {  // back to Cartesian momentum: M rows = unitNorm, tangent1, tangent2; momX = M^-1 momN
+      double M[9] = {0}, invM[9];
+      for (int d = 0; d < dim; d++) {  // column-major M(i, d)
+        M[0 + dim * d] = unitNorm[d];
+        M[1 + dim * d] = tangent1[d];
+        if (dim == 3) M[2 + dim * d] = tangent2[d];
+      }
+      if (dim == 2) {
+        const double det = M[0] * M[3] - M[2] * M[1];
+        invM[0] = M[3] / det;
+        invM[1] = -M[1] / det;
+        invM[2] = -M[2] / det;
+        invM[3] = M[0] / det;
+      } else {
+        const double c00 = M[4] * M[8] - M[7] * M[5], c10 = M[7] * M[2] - M[1] * M[8], c20 = M[1] * M[5] - M[4] * M[2];
+        const double det = M[0] * c00 + M[3] * c10 + M[6] * c20;
+        invM[0] = c00 / det;
+        invM[1] = c10 / det;
+        invM[2] = c20 / det;
+        invM[3] = (M[6] * M[5] - M[3] * M[8]) / det;
+        invM[4] = (M[0] * M[8] - M[6] * M[2]) / det;
+        invM[5] = (M[3] * M[2] - M[0] * M[5]) / det;
+        invM[6] = (M[3] * M[7] - M[6] * M[4]) / det;
+        invM[7] = (M[6] * M[1] - M[0] * M[7]) / det;
+        invM[8] = (M[0] * M[4] - M[3] * M[1]) / det;
+      }
+      double momX[3] = {0, 0, 0};
+      for (int i = 0; i < dim; i++)
+        for (int j = 0; j < dim; j++) momX[i] += invM[i + dim * j] * newU[1 + j];
+      for (int d = 0; d < dim; d++) newU[1 + d] = momX[d];
+    }
+    for (int eq = 0; eq < num_equation; eq++) boundaryU[eq + bdrN * num_equation] = newU[eq];
+    rsolver->Eval(stateIn, state2, normal, bdrFlux, true);
   }
 
   // src/wallBC.cpp:241-266 (only the isothermal wall alters the gradient ghost state)
@@ -704,7 +867,12 @@ class BoundaryCondition {
   }
 
   void computeBdrFlux(const double *normal, const double *stateIn, const double *gradState, const double *transip,
-                      double delta, double distance, double *bdrFlux) const {
+                      double delta, double distance, double *bdrFlux, int bdrN = -1) const {
+    if (nonReflecting) {
+      if (bdrN < 0 || !dt) throw std::runtime_error("non-reflecting boundary condition without its boundary state");
+      computeNonReflectingFlux(normal, stateIn, gradState, bdrN, bdrFlux);
+      return;
+    }
     // the reference stores the unit normal in the member bcFlux_ (src/wallBC.cpp:448,492); the
     // oracle's face loop is threaded, so each call works on its own copy
     BoundaryViscousFluxData bcFlux = this->bcFlux;

@@ -326,8 +326,69 @@ struct Operator {
       }
   }
 
+  // BCintegrator::updateBCMean -> InletBC/OutletBC::updateMean (src/outletBC.cpp:470-561, src/inletBC.cpp:482-566):
+  // unweighted mean of the interpolated primitives over the boundary quadrature points of each non-reflecting
+  // patch; on the first call the boundary state is initialised from the same interpolated primitives.
+  double bc_dt = 0.0;
+  std::vector<int> nrFaceOrdinal;  // face -> ordinal among the faces of its (non-reflecting) patch, -1 otherwise
+  void updateBCMean() {
+    const int64_t N = ndofs;
+    const int nf = static_cast<int>(mesh.faces.size());
+    bool any = false;
+    for (auto &kv : bcs) any = any || kv.second->nonReflecting;
+    if (!any) return;
+    if (nrFaceOrdinal.empty()) {
+      nrFaceOrdinal.assign(nf, -1);
+      std::map<int, int> count;
+      for (int f = 0; f < nf; f++) {
+        const Face &F = mesh.faces[f];
+        if (F.e2 < 0 && bcs.at(F.attr)->nonReflecting) nrFaceOrdinal[f] = count[F.attr]++;
+      }
+      for (auto &kv : bcs)
+        if (kv.second->nonReflecting) {
+          kv.second->boundaryU.assign(static_cast<size_t>(count[kv.first]) * faceRule.npts * neq, 0.0);
+          kv.second->dt = &bc_dt;
+          kv.second->refLength = disc.ref_length > 0.0 ? disc.ref_length : 1.0;
+        }
+    }
+    for (auto &kv : bcs) {
+      BoundaryCondition &bc = *kv.second;
+      if (!bc.nonReflecting) continue;
+      double localMeanUp[MAXEQ + 1] = {0};
+      std::vector<double> shape(dof);
+      for (int f = 0; f < nf; f++) {
+        const Face &F = mesh.faces[f];
+        if (F.e2 >= 0 || F.attr != kv.first) continue;
+        for (int q = 0; q < faceRule.npts; q++) {
+          FacePoint fp;
+          facePoint(F, q, fp);
+          fe.calc_shape(fp.xi1, shape.data());
+          const int Nbdr = nrFaceOrdinal[f] * faceRule.npts + q;
+          for (int eq = 0; eq < neq; eq++) {
+            double sum = 0.;
+            for (int k = 0; k < dof; k++) sum += shape[k] * Up[static_cast<int64_t>(F.e1) * dof + k + eq * N];
+            localMeanUp[eq] += sum;
+            if (!bc.bdrUInit) bc.boundaryU[eq + Nbdr * neq] = sum;
+          }
+        }
+      }
+      const double totNbdr = static_cast<double>(bc.boundaryU.size() / neq);
+      for (int eq = 0; eq < neq; eq++) bc.meanUp[eq] = localMeanUp[eq] / totNbdr;  // single rank: no Allreduce
+      if (!bc.bdrUInit) {
+        for (size_t i = 0; i < bc.boundaryU.size() / neq; i++) {
+          double iUp[MAXEQ], iState[MAXEQ];
+          for (int eq = 0; eq < neq; eq++) iUp[eq] = bc.boundaryU[eq + i * neq];
+          mixture->GetConservativesFromPrimitives(iUp, iState);
+          for (int eq = 0; eq < neq; eq++) bc.boundaryU[eq + i * neq] = iState[eq];
+        }
+        bc.bdrUInit = true;
+      }
+    }
+  }
+
   // A->Mult: interior faces (src/face_integrator.cpp:194-352) + boundary (src/BCintegrator.cpp:295-441)
   void faceFluxes(const double *x, double /*time*/) {
+    updateBCMean();  // src/rhs_operator.cpp:364
     const int64_t N = ndofs;
     const int nf = static_cast<int>(mesh.faces.size());
     std::vector<double> fbuf(static_cast<size_t>(nf) * 2 * dof * neq, 0.0);
@@ -376,7 +437,8 @@ struct Operator {
               el1[k + eq * dof] -= shape1[k] * fluxN[eq];
             }
         } else {
-          bcs.at(F.attr)->computeBdrFlux(fp.nor, u1, g1, transip, 0.0, 0.0, fluxN);
+          bcs.at(F.attr)->computeBdrFlux(fp.nor, u1, g1, transip, 0.0, 0.0, fluxN,
+                                         nrFaceOrdinal.empty() || nrFaceOrdinal[f] < 0 ? -1 : nrFaceOrdinal[f] * faceRule.npts + q);
           for (int eq = 0; eq < neq; eq++) fluxN[eq] *= fp.w;
           if (axisym)
             for (int eq = 0; eq < neq; eq++) fluxN[eq] *= transip[0];
@@ -700,6 +762,19 @@ int tpsoracle_destroy(void *h) {
   delete static_cast<Operator *>(h);
   return 0;
 }
+int tpsoracle_set_dt(void *h, double dt) {
+  static_cast<Operator *>(h)->bc_dt = dt;
+  return 0;
+}
+// boundaryU of a non-reflecting patch ([point][eq], points = faces of the patch in mesh order x quadrature
+// points) and its meanUp; returns the number of points
+int tpsoracle_get_boundary_state(void *h, int attr, double *boundaryU, double *meanUp) {
+  Operator *op = static_cast<Operator *>(h);
+  const tpsoracle::BoundaryCondition &bc = *op->bcs.at(attr);
+  if (boundaryU) std::memcpy(boundaryU, bc.boundaryU.data(), bc.boundaryU.size() * sizeof(double));
+  if (meanUp) std::memcpy(meanUp, bc.meanUp, op->neq * sizeof(double));
+  return static_cast<int>(bc.boundaryU.size() / op->neq);
+}
 int tpsoracle_set_forcing(void *h, const tpsrhs_forcing *f) {
   try {
     static_cast<Operator *>(h)->setForcing(f);
@@ -859,6 +934,7 @@ int tpsoracle_rk4_step(void *h, double *x, double *time, double dt, double *max_
   const int64_t n = static_cast<int64_t>(op->neq) * op->ndofs;
   std::vector<double> k(n), y(n), z(n);
   try {
+    op->bc_dt = dt;
     op->mult(x, k.data(), *time);
     for (int64_t i = 0; i < n; i++) {
       y[i] = x[i] + (dt / 2) * k[i];

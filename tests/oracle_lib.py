@@ -39,6 +39,8 @@ def lib():
         L.tpsoracle_get_primitives.argtypes = [vp, _dp]
         L.tpsoracle_get_gradients.argtypes = [vp, _dp]
         L.tpsoracle_node_coords.argtypes = [vp, _dp]
+        L.tpsoracle_set_dt.argtypes = [vp, C.c_double]
+        L.tpsoracle_get_boundary_state.argtypes = [vp, C.c_int, _dp, _dp]
         L.tpsoracle_set_forcing.argtypes = [vp, C.POINTER(capi.Forcing)]
         L.tpsoracle_set_joule_heating.argtypes = [vp, _dp]
         L.tpsoracle_l2_norm.restype = C.c_double
@@ -99,6 +101,17 @@ class Oracle:
         out = np.zeros((self.dim, self.ndofs))
         lib().tpsoracle_node_coords(self.h, _p(out))
         return out
+
+    def boundary_state(self, attr):
+        """(boundaryU [points, neq], meanUp [neq]) of a non-reflecting patch"""
+        n = lib().tpsoracle_get_boundary_state(self.h, int(attr), None, None)
+        bu = np.zeros((n, self.neq))
+        mean = np.zeros(self.neq)
+        lib().tpsoracle_get_boundary_state(self.h, int(attr), _p(bu), _p(mean))
+        return bu, mean
+
+    def set_dt(self, dt):
+        lib().tpsoracle_set_dt(self.h, float(dt))
 
     def set_forcing(self, forcing):
         st = lib().tpsoracle_set_forcing(self.h, C.byref(forcing) if forcing is not None else None)

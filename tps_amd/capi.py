@@ -27,8 +27,8 @@ NONE_RAD, NET_EMISSION = 0, 1
 SPECIES_MW, SPECIES_CHARGES, FORMATION_ENERGY, SPECIES_DEGENERACY = 0, 1, 2, 3
 CLMB_ATT, CLMB_REP, AR_AR1P, AR_E, AR_AR, NONE_ARGCOLL = 0, 1, 2, 3, 4, 5
 INLET, OUTLET, WALL = 0, 1, 2
-SUB_DENS_VEL = 2
-SUB_P = 0
+SUB_DENS_VEL, SUB_DENS_VEL_NR, SUB_VEL_CONST_ENT = 2, 6, 7
+SUB_P, SUB_P_NR, SUB_MF_NR, SUB_MF_NR_PW = 0, 2, 3, 4
 INV, SLIP, VISC_ADIAB, VISC_ISOTH, VISC_GNRL = 0, 1, 2, 3, 4
 ADIAB, ISOTH, SHTH, NONE_THMCND = 0, 1, 2, 3  # ThermalCondition of viscous_general walls
 
@@ -49,7 +49,8 @@ class Mesh(C.Structure):
 
 class Disc(C.Structure):
     _fields_ = [("order", C.c_int), ("basis_type", C.c_int), ("int_rule_type", C.c_int),
-                ("axisymmetric", C.c_int), ("use_bc_in_grad", C.c_int), ("use_roe", C.c_int)]
+                ("axisymmetric", C.c_int), ("use_bc_in_grad", C.c_int), ("use_roe", C.c_int),
+                ("ref_length", C.c_double)]
 
 
 class DryAir(C.Structure):
@@ -112,8 +113,12 @@ HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_
                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
 
 
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+
 class Runtime(C.Structure):
-    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("halo", HALO_FN), ("halo_ctx", C.c_void_p)]
+    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("halo", HALO_FN), ("halo_ctx", C.c_void_p),
+                ("reduce", REDUCE_FN), ("reduce_ctx", C.c_void_p)]
 
 
 MAXHEATSOURCES, MAXSPONGEZONES = 4, 2
@@ -426,6 +431,7 @@ def load():
     lib.tpsrhs_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_kernel_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_rk4_step.argtypes = [vp, C.c_void_p, _dp, C.c_double, _dp, C.POINTER(C.c_int64)]
+    lib.tpsrhs_set_dt.argtypes = [vp, C.c_double]
     lib.tpsrhs_set_forcing.argtypes = [vp, C.POINTER(Forcing)]
     lib.tpsrhs_set_joule_heating.argtypes = [vp, C.c_void_p]
     lib.tpsrhs_face_tables.restype = C.c_int
@@ -442,7 +448,7 @@ EXPORTED_SYMBOLS = [
     "tpsrhs_create", "tpsrhs_destroy", "tpsrhs_mult", "tpsrhs_mult_host", "tpsrhs_update_gradients",
     "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
     "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_kernel_bytes", "tpsrhs_face_tables",
-    "tpsrhs_rk4_step", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_status_string",
+    "tpsrhs_rk4_step", "tpsrhs_set_dt", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_status_string",
     "tpsrhs_last_error", "tpsrhs_version",
 ]
 

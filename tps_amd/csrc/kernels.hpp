@@ -1116,6 +1116,139 @@ __device__ inline void apply_forcing(const ForcingDev &f, const typename PH::Par
   }
 }
 
+// =============================================================================================
+// Non-reflecting inlet / outlet conditions (src/inletBC.cpp:576-727,
+// src/outletBC.cpp:573-1027).  They carry a boundary state per face quadrature point that every Mult
+// advances by dt, and they need the patch mean of the primitives (BCintegrator::updateBCMean,
+// src/rhs_operator.cpp:364).  Two small kernels over the faces of such patches only:
+//   k_bc_mean  after k_traces:   sums of the interpolated Up over the boundary quadrature points
+//   k_bc_nr    after k_gradient: the characteristic update old state -> new state of every point
+// k_flux reads the OLD state as the ghost of the Riemann solver (as the reference does: the update and the
+// flux of one point use the state before the update); the host swaps the two buffers after the Mult.
+// =============================================================================================
+template <class C, class PH>
+__device__ inline const double *nr_state(const typename PH::Params &prm, int nb, int slot, int q) {
+  if constexpr (PH::HAS_NR_BC) {
+    const auto &bc = prm.bc[-nb - 1];
+    if (is_non_reflecting(bc.category, bc.type))
+      return prm.bstate + (static_cast<int64_t>(prm.nr_ordinal[slot]) * C::NQ + q) * PH::NEQ;
+  }
+  return nullptr;
+}
+
+// sums[b][0..NEQ-1] = sum over the faces of patch b and their quadrature points of the interpolated Up,
+// sums[b][NEQ] = number of points (src/outletBC.cpp:485-531).  The interpolation is linear, so the sum over the
+// points of a face is a weighted sum of its face-node traces (already in TA): weight = product of the column
+// sums of the 1-D node -> quadrature matrix.  One block per boundary condition, fixed summation order.
+template <class C, class PH>
+__global__ __launch_bounds__(256) void k_bc_mean(int nfaces, const int2 *__restrict__ faces,
+                                                 const double *__restrict__ TA, double *__restrict__ sums) {
+  constexpr int NEQ = PH::NEQ;
+  const Tables1D &ct = c_tab[C::DIM - 2][C::P];
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double cw[C::N1];
+#pragma unroll
+  for (int a = 0; a < C::N1; a++) {
+    double c = 0.0;
+#pragma unroll
+    for (int q = 0; q < C::Q1; q++) c += ct.B[q * C::N1 + a];
+    cw[a] = c;
+  }
+  double acc[NEQ + 1];
+#pragma unroll
+  for (int k = 0; k <= NEQ; k++) acc[k] = 0.0;
+  for (int i = tid; i < nfaces; i += 256) {
+    if (faces[i].y != b) continue;
+    const double *rec = TA + static_cast<int64_t>(faces[i].x) * (2 * NEQ * C::NF) + NEQ * C::NF;  // Up traces
+    for (int fn = 0; fn < C::NF; fn++) {
+      double w = 0.0;
+#pragma unroll
+      for (int a = 0; a < C::N1; a++)
+#pragma unroll
+        for (int bb = 0; bb < (C::DIM == 3 ? C::N1 : 1); bb++)
+          if (fn == a + C::N1 * bb) w = cw[a] * (C::DIM == 3 ? cw[bb] : 1.0);
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) acc[eq] += w * rec[eq * C::NF + fn];
+    }
+    acc[NEQ] += C::NQ;
+  }
+  for (int k = 0; k <= NEQ; k++) {
+    red[tid] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off) red[tid] += red[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) sums[b * (TPSRHS_MAXEQUATIONS + 1) + k] = red[0];
+    __syncthreads();
+  }
+}
+
+// One block per face of a non-reflecting patch, one lane per face quadrature point.
+template <class C, class PH>
+__global__ __launch_bounds__(64) void k_bc_nr(MeshDev m, typename PH::Params prm, const int2 *__restrict__ faces,
+                                              const double *__restrict__ sums, const double *__restrict__ U,
+                                              const double *__restrict__ Up, const double *__restrict__ gradUp,
+                                              double *__restrict__ state_old, double *__restrict__ state_new, int first) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  static_assert(C::NQ <= 64, "one lane per face quadrature point");
+  const Tables1D &ct = c_tab[DIM - 2][C::P];
+  __shared__ Tab<C> tab;
+  load_tables<C>(tab, ct);
+  __syncthreads();
+  const int q = threadIdx.x;
+  if (q >= C::NQ) return;
+  const int slot = faces[blockIdx.x].x, b = faces[blockIdx.x].y;
+  const int e = slot / C::NFACES, lf = slot - e * C::NFACES, D = lf >> 1, s = lf & 1;
+  const int da = (DIM == 2) ? 1 - D : (D == 0 ? 1 : 0), db = (D == 2) ? 1 : 2;
+  int str[3] = {1, C::N1, C::N1 * C::N1};
+  const int sd = str[D], sa = str[da], sb = (DIM == 3) ? str[db] : 0;
+  const int qa = (DIM == 3) ? q % C::Q1 : q, qb = (DIM == 3) ? q / C::Q1 : 0;
+  double Uq[NEQ], Upq[NEQ], g[NEQ * DIM];
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) Uq[eq] = Upq[eq] = 0.0;
+#pragma unroll
+  for (int k = 0; k < NEQ * DIM; k++) g[k] = 0.0;
+  const int64_t n0 = static_cast<int64_t>(e) * C::NPE;
+  for (int jd = 0; jd < C::N1; jd++) {
+    const double wd = s ? tab.b1[jd] : tab.b0[jd];
+    for (int jb = 0; jb < (DIM == 3 ? C::N1 : 1); jb++) {
+      const double wb = (DIM == 3) ? tab.B[qb * C::N1 + jb] : 1.0;
+      for (int ja = 0; ja < C::N1; ja++) {
+        const double w = wd * wb * tab.B[qa * C::N1 + ja];
+        const int64_t n = n0 + jd * sd + ja * sa + jb * sb;
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) {
+          Uq[eq] += w * field_ptr(U, eq, m.ndofs)[n];
+          if (first) Upq[eq] += w * field_ptr(Up, eq, m.ndofs)[n];
+        }
+#pragma unroll
+        for (int k = 0; k < NEQ * DIM; k++) g[k] += w * field_ptr(gradUp, k, m.ndofs)[n];
+      }
+    }
+  }
+  double nrm[DIM], wq, Xq[DIM];
+  face_geometry_rt<C>(D, m.verts + static_cast<int64_t>(e) * C::NV * DIM, tab, s, q, nrm, wq, Xq);
+  const double *sm = sums + b * (TPSRHS_MAXEQUATIONS + 1);
+  double meanUp[NEQ];
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) meanUp[eq] = sm[eq] / sm[NEQ];
+  const int64_t rec = (static_cast<int64_t>(blockIdx.x) * C::NQ + q) * NEQ;
+  double s2[NEQ], newU[NEQ];
+  if (first) {  // initBoundaryU / first updateMean: cons(interpolated Up), src/outletBC.cpp:420-468,541-560
+    PH::cons(prm, Upq, s2);
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) state_old[rec + eq] = s2[eq];
+  } else {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) s2[eq] = state_old[rec + eq];
+  }
+  PH::nr_update(prm, prm.bc[b], meanUp, nrm, Uq, g, s2, newU);
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) state_new[rec + eq] = newU[eq];
+}
+
 // y += optional forcing terms: a streaming pass of its own (one lane per node), launched after k_flux
 // only when such a term is configured -- the hot sweeps carry neither its registers nor a branch.
 template <class C, class PH>
@@ -1209,7 +1342,7 @@ __device__ inline void face_flux_dir(const MeshDev &m, const typename PH::Params
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] -= 0.5 * (tb.own[rd][eq] - tb.nbv[rd][eq]);
     } else {
       double ug[NEQ];
-      PH::bc_ghost(prm, prm.bc[-nb - 1], u1, n, ug);
+      PH::bc_ghost(prm, prm.bc[-nb - 1], u1, n, ug, nr_state<C, PH>(prm, nb, (e0 + le) * C::NFACES + 2 * D + s, q));
       PH::riemann_bc(prm, prm.bc[-nb - 1], u1, ug, n, fh[rd]);
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] += tb.own[rd][eq];
@@ -1323,7 +1456,7 @@ __device__ inline void face_flux_2d(const MeshDev &m, const typename PH::Params 
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] -= 0.5 * (tb.own[rd][eq] - tb.nbv[rd][eq]);
     } else {
       double ug[NEQ];
-      PH::bc_ghost(prm, prm.bc[-nb - 1], u1, n, ug);
+      PH::bc_ghost(prm, prm.bc[-nb - 1], u1, n, ug, nr_state<C, PH>(prm, nb, (e0 + le) * C::NFACES + 2 * d + s, q));
       PH::riemann_bc(prm, prm.bc[-nb - 1], u1, ug, n, fh[rd]);
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fh[rd][eq] += tb.own[rd][eq];

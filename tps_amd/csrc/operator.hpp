@@ -77,6 +77,18 @@ struct tpsrhs_operator {
   ForcingDev forcing = {};                  // host copy of the optional forcing terms (tpsrhs_set_forcing / _joule_heating)
   ForcingDev *d_forcing = nullptr;
   bool forcing_active = false;
+  // non-reflecting inlet / outlet patches (dry air): their faces {slot, bc index}, slot -> ordinal, the
+  // double-buffered boundary state, the patch sums of the primitives, the time step they integrate with
+  int n_nr_faces = 0;
+  int2 *d_nr_faces = nullptr;
+  int *d_nr_ordinal = nullptr;
+  double *d_bstate[2] = {nullptr, nullptr};
+  int bstate_cur = 0;
+  bool bstate_init = false;
+  double *d_bc_sums = nullptr;
+  double nr_dt = 0.0;
+  tpsrhs_reduce_fn reduce = nullptr;
+  void *reduce_ctx = nullptr;
   // halo
   tpsrhs_halo_fn halo = nullptr;
   void *halo_ctx = nullptr;
@@ -119,6 +131,9 @@ struct tpsrhs_operator {
     if (d_rk) (void)hipFree(d_rk);
     if (d_nan) (void)hipFree(d_nan);
     if (d_forcing) (void)hipFree(d_forcing);
+    for (void *p : {static_cast<void *>(d_nr_faces), static_cast<void *>(d_nr_ordinal), static_cast<void *>(d_bstate[0]),
+                    static_cast<void *>(d_bstate[1]), static_cast<void *>(d_bc_sums)})
+      if (p) (void)hipFree(p);
     if (d_blocks_halo) (void)hipFree(d_blocks_halo);
     if (d_blocks_interior) (void)hipFree(d_blocks_interior);
     for (auto &e : ev_halo)
@@ -159,6 +174,12 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
   const typename PH::Params &prm = *reinterpret_cast<const typename PH::Params *>(op->params);
   const int nblocks = (op->ne + C::EPB - 1) / C::EPB;
   hipStream_t s = op->stream;
+  if constexpr (PH::HAS_NR_BC) {  // this Mult's view of the non-reflecting boundary state
+    typename PH::Params &w = *reinterpret_cast<typename PH::Params *>(op->params);
+    w.bstate = op->d_bstate[op->bstate_cur];
+    w.nr_ordinal = op->d_nr_ordinal;
+    w.nr_dt = op->nr_dt;
+  }
   if (!op->d_block_speed && !gradients_only) {
     op->d_block_speed = dev_alloc<double>(nblocks);
     op->flux_grid = nblocks;
@@ -176,6 +197,29 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_gradUp, op->d_TA, op->d_TB, y,
                        op->d_block_speed);
     HIP_CHECK(hipGetLastError());
+  };
+  // non-reflecting patches: mean of the primitives (+ sum over the ranks), then the boundary-state update;
+  // after the last k_gradient launch, before the first k_flux launch
+  auto nr_update = [&](const MeshDev &m) {
+    if constexpr (PH::HAS_NR_BC) {
+      if (op->n_nr_faces == 0 && !op->reduce) return;
+      const int nbc = prm.num_bcs;
+      if (op->n_nr_faces > 0 || op->reduce) {
+        hipLaunchKernelGGL((k_bc_mean<C, PH>), dim3(nbc), dim3(256), 0, s, op->n_nr_faces, op->d_nr_faces, op->d_TA,
+                           op->d_bc_sums);
+        HIP_CHECK(hipGetLastError());
+      }
+      if (op->reduce) {
+        const int st = op->reduce(op->reduce_ctx, op->d_bc_sums, nbc * (TPSRHS_MAXEQUATIONS + 1), s);
+        if (st != 0) throw std::runtime_error("halo: reduce callback failed");
+      }
+      if (op->n_nr_faces > 0) {
+        hipLaunchKernelGGL((k_bc_nr<C, PH>), dim3(op->n_nr_faces), dim3(64), 0, s, m, prm, op->d_nr_faces, op->d_bc_sums, x,
+                           op->d_Up, op->d_gradUp, op->d_bstate[op->bstate_cur], op->d_bstate[1 - op->bstate_cur],
+                           op->bstate_init ? 0 : 1);
+        HIP_CHECK(hipGetLastError());
+      }
+    }
   };
   // ConstantPressureGradient / SpongeZone / HeatSource / JouleHeating, after the last k_flux launch
   auto forcing = [&](const MeshDev &m) {
@@ -195,6 +239,7 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     gradient(all, nblocks);
     if (op->timing) HIP_CHECK(hipEventRecord(op->ev[2], s));
     if (gradients_only) return;
+    nr_update(all);
     flux(all, nblocks);
   } else {
     // Partitioned mesh.  Blocks that touch a shared face ("halo blocks") run first in the producing
@@ -233,6 +278,7 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     if (op->timing) HIP_CHECK(hipEventRecord(op->ev[2], s));
     if (gradients_only) return;
     HIP_CHECK(hipEventRecord(op->ev_halo[2], s));
+    nr_update(all);
     if (ni) flux(mi, ni);
     HIP_CHECK(hipStreamWaitEvent(c, op->ev_halo[2], 0));
     exchange(op, 1, op->d_TB, PH::NEQ - 1, C::NQ, c);  // overlaps the interior flux launch
@@ -241,6 +287,12 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     flux(mh, nh);
   }
   forcing(all);
+  if constexpr (PH::HAS_NR_BC) {
+    if (op->n_nr_faces > 0) {  // the updated states are what the next Mult's Riemann solver sees
+      op->bstate_cur = 1 - op->bstate_cur;
+      op->bstate_init = true;
+    }
+  }
   if (op->timing) {
     HIP_CHECK(hipEventRecord(op->ev[3], s));
     op->sets_recorded++;

@@ -59,10 +59,22 @@ struct DryAirParams {
   int use_bc_in_grad;
   int num_bcs;
   int use_roe;  // flow/useRoe: Roe flux on interior faces and inviscid walls (2-D only)
+  // non-reflecting inlet / outlet types: time step of the boundary-state update, relaxation length, and the
+  // boundary states the Riemann solver sees in this Mult ([face ordinal][q][eq]; swapped by the host)
+  double nr_dt, ref_length;
+  const double *bstate;
+  const int *nr_ordinal;  // [face slot] -> ordinal among the faces of non-reflecting patches
   BcDev bc[MAXBC];
 };
 
-template <int DIM_>
+__host__ __device__ inline bool is_non_reflecting(int category, int type) {
+  return (category == TPSRHS_INLET && (type == TPSRHS_SUB_DENS_VEL_NR || type == TPSRHS_SUB_VEL_CONST_ENT)) ||
+         (category == TPSRHS_OUTLET && (type == TPSRHS_SUB_P_NR || type == TPSRHS_SUB_MF_NR || type == TPSRHS_SUB_MF_NR_PW));
+}
+
+// NR_: instantiate the non-reflecting inlet / outlet types.  A flavour of its own, picked only when such a
+// patch exists: the extra ghost-state path costs the hot k_flux registers (measured +5 % at cfg2).
+template <int DIM_, bool NR_ = false>
 struct DryAirPhys {
   static constexpr int DIM = DIM_;
   static constexpr int NVEL = DIM_;
@@ -70,6 +82,7 @@ struct DryAirPhys {
   static constexpr int NACTIVE = 0;
   static constexpr bool HAS_SOURCE = false;
   static constexpr bool TWO_TEMPERATURE = false;
+  static constexpr bool HAS_NR_BC = NR_;  // non-reflecting inlet / outlet types (perfect gas only, as in the reference)
   static constexpr bool AXISYM = false;
   static constexpr bool VISC_USES_GRAD_RHO = false;  // Newtonian stress + Fourier flux: grad u and grad T only
   static constexpr bool HEAVY = false;  // light point physics: inlined at every face pass
@@ -365,13 +378,173 @@ struct DryAirPhys {
     Fn[1 + NVEL] = e;
   }
 
+  // ---- non-reflecting inlet (src/inletBC.cpp:576-727) and outlets (src/outletBC.cpp:573-728, 739-892,
+  // 894-1027): characteristic estimate of dU/dt at a boundary point from the patch mean of the primitives, the
+  // normal gradient and the target; `state2` (the boundary state the Riemann solver sees) advanced by dt -> newU.
+  __device__ static inline void nr_update(const Params &p, const BcDev &bc, const double *meanUp, const double *n,
+                                          const double *U, const double *g, const double *state2, double *newU) {
+    const bool inlet = bc.category == TPSRHS_INLET;
+    double un[DIM], t1[DIM], t2[3] = {0.0, 0.0, 0.0};
+    {
+      double mod = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) mod += n[d] * n[d];
+      const double sc = (inlet ? -1.0 : 1.0) / sqrt(mod);  // inlet: pointing into the domain
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        un[d] = n[d] * sc;
+        t1[d] = bc.data[4 + d];
+      }
+    }
+    double meanVel[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      meanVel[0] += un[d] * meanUp[d + 1];
+      meanVel[1] += t1[d] * meanUp[d + 1];
+    }
+    if constexpr (DIM == 3) {
+      t2[0] = un[1] * t1[2] - un[2] * t1[1];
+      t2[1] = un[2] * t1[0] - un[0] * t1[2];
+      t2[2] = un[0] * t1[1] - un[1] * t1[0];
+#pragma unroll
+      for (int d = 0; d < 3; d++) meanVel[2] += t2[d] * meanUp[d + 1];
+    }
+    double ng[NEQ];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) {
+      ng[eq] = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) ng[eq] += un[d] * g[eq + d * NEQ];
+    }
+    const State s = make_state(p, U);
+    const double T = s.p * p.inv_Rg * s.ir;
+    const double dpdn = p.Rg * (T * ng[0] + U[0] * ng[NVEL + 1]);  // ComputePressureDerivative, equation_of_state.cpp:350-359
+    const double meanP = p.Rg * meanUp[0] * meanUp[NVEL + 1];
+    const double c = sqrt(p.gamma * p.Rg * meanUp[NVEL + 1]);
+    double meanK = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) meanK += meanUp[1 + d] * meanUp[1 + d];
+    meanK *= 0.5;
+    const double sigma = c / p.ref_length;
+    double L1, L2, L3 = 0.0, L4 = 0.0, L5;
+    if (inlet) {
+      double dv[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) dv[d] = meanUp[1 + d] - bc.data[1 + d];
+      L1 = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) L1 += un[d] * ng[1 + d];
+      L1 = dpdn - meanUp[0] * c * L1;
+      L1 *= meanVel[0] - c;
+      L5 = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) L5 += dv[d] * un[d];
+      L5 *= sigma * 2.0 * meanUp[0] * c;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) L3 += dv[d] * t1[d];
+      L3 *= sigma;
+      if constexpr (DIM == 3) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) L4 += dv[d] * t2[d];
+        L4 *= sigma;
+      }
+      L2 = sigma * c * c * (meanUp[0] - bc.data[0]) - 0.5 * L5;
+      if (bc.type == TPSRHS_SUB_VEL_CONST_ENT) L2 = 0.0;
+    } else {
+      L2 = (c * c * ng[0] - dpdn) * meanVel[0];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) L3 += t1[d] * ng[1 + d];
+      L3 *= meanVel[0];
+      if constexpr (DIM == 3) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) L4 += t2[d] * ng[1 + d];
+        L4 *= meanVel[0];
+      }
+      L5 = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) L5 += un[d] * ng[1 + d];
+      L5 = dpdn + meanUp[0] * c * L5;
+      L5 *= meanVel[0] + c;
+      if (bc.type == TPSRHS_SUB_P_NR) {
+        L1 = sigma * (meanP - bc.data[0]);
+      } else {
+        double vn = meanVel[0];
+        if (bc.type == TPSRHS_SUB_MF_NR_PW) {
+          vn = 0.0;
+#pragma unroll
+          for (int d = 0; d < DIM; d++) vn += U[1 + d] * un[d];
+          vn /= U[0];
+        }
+        L1 = -sigma * (vn - bc.data[0] / meanUp[0] / bc.data[7]);
+        L1 *= meanUp[0] * c;
+      }
+    }
+    const double d1 = (L2 + 0.5 * (L5 + L1)) / c / c;
+    const double d2 = 0.5 * (L5 - L1) / meanUp[0] / c;
+    const double d5 = 0.5 * (L5 + L1);
+    double f[NEQ];
+    f[0] = d1;
+    f[1] = meanVel[0] * d1 + meanUp[0] * d2;
+    f[2] = meanVel[1] * d1 + meanUp[0] * L3;
+    if constexpr (DIM == 3) f[3] = meanVel[2] * d1 + meanUp[0] * L4;
+    f[1 + DIM] = meanUp[0] * meanVel[0] * d2;
+    f[1 + DIM] += meanUp[0] * meanVel[1] * L3;
+    if constexpr (DIM == 3) f[1 + DIM] += meanUp[0] * meanVel[2] * L4;
+    f[1 + DIM] += meanK * d1 + d5 / (p.gamma - 1.0);
+    // boundary state in the (normal, tangent) frame, advanced, and back: momX = M^-1 momN, rows of M = un, t1, t2
+    double sn[NEQ];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) sn[eq] = state2[eq];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) sn[1 + d] = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      sn[1] += state2[1 + d] * un[d];
+      sn[2] += state2[1 + d] * t1[d];
+      if constexpr (DIM == 3) sn[3] += state2[1 + d] * t2[d];
+    }
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) newU[eq] = sn[eq] - p.nr_dt * f[eq];
+    if constexpr (DIM == 2) {
+      const double det = un[0] * t1[1] - un[1] * t1[0];
+      const double m0 = newU[1], m1 = newU[2];
+      newU[1] = (t1[1] * m0 - un[1] * m1) / det;
+      newU[2] = (-t1[0] * m0 + un[0] * m1) / det;
+    } else {
+      const double M[9] = {un[0], un[1], un[2], t1[0], t1[1], t1[2], t2[0], t2[1], t2[2]};  // row-major
+      const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+      const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+      const double inv[9] = {c00, M[2] * M[7] - M[1] * M[8], M[1] * M[5] - M[2] * M[4],
+                             c01, M[0] * M[8] - M[2] * M[6], M[2] * M[3] - M[0] * M[5],
+                             c02, M[1] * M[6] - M[0] * M[7], M[0] * M[4] - M[1] * M[3]};
+      const double m0 = newU[1], m1 = newU[2], m2 = newU[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) newU[1 + i] = (inv[3 * i] * m0 + inv[3 * i + 1] * m1 + inv[3 * i + 2] * m2) / det;
+    }
+  }
+  // GetConservativesFromPrimitives, src/equation_of_state.cpp:294-319 (initial boundary state)
+  __device__ static inline void cons(const Params &p, const double *Up, double *U) {
+    U[0] = Up[0];
+    double k = 0.0;
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) {
+      U[1 + d] = Up[0] * Up[1 + d];
+      k += Up[1 + d] * Up[1 + d];
+    }
+    U[1 + NVEL] = p.Rg * Up[0] * Up[1 + NVEL] / (p.gamma - 1.0) + 0.5 * Up[0] * k;
+  }
+
   // ---- boundary conditions ------------------------------------------------------------------
   // ghost (second) state handed to the Riemann solver
+  // (`bs`: this face point's record of the non-reflecting boundary state, or NULL)
   __device__ static inline void bc_ghost(const Params &p, const BcDev &bc, const double *U, const double *n,
-                                         double *Ug) {
+                                         double *Ug, const double *bs = nullptr) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) Ug[eq] = U[eq];
-    if (bc.category == TPSRHS_INLET) {  // SUB_DENS_VEL, src/inletBC.cpp:729-757
+    if (NR_ && is_non_reflecting(bc.category, bc.type)) {  // state2 = boundaryU[bdrN], src/outletBC.cpp:693-727
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) Ug[eq] = bs[eq];
+    } else if (bc.category == TPSRHS_INLET) {  // SUB_DENS_VEL, src/inletBC.cpp:729-757
       const double pres = pressure(p, U);
       Ug[0] = bc.data[0];
       double k = 0.0;

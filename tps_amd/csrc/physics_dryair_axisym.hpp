@@ -16,7 +16,7 @@ namespace tpsrhs {
 
 struct DryAirAxiPhys {
   static constexpr int DIM = 2, NVEL = 3, NEQ = 5, NACTIVE = 0, ITH = 4;
-  static constexpr bool HAS_SOURCE = true, AXISYM = true, HEAVY = true, TWO_TEMPERATURE = false;
+  static constexpr bool HAS_SOURCE = true, AXISYM = true, HEAVY = true, TWO_TEMPERATURE = false, HAS_NR_BC = false;
   static constexpr bool VISC_USES_GRAD_RHO = false;
   static constexpr int MINW_GRAD = 1, MINW_FLUX = 2;
   typedef DryAirParams Params;
@@ -139,7 +139,7 @@ struct DryAirAxiPhys {
     }
   }
   __device__ static inline void bc_ghost(const Params &p, const BcDev &bc, const double *U, const double *n,
-                                         double *Ug) {
+                                         double *Ug, const double * = nullptr) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) Ug[eq] = U[eq];
     const State s = make_state(p, U);

@@ -167,6 +167,7 @@ struct PlasmaPhys {
   static constexpr int ITH = NVEL_ + 1, ITE = NEQ - 1;
   static constexpr bool HAS_SOURCE = true;
   static constexpr bool TWO_TEMPERATURE = TWOT;
+  static constexpr bool HAS_NR_BC = false;  // the reference's non-reflecting conditions are perfect-gas algebra
   static constexpr bool VISC_USES_GRAD_RHO = true;  // mole-fraction gradients need grad(rho)
   static constexpr bool AXISYM = NVEL_ > DIM_;  // dim 2 with (r, z, theta) velocity components
   static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : 2, MINW_FLUX = 2;  // waves per SIMD asked of the allocator
@@ -954,7 +955,7 @@ struct PlasmaPhys {
     Uo[ITH] = rE;
   }
   __device__ static inline void bc_ghost(const Params &p, const BcDev &bc, const double *U, const double *n,
-                                         double *Ug) {
+                                         double *Ug, const double * = nullptr) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) Ug[eq] = U[eq];
     if (bc.category == TPSRHS_INLET) {  // src/inletBC.cpp:729-757

@@ -170,7 +170,13 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   if (num_bcs > (plasma ? PLASMA_MAXBC : MAXBC)) throw Unsupported("too many boundary conditions");
   for (int i = 0; i < num_bcs; i++) {
     const tpsrhs_bc &b = bcs[i];
-    const bool ok = (b.category == TPSRHS_INLET && b.type == TPSRHS_SUB_DENS_VEL) ||
+    const bool nr = is_non_reflecting(b.category, b.type);
+    if (nr && (plasma || disc->axisymmetric))
+      throw Unsupported("non-reflecting inlet/outlet types: perfect gas (dry air), not axisymmetric -- the reference's "
+                        "characteristic algebra (src/outletBC.cpp:573-1027)");
+    if (nr && (b.type == TPSRHS_SUB_MF_NR || b.type == TPSRHS_SUB_MF_NR_PW) && !(b.data[7] > 0.0))
+      throw std::invalid_argument("mass-flow outlet: data[7] must hold the total patch area");
+    const bool ok = nr || (b.category == TPSRHS_INLET && b.type == TPSRHS_SUB_DENS_VEL) ||
                     (b.category == TPSRHS_OUTLET && b.type == TPSRHS_SUB_P) ||
                     (b.category == TPSRHS_WALL &&
                      (b.type == TPSRHS_INV || b.type == TPSRHS_VISC_ADIAB || b.type == TPSRHS_VISC_ISOTH ||
@@ -221,6 +227,8 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   op->stream = rt ? static_cast<hipStream_t>(rt->stream) : nullptr;
   op->halo = rt ? rt->halo : nullptr;
   op->halo_ctx = rt ? rt->halo_ctx : nullptr;
+  op->reduce = rt ? rt->reduce : nullptr;
+  op->reduce_ctx = rt ? rt->reduce_ctx : nullptr;
 
   op->topo = build_topology(*mesh, num_bcs, bcs);
   const Topology &tp = op->topo;
@@ -264,18 +272,21 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     d.eq_system = phys->eq_system;
     d.use_bc_in_grad = disc->use_bc_in_grad;
     d.use_roe = disc->use_roe ? 1 : 0;
+    d.ref_length = disc->ref_length > 0.0 ? disc->ref_length : 1.0;  // config.refLength default, run_configuration.cpp:66
     d.num_bcs = num_bcs;
     for (int i = 0; i < num_bcs; i++) {
       d.bc[i].category = bcs[i].category;
       d.bc[i].type = bcs[i].type;
       for (int k = 0; k < 4 + TPSRHS_MAXSPECIES; k++) d.bc[i].data[k] = bcs[i].data[k];
     }
-    if (op->dim == 3)
-      pick_order<3, DryAirPhys<3>>(op);
-    else if (disc->axisymmetric)
+    bool any_nr = false;
+    for (int i = 0; i < num_bcs; i++) any_nr = any_nr || is_non_reflecting(bcs[i].category, bcs[i].type);
+    if (disc->axisymmetric)
       pick_dryair_axisym(op);
+    else if (op->dim == 3)
+      any_nr ? pick_order<3, DryAirPhys<3, true>>(op) : pick_order<3, DryAirPhys<3>>(op);
     else
-      pick_order<2, DryAirPhys<2>>(op);
+      any_nr ? pick_order<2, DryAirPhys<2, true>>(op) : pick_order<2, DryAirPhys<2>>(op);
   }
 
   op->d_verts = dev_upload(tp.verts);
@@ -283,6 +294,56 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     std::vector<int2> fi(tp.face_nbr.size());
     for (size_t i = 0; i < fi.size(); i++) fi[i] = make_int2(tp.face_nbr[i], tp.face_orient[i]);
     op->d_face_info = dev_upload(fi);
+  }
+  if (!plasma && !disc->axisymmetric) {  // faces of the non-reflecting patches, in slot order
+    std::vector<int2> nrf;
+    std::vector<int> ordinal(tp.face_nbr.size(), -1);
+    bool any_nr = false;
+    for (int i = 0; i < num_bcs; i++) any_nr = any_nr || is_non_reflecting(bcs[i].category, bcs[i].type);
+    if (any_nr) {
+      DryAirParams &d = *reinterpret_cast<DryAirParams *>(op->params);
+      for (size_t slot = 0; slot < tp.face_nbr.size(); slot++) {
+        const int nb = tp.face_nbr[slot];
+        if (nb >= 0) continue;
+        const int b = -nb - 1;
+        if (!is_non_reflecting(bcs[b].category, bcs[b].type)) continue;
+        ordinal[slot] = static_cast<int>(nrf.size());
+        nrf.push_back(make_int2(static_cast<int>(slot), b));
+        // tangent1 of the patch: the caller's (the reference takes it from its first boundary face,
+        // src/outletBC.cpp:160-172) or an edge of our first face of the patch, orthogonalised to nothing --
+        // as there, the patch is assumed planar
+        double *t1 = &d.bc[b].data[4];
+        if (t1[0] == 0.0 && t1[1] == 0.0 && t1[2] == 0.0) {
+          const int e = static_cast<int>(slot) / op->nfaces, lf = static_cast<int>(slot) % op->nfaces, D = lf >> 1, sd = lf & 1;
+          const int nv = 1 << op->dim, a = (op->dim == 2) ? 1 - D : (D == 0 ? 1 : 0);
+          const int c0 = sd << D, c1 = c0 | (1 << a);
+          double mod = 0.0, t[3] = {0, 0, 0};
+          for (int k = 0; k < op->dim; k++) {
+            t[k] = tp.verts[(static_cast<size_t>(e) * nv + c1) * op->dim + k] - tp.verts[(static_cast<size_t>(e) * nv + c0) * op->dim + k];
+            mod += t[k] * t[k];
+          }
+          for (int k = 0; k < 3; k++) t1[k] = t[k] / std::sqrt(mod);
+        }
+      }
+      if (tp.num_shared > 0 && !op->reduce)
+        throw std::runtime_error("halo: a partitioned mesh with non-reflecting patches needs runtime.reduce");
+      op->n_nr_faces = static_cast<int>(nrf.size());
+      op->d_bc_sums = dev_alloc<double>(MAXBC * (TPSRHS_MAXEQUATIONS + 1));
+      HIP_CHECK(hipMemset(op->d_bc_sums, 0, MAXBC * (TPSRHS_MAXEQUATIONS + 1) * sizeof(double)));
+      if (!nrf.empty()) {
+        op->d_nr_faces = dev_upload(nrf);
+        op->d_nr_ordinal = dev_upload(ordinal);
+        const size_t n = nrf.size() * static_cast<size_t>(op->nq) * op->neq;
+        for (int k = 0; k < 2; k++) {
+          op->d_bstate[k] = dev_alloc<double>(n);
+          HIP_CHECK(hipMemset(op->d_bstate[k], 0, n * sizeof(double)));
+        }
+      }
+    } else {
+      op->reduce = nullptr;  // nothing to sum
+    }
+  } else {
+    op->reduce = nullptr;
   }
   if (op->ndofs >= (int64_t(1) << 31)) throw Unsupported("more than 2^31 nodes per rank");
   const int64_t nslots = static_cast<int64_t>(op->ne) * op->nfaces + tp.num_shared;
@@ -400,6 +461,7 @@ int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double 
       h->d_nan = dev_alloc<unsigned long long>(1);
     }
     double *k = h->d_rk, *y = k + n, *z = y + n;
+    h->nr_dt = dt;  // the boundary conditions see M2ulPhyS::dt (src/BoundaryCondition.hpp:54)
     HIP_CHECK(hipMemsetAsync(h->d_nan, 0, sizeof(unsigned long long), h->stream));
     const bool mixture = h->phys.working_fluid == TPSRHS_USER_DEFINED;
     const int sp_first = h->nvel + 2;
@@ -428,6 +490,12 @@ int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double 
       if (nan_count) *nan_count = static_cast<int64_t>(bad);
     }
   });
+}
+
+int tpsrhs_set_dt(tpsrhs_handle h, double dt) {
+  if (!h) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_set_dt: NULL handle");
+  h->nr_dt = dt;
+  return TPSRHS_OK;
 }
 
 namespace {

@@ -75,6 +75,30 @@ class HaloExchange:
             self.error = exc
             return 1
 
+    def reduce_callback(self, ctx, values, count, stream):
+        """``tpsrhs_reduce_fn``: in-place sum over the ranks of ``count`` device doubles (boundary means of the
+        non-reflecting conditions: the reference's ``MPI_Allreduce`` of ``src/outletBC.cpp:533-540``)."""
+        try:
+            if self.host_buffers or not torch.cuda.is_available():
+                t = self._view(values, count)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                return 0
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0), device=self.device)):
+                t = self._view(values, count)
+                if self.backend == "nccl":
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                else:  # device buffer over a CPU backend
+                    h = t.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                    t.copy_(h)
+            return 0
+        except Exception as exc:  # never let an exception cross the C boundary
+            import traceback
+
+            traceback.print_exc()
+            self.error = exc
+            return 1
+
     def _exchange(self, send, recv, nnbr, ranks, send_off, recv_off):
         key = (send, recv, nnbr, send_off[nnbr], recv_off[nnbr])
         cached = self._plans.get(key)

@@ -51,6 +51,9 @@ class RHSoperator:
         if halo is not None:
             self._halo_cb = capi.HALO_FN(halo.callback)
             rt.halo = self._halo_cb
+            if hasattr(halo, "reduce_callback"):
+                self._reduce_cb = capi.REDUCE_FN(halo.reduce_callback)
+                rt.reduce = self._reduce_cb
         self._rt = rt
         h = C.c_void_p()
         st_code = self._lib.tpsrhs_create(C.byref(self._margs.c), C.byref(disc), C.byref(physics), len(bcs),
@@ -135,6 +138,13 @@ class RHSoperator:
         if want_nan_count:
             self.nan_count = bad.value
         return t.value
+
+    def setDt(self, dt: float):
+        """The ``dt`` the non-reflecting boundary conditions advance their boundary state with in every
+        ``Mult`` (the reference's ``BoundaryCondition::dt`` is a reference to ``M2ulPhyS::dt``)."""
+        st = self._lib.tpsrhs_set_dt(self._h, float(dt))
+        if st != 0:
+            raise TpsRhsError(st, "tpsrhs_set_dt")
 
     def setForcing(self, forcing):
         """ConstantPressureGradient / SpongeZone / HeatSource of the reference's ``forcing`` array
