@@ -24,7 +24,7 @@ def _compare(mesh, disc, ph, bcs, U, tol=RHS_RTOL):
     assert abs(got["max_char_speed"] - ref["max_char_speed"]) < 1e-12 * ref["max_char_speed"]
 
 
-@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("order", [1, 2, 3, 5])
 def test_periodic_box_hex(order):
     mesh = meshgen.scramble_orientations(meshgen.box_hex(4, 3, 5, lengths=(1.0, 0.8, 1.2), warp=0.12), 11 + order)
     disc = capi.Disc(order, 0, 0, 0, 0)
@@ -34,7 +34,8 @@ def test_periodic_box_hex(order):
 
 
 @pytest.mark.parametrize("order,eq,wall", [(1, capi.EULER, capi.INV), (2, capi.NS, capi.VISC_ADIAB),
-                                            (3, capi.NS, capi.VISC_ISOTH), (3, capi.NS, capi.INV)])
+                                            (3, capi.NS, capi.VISC_ISOTH), (3, capi.NS, capi.INV),
+                                            (4, capi.NS, capi.VISC_ADIAB), (5, capi.NS, capi.VISC_ISOTH)])
 def test_cylinder(order, eq, wall):
     c = cases.cyl3d(5, 12, 4, order, eq, wall)
     c.mesh = meshgen.scramble_orientations(c.mesh, 5)
@@ -43,7 +44,7 @@ def test_cylinder(order, eq, wall):
     _compare(c.mesh, c.disc, c.physics, c.bcs, U)
 
 
-@pytest.mark.parametrize("order", [1, 2, 3, 4])
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5])
 def test_periodic_box_quad(order):
     mesh = meshgen.scramble_orientations(meshgen.box_quad(7, 5, lengths=(1.0, 0.7), warp=0.1), 2)
     disc = capi.Disc(order, 0, 0, 0, 0)

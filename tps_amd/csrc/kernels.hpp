@@ -1187,12 +1187,12 @@ __global__ __launch_bounds__(256) void k_bc_mean(int nfaces, const int2 *__restr
 
 // One block per face of a non-reflecting patch, one lane per face quadrature point.
 template <class C, class PH>
-__global__ __launch_bounds__(64) void k_bc_nr(MeshDev m, typename PH::Params prm, const int2 *__restrict__ faces,
+__global__ __launch_bounds__(C::BLOCK) void k_bc_nr(MeshDev m, typename PH::Params prm, const int2 *__restrict__ faces,
                                               const double *__restrict__ sums, const double *__restrict__ U,
                                               const double *__restrict__ Up, const double *__restrict__ gradUp,
                                               double *__restrict__ state_old, double *__restrict__ state_new, int first) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-  static_assert(C::NQ <= 64, "one lane per face quadrature point");
+  static_assert(C::NQ <= C::BLOCK, "one lane per face quadrature point");
   const Tables1D &ct = c_tab[DIM - 2][C::P];
   __shared__ Tab<C> tab;
   load_tables<C>(tab, ct);

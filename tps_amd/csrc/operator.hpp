@@ -214,7 +214,7 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
         if (st != 0) throw std::runtime_error("halo: reduce callback failed");
       }
       if (op->n_nr_faces > 0) {
-        hipLaunchKernelGGL((k_bc_nr<C, PH>), dim3(op->n_nr_faces), dim3(64), 0, s, m, prm, op->d_nr_faces, op->d_bc_sums, x,
+        hipLaunchKernelGGL((k_bc_nr<C, PH>), dim3(op->n_nr_faces), dim3(C::BLOCK), 0, s, m, prm, op->d_nr_faces, op->d_bc_sums, x,
                            op->d_Up, op->d_gradUp, op->d_bstate[op->bstate_cur], op->d_bstate[1 - op->bstate_cur],
                            op->bstate_init ? 0 : 1);
         HIP_CHECK(hipGetLastError());
@@ -314,7 +314,15 @@ void pick_order(tpsrhs_operator *op) {
     case 2: op->launch = &launch_all<DIM, 2, PH>; break;
     case 3: op->launch = &launch_all<DIM, 3, PH>; break;
     case 4: op->launch = &launch_all<DIM, 4, PH>; break;
-    default: throw Unsupported("polynomial order " + std::to_string(op->order) + " is not built (1..4)");
+    case 5:  // MAXDOFS = 216 of the reference (src/dataStructures.hpp:41-65): light physics only
+      if constexpr (PH::MAX_ORDER >= 5) {
+        op->launch = &launch_all<DIM, 5, PH>;
+        break;
+      }
+      [[fallthrough]];
+    default:
+      throw Unsupported("polynomial order " + std::to_string(op->order) + " is not built for this physics (1.." +
+                        std::to_string(PH::MAX_ORDER) + ")");
   }
 }
 

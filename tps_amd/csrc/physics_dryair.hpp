@@ -82,6 +82,7 @@ struct DryAirPhys {
   static constexpr int NACTIVE = 0;
   static constexpr bool HAS_SOURCE = false;
   static constexpr bool TWO_TEMPERATURE = false;
+  static constexpr int MAX_ORDER = 5;
   static constexpr bool HAS_NR_BC = NR_;  // non-reflecting inlet / outlet types (perfect gas only, as in the reference)
   static constexpr bool AXISYM = false;
   static constexpr bool VISC_USES_GRAD_RHO = false;  // Newtonian stress + Fourier flux: grad u and grad T only

@@ -167,6 +167,7 @@ struct PlasmaPhys {
   static constexpr int ITH = NVEL_ + 1, ITE = NEQ - 1;
   static constexpr bool HAS_SOURCE = true;
   static constexpr bool TWO_TEMPERATURE = TWOT;
+  static constexpr int MAX_ORDER = 4;
   static constexpr bool HAS_NR_BC = false;  // the reference's non-reflecting conditions are perfect-gas algebra
   static constexpr bool VISC_USES_GRAD_RHO = true;  // mole-fraction gradients need grad(rho)
   static constexpr bool AXISYM = NVEL_ > DIM_;  // dim 2 with (r, z, theta) velocity components
