@@ -210,6 +210,18 @@ def main():
         ktimes = op.kernel_times()  # ms, averaged over the timed Mults
         op.enable_kernel_timing(False)
         finite = bool(torch.isfinite(y).all().item())
+        rk4 = None
+        if world == 1 and wname == args.workload:
+            # next row of the scope table: the RK4 time loop on the device (tpsrhs_advance),
+            # a constant, tiny dt so that the state stays where the Mult timing left it
+            nst = max(2, min(10, steps // 4))
+            op.advance(x, 0.0, 1.0e-10, 1, True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, _, bad = op.advance(x, 0.0, 1.0e-10, nst, True)
+            t_loop = time.perf_counter() - t1
+            rk4 = {"rk4_steps_per_s": nst / t_loop, "ms_per_rk4_step": 1e3 * t_loop / nst, "steps": nst,
+                   "nan_entries": int(bad), "mult_per_step": 4}
         op.close()
         del x, y
         if rank != 0:
@@ -234,7 +246,7 @@ def main():
                                     f"p={order}, GL basis + GL rule, {description}"),
                        "elements_per_gpu": mesh.num_elements, "nodes_per_gpu": ndofs, "num_equation": neq,
                        "partition": "spanwise slabs, RCCL send/recv of face traces" if world > 1 else "single GPU"},
-            "rhs_evals_per_s": evals_per_s, "kernel_ms": ktimes, "finite": finite,
+            "rhs_evals_per_s": evals_per_s, "kernel_ms": ktimes, "finite": finite, "time_loop": rk4,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_node": alg[dom],
@@ -263,6 +275,8 @@ def main():
             "rhs_evals_per_s": res["rhs_evals_per_s"], "kernel_ms": res["kernel_ms"], "finite": res["finite"],
             "roofline": res["roofline"],
         }
+        if res.get("time_loop"):
+            out["time_loop"] = res["time_loop"]
         if others:
             out["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:

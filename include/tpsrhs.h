@@ -248,19 +248,22 @@ typedef int (*tpsrhs_halo_fn)(void *ctx, int phase, const double *send, double *
                               int num_neighbors, const int *neighbor_ranks,
                               const int64_t *send_offsets, const int64_t *recv_offsets, void *stream);
 
-/* Sum over the ranks of the job, in place, of `count` doubles in DEVICE memory, ordered on `stream`: the
- * MPI_Allreduce(SUM) of the boundary means of the non-reflecting inlet/outlet conditions
+/* Reduction over the ranks of the job (`op`: tpsrhs_reduce_op), in place, of `count` doubles in DEVICE memory,
+ * ordered on `stream`.  SUM: the MPI_Allreduce of the boundary means of the non-reflecting inlet/outlet conditions
  * (src/outletBC.cpp:533-540, src/inletBC.cpp:548-555; one call per Mult for all such patches together --
  * ranks without faces on a patch contribute zeros, so the job-wide sum equals the reference's
- * per-patch communicator).  Return 0 on success. */
-typedef int (*tpsrhs_reduce_fn)(void *ctx, double *values, int count, void *stream);
+ * per-patch communicator).  MIN: the MPI_Allreduce of the time step in tpsrhs_advance
+ * (src/M2ulPhyS.cpp:2013-2016).  Return 0 on success. */
+enum tpsrhs_reduce_op { TPSRHS_REDUCE_SUM = 0, TPSRHS_REDUCE_MIN = 1 };
+typedef int (*tpsrhs_reduce_fn)(void *ctx, double *values, int count, int op, void *stream);
 
 typedef struct tpsrhs_runtime {
   int device;            /* HIP device ordinal (reference: rank % numGpusPerRank, src/tps.cpp:196) */
   void *stream;          /* hipStream_t for all work of this operator, NULL = default stream */
   tpsrhs_halo_fn halo;   /* required when mesh.num_shared_faces > 0 */
   void *halo_ctx;
-  tpsrhs_reduce_fn reduce; /* required when mesh.num_shared_faces > 0 and a non-reflecting patch exists */
+  tpsrhs_reduce_fn reduce; /* required when mesh.num_shared_faces > 0 and a non-reflecting patch exists, or
+                            * tpsrhs_advance runs with a variable time step */
   void *reduce_ctx;
 } tpsrhs_runtime;
 
@@ -322,6 +325,17 @@ int tpsrhs_kernel_bytes(tpsrhs_handle h, int capacity, const char **names, doubl
  * max_char_speed (may be NULL): value left by the last stage's Mult, which the reference turns into the
  * next dt (src/M2ulPhyS.cpp:2013-2016).  nan_count (may be NULL): number of NaN entries of the new x. */
 int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double *max_char_speed, int64_t *nan_count);
+
+/* The time loop on the device: `num_steps` times M2ulPhyS::solveStep (src/M2ulPhyS.cpp:2004-2019) --
+ *   timeIntegrator->Step(*U, time, dt); Check_NAN(); Check_Undershoot();
+ *   if (!constant_dt) dt = MPI_MIN over ranks of CFL * hmin / max_char_speed / dim;
+ * -- with dt, the time and the NaN census kept in device memory, so that nothing returns to the host between
+ * steps (one synchronisation at the end).  x: device vector, updated in place; *time and *dt: in/out (dt of
+ * the NEXT step on return); hmin: the reference's minimum element size (mesh->GetElementSize(i, 1),
+ * src/M2ulPhyS.cpp:757-761 [third party: MFEM], passed in by the adapter); nan_count (may be NULL): NaN entries
+ * seen by the censuses of all steps (the reference exits at the first). */
+int tpsrhs_advance(tpsrhs_handle h, double *x, double *time, double *dt, int num_steps, int constant_dt, double cfl,
+                   double hmin, int64_t *nan_count);
 
 /* The time step the non-reflecting boundary conditions integrate their boundary state with: the reference's
  * BoundaryCondition holds a reference to M2ulPhyS::dt (src/BoundaryCondition.hpp:54) and advances `boundaryU`

@@ -762,6 +762,24 @@ int tpsoracle_destroy(void *h) {
   delete static_cast<Operator *>(h);
   return 0;
 }
+int tpsoracle_rk4_step(void *h, double *x, double *time, double dt, double *max_char_speed, int64_t *nan_count);
+// num_steps x M2ulPhyS::solveStep (src/M2ulPhyS.cpp:2004-2019): RK4 step, NaN census, species clamp, then
+// dt = CFL * hmin / max_char_speed / dim unless the time step is constant
+int tpsoracle_advance(void *h, double *x, double *time, double *dt, int num_steps, int constant_dt, double cfl,
+                      double hmin, int64_t *nan_count) {
+  Operator *op = static_cast<Operator *>(h);
+  int64_t total = 0;
+  for (int s = 0; s < num_steps; s++) {
+    double speed = 0.0;
+    int64_t bad = 0;
+    const int st = tpsoracle_rk4_step(h, x, time, *dt, &speed, &bad);
+    if (st != 0) return st;
+    total += bad;
+    if (!constant_dt) *dt = cfl * hmin / speed / static_cast<double>(op->dim);
+  }
+  if (nan_count) *nan_count = total;
+  return 0;
+}
 int tpsoracle_set_dt(void *h, double dt) {
   static_cast<Operator *>(h)->bc_dt = dt;
   return 0;

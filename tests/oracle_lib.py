@@ -39,6 +39,7 @@ def lib():
         L.tpsoracle_get_primitives.argtypes = [vp, _dp]
         L.tpsoracle_get_gradients.argtypes = [vp, _dp]
         L.tpsoracle_node_coords.argtypes = [vp, _dp]
+        L.tpsoracle_advance.argtypes = [vp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int64)]
         L.tpsoracle_set_dt.argtypes = [vp, C.c_double]
         L.tpsoracle_get_boundary_state.argtypes = [vp, C.c_int, _dp, _dp]
         L.tpsoracle_set_forcing.argtypes = [vp, C.POINTER(capi.Forcing)]
@@ -250,6 +251,16 @@ class Oracle:
         if st != 0:
             raise RuntimeError("oracle: " + lib().tpsoracle_last_error().decode())
         return xx, t.value, speed.value, bad.value
+
+    def advance(self, x, time, dt, num_steps, constant_dt=True, cfl=0.0, hmin=0.0):
+        """-> (new x, time, next dt, NaN count)"""
+        xx = np.ascontiguousarray(x, dtype=np.float64).copy()
+        t, d, bad = C.c_double(time), C.c_double(dt), C.c_int64(0)
+        st = lib().tpsoracle_advance(self.h, _p(xx), C.byref(t), C.byref(d), int(num_steps), 1 if constant_dt else 0,
+                                     float(cfl), float(hmin), C.byref(bad))
+        if st != 0:
+            raise RuntimeError("oracle: " + lib().tpsoracle_last_error().decode())
+        return xx, t.value, d.value, bad.value
 
     def flux_transport(self, state, grad):
         """(viscosity, bulk, k_heavy, k_electron), diffusion velocities [sp + d*nsp]"""

@@ -62,3 +62,30 @@ def test_rk4_counts_nans_and_clamps_species():
     # the census (Check_NAN) runs before the clamp (Check_Undershoot), and max(NaN, 0) = 0 in the species rows
     assert bad >= np.isnan(got).sum() > 0
     assert not np.isnan(got[5]).any() and np.isnan(got[:5]).sum() == np.isnan(got).sum()
+
+
+@pytest.mark.parametrize("constant_dt", [True, False])
+def test_advance_keeps_the_time_loop_on_the_device(constant_dt):
+    """tpsrhs_advance: several solveStep's with dt (CFL controlled or constant), time and NaN census on the device,
+    against the oracle's host loop."""
+    import torch
+    from tps_amd.rhs_operator import RHSoperator
+
+    c = cases.cyl3d(4, 12, 3, 2, capi.NS, capi.VISC_ISOTH)
+    c.physics.dry_air.visc_mult = 100.0
+    # a non-reflecting outlet on top: its boundary state integrates with the device-side dt too
+    c.bcs[1] = capi.make_bc(2, capi.OUTLET, capi.SUB_P_NR, [101000.0, 0, 0, 0, 0.0, 0.0, 1.0, 0.0])
+    U = c.state(seed=2)
+    o = Oracle(c.mesh, c.disc, c.physics, c.bcs)
+    dt0, cfl, hmin, nsteps = 2.0e-5, 0.12, 0.05, 4
+    ref, t, dt, bad = o.advance(U, 0.0, dt0, nsteps, constant_dt, cfl, hmin)
+    op = RHSoperator(c.mesh, c.disc, c.physics, c.bcs)
+    x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
+    tg, dtg, gbad = op.advance(x, 0.0, dt0, nsteps, constant_dt, cfl, hmin)
+    got = x.cpu().numpy().reshape(U.shape)
+    op.close()
+    print("time", tg, t, "next dt", dtg, dt)
+    assert gbad == bad == 0
+    assert tg == pytest.approx(t, rel=1e-13) and dtg == pytest.approx(dt, rel=1e-12)
+    assert (dtg == dt0) == constant_dt
+    assert rel_maxnorm(got, ref).max() < 1e-13

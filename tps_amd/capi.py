@@ -113,7 +113,8 @@ HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_
                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
 
 
-REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
+REDUCE_SUM, REDUCE_MIN = 0, 1
 
 
 class Runtime(C.Structure):
@@ -431,6 +432,8 @@ def load():
     lib.tpsrhs_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_kernel_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_rk4_step.argtypes = [vp, C.c_void_p, _dp, C.c_double, _dp, C.POINTER(C.c_int64)]
+    lib.tpsrhs_advance.argtypes = [vp, C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                   C.POINTER(C.c_int64)]
     lib.tpsrhs_set_dt.argtypes = [vp, C.c_double]
     lib.tpsrhs_set_forcing.argtypes = [vp, C.POINTER(Forcing)]
     lib.tpsrhs_set_joule_heating.argtypes = [vp, C.c_void_p]
@@ -448,7 +451,7 @@ EXPORTED_SYMBOLS = [
     "tpsrhs_create", "tpsrhs_destroy", "tpsrhs_mult", "tpsrhs_mult_host", "tpsrhs_update_gradients",
     "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
     "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_kernel_bytes", "tpsrhs_face_tables",
-    "tpsrhs_rk4_step", "tpsrhs_set_dt", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_status_string",
+    "tpsrhs_rk4_step", "tpsrhs_advance", "tpsrhs_set_dt", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_status_string",
     "tpsrhs_last_error", "tpsrhs_version",
 ]
 

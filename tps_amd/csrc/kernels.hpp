@@ -1190,8 +1190,10 @@ template <class C, class PH>
 __global__ __launch_bounds__(C::BLOCK) void k_bc_nr(MeshDev m, typename PH::Params prm, const int2 *__restrict__ faces,
                                               const double *__restrict__ sums, const double *__restrict__ U,
                                               const double *__restrict__ Up, const double *__restrict__ gradUp,
-                                              double *__restrict__ state_old, double *__restrict__ state_new, int first) {
+                                              double *__restrict__ state_old, double *__restrict__ state_new, int first,
+                                              const double *__restrict__ dt_dev) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  if (dt_dev) prm.nr_dt = *dt_dev;  // tpsrhs_advance keeps dt in device memory
   static_assert(C::NQ <= C::BLOCK, "one lane per face quadrature point");
   const Tables1D &ct = c_tab[DIM - 2][C::P];
   __shared__ Tab<C> tab;
@@ -1703,9 +1705,10 @@ __global__ void k_reduce_max(int n, const double *__restrict__ v, double *__rest
 //   stage 3: y = x + dt k,   z += dt/3 k        stage 4: x = z + dt/6 k (+ NaN census, species clamp)
 // =============================================================================================
 template <int BLOCK>
-__global__ void k_rk4_stage(int stage, int64_t n, int64_t ndofs, int sp_first, int sp_last, double dt,
-                            double *__restrict__ x, const double *__restrict__ k, double *__restrict__ y,
-                            double *__restrict__ z, unsigned long long *__restrict__ nan_count) {
+__global__ void k_rk4_stage(int stage, int64_t n, int64_t ndofs, int sp_first, int sp_last, double dt_host,
+                            const double *__restrict__ dt_dev, double *__restrict__ x, const double *__restrict__ k,
+                            double *__restrict__ y, double *__restrict__ z, unsigned long long *__restrict__ nan_count) {
+  const double dt = dt_dev ? *dt_dev : dt_host;  // tpsrhs_advance keeps dt in device memory
   unsigned long long bad = 0;
   for (int64_t i = blockIdx.x * static_cast<int64_t>(BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * BLOCK) {
     const double ki = k[i];
@@ -1728,6 +1731,27 @@ __global__ void k_rk4_stage(int stage, int64_t n, int64_t ndofs, int sp_first, i
     }
   }
   if (stage == 4 && bad) atomicAdd(nan_count, bad);
+}
+
+// End of a step of tpsrhs_advance (src/M2ulPhyS.cpp:2004-2016): time += dt; with a variable time step
+// dt = CFL hmin / max_char_speed / dim from the per-block maxima the last k_flux left.  ctl = {dt, time, speed}.
+template <int BLOCK>
+__global__ void k_step_end(int n, const double *__restrict__ block_speed, double *__restrict__ ctl, int constant_dt,
+                           double cfl_hmin_over_dim) {
+  __shared__ double s[BLOCK];
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += BLOCK) m = fmax(m, block_speed[i]);
+  s[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = BLOCK / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    ctl[1] += ctl[0];
+    ctl[2] = s[0];
+    if (!constant_dt) ctl[0] = cfl_hmin_over_dim / s[0];
+  }
 }
 
 // =============================================================================================

@@ -79,6 +79,7 @@ struct tpsrhs_operator {
   bool forcing_active = false;
   // non-reflecting inlet / outlet patches (dry air): their faces {slot, bc index}, slot -> ordinal, the
   // double-buffered boundary state, the patch sums of the primitives, the time step they integrate with
+  bool has_nr = false;  // some boundary condition is of a non-reflecting type (possibly without local faces)
   int n_nr_faces = 0;
   int2 *d_nr_faces = nullptr;
   int *d_nr_ordinal = nullptr;
@@ -87,6 +88,8 @@ struct tpsrhs_operator {
   bool bstate_init = false;
   double *d_bc_sums = nullptr;
   double nr_dt = 0.0;
+  double *d_ctl = nullptr;          // {dt, time, max speed} of tpsrhs_advance
+  const double *nr_dt_dev = nullptr;  // non-NULL while tpsrhs_advance runs: the boundary conditions read dt there
   tpsrhs_reduce_fn reduce = nullptr;
   void *reduce_ctx = nullptr;
   // halo
@@ -132,7 +135,7 @@ struct tpsrhs_operator {
     if (d_nan) (void)hipFree(d_nan);
     if (d_forcing) (void)hipFree(d_forcing);
     for (void *p : {static_cast<void *>(d_nr_faces), static_cast<void *>(d_nr_ordinal), static_cast<void *>(d_bstate[0]),
-                    static_cast<void *>(d_bstate[1]), static_cast<void *>(d_bc_sums)})
+                    static_cast<void *>(d_bstate[1]), static_cast<void *>(d_bc_sums), static_cast<void *>(d_ctl)})
       if (p) (void)hipFree(p);
     if (d_blocks_halo) (void)hipFree(d_blocks_halo);
     if (d_blocks_interior) (void)hipFree(d_blocks_interior);
@@ -202,21 +205,19 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
   // after the last k_gradient launch, before the first k_flux launch
   auto nr_update = [&](const MeshDev &m) {
     if constexpr (PH::HAS_NR_BC) {
-      if (op->n_nr_faces == 0 && !op->reduce) return;
+      if (!op->has_nr) return;
       const int nbc = prm.num_bcs;
-      if (op->n_nr_faces > 0 || op->reduce) {
-        hipLaunchKernelGGL((k_bc_mean<C, PH>), dim3(nbc), dim3(256), 0, s, op->n_nr_faces, op->d_nr_faces, op->d_TA,
-                           op->d_bc_sums);
-        HIP_CHECK(hipGetLastError());
-      }
-      if (op->reduce) {
-        const int st = op->reduce(op->reduce_ctx, op->d_bc_sums, nbc * (TPSRHS_MAXEQUATIONS + 1), s);
+      hipLaunchKernelGGL((k_bc_mean<C, PH>), dim3(nbc), dim3(256), 0, s, op->n_nr_faces, op->d_nr_faces, op->d_TA,
+                         op->d_bc_sums);
+      HIP_CHECK(hipGetLastError());
+      if (op->reduce && op->topo.num_shared > 0) {
+        const int st = op->reduce(op->reduce_ctx, op->d_bc_sums, nbc * (TPSRHS_MAXEQUATIONS + 1), TPSRHS_REDUCE_SUM, s);
         if (st != 0) throw std::runtime_error("halo: reduce callback failed");
       }
       if (op->n_nr_faces > 0) {
         hipLaunchKernelGGL((k_bc_nr<C, PH>), dim3(op->n_nr_faces), dim3(C::BLOCK), 0, s, m, prm, op->d_nr_faces, op->d_bc_sums, x,
                            op->d_Up, op->d_gradUp, op->d_bstate[op->bstate_cur], op->d_bstate[1 - op->bstate_cur],
-                           op->bstate_init ? 0 : 1);
+                           op->bstate_init ? 0 : 1, op->nr_dt_dev);
         HIP_CHECK(hipGetLastError());
       }
     }

@@ -339,11 +339,8 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
           HIP_CHECK(hipMemset(op->d_bstate[k], 0, n * sizeof(double)));
         }
       }
-    } else {
-      op->reduce = nullptr;  // nothing to sum
     }
-  } else {
-    op->reduce = nullptr;
+    op->has_nr = any_nr;
   }
   if (op->ndofs >= (int64_t(1) << 31)) throw Unsupported("more than 2^31 nodes per rank");
   const int64_t nslots = static_cast<int64_t>(op->ne) * op->nfaces + tp.num_shared;
@@ -451,32 +448,40 @@ int tpsrhs_mult_host(tpsrhs_handle h, const double *x, double *y, double time, d
   });
 }
 
+namespace {
+// the four stages of MFEM's RK4Solver::Step around Mult; dt by value or from device memory (dt_dev)
+void rk4_stages(tpsrhs_operator *h, double *x, double dt, const double *dt_dev) {
+  const int64_t n = static_cast<int64_t>(h->neq) * h->ndofs;
+  if (!h->d_rk) {
+    h->d_rk = dev_alloc<double>(3 * n);
+    h->d_nan = dev_alloc<unsigned long long>(1);
+    HIP_CHECK(hipMemsetAsync(h->d_nan, 0, sizeof(unsigned long long), h->stream));
+  }
+  double *k = h->d_rk, *y = k + n, *z = y + n;
+  const bool mixture = h->phys.working_fluid == TPSRHS_USER_DEFINED;
+  const int sp_first = h->nvel + 2;
+  const int sp_last = mixture ? sp_first + (h->phys.mixture.ambipolar ? h->phys.mixture.num_species - 2
+                                                                       : h->phys.mixture.num_species - 1)
+                              : sp_first;
+  const int grid = static_cast<int>(std::min<int64_t>((n + 255) / 256, 8192));
+  const double *in = x;
+  for (int stage = 1; stage <= 4; stage++) {
+    h->launch(h, in, k, false);  // k_s = f(stage input); SetTime is a no-op for this operator
+    hipLaunchKernelGGL(k_rk4_stage<256>, dim3(grid), dim3(256), 0, h->stream, stage, n, h->ndofs, sp_first, sp_last, dt,
+                       dt_dev, x, k, y, z, h->d_nan);
+    HIP_CHECK(hipGetLastError());
+    in = y;
+  }
+}
+}  // namespace
+
 int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double *max_char_speed, int64_t *nan_count) {
   if (!h || !x || !time) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_rk4_step: NULL argument");
   return guarded([&] {
     HIP_CHECK(hipSetDevice(h->device));
-    const int64_t n = static_cast<int64_t>(h->neq) * h->ndofs;
-    if (!h->d_rk) {
-      h->d_rk = dev_alloc<double>(3 * n);
-      h->d_nan = dev_alloc<unsigned long long>(1);
-    }
-    double *k = h->d_rk, *y = k + n, *z = y + n;
     h->nr_dt = dt;  // the boundary conditions see M2ulPhyS::dt (src/BoundaryCondition.hpp:54)
-    HIP_CHECK(hipMemsetAsync(h->d_nan, 0, sizeof(unsigned long long), h->stream));
-    const bool mixture = h->phys.working_fluid == TPSRHS_USER_DEFINED;
-    const int sp_first = h->nvel + 2;
-    const int sp_last = mixture ? sp_first + (h->phys.mixture.ambipolar ? h->phys.mixture.num_species - 2
-                                                                         : h->phys.mixture.num_species - 1)
-                                : sp_first;
-    const int grid = static_cast<int>(std::min<int64_t>((n + 255) / 256, 8192));
-    const double *in = x;
-    for (int stage = 1; stage <= 4; stage++) {
-      h->launch(h, in, k, false);  // k_s = f(stage input); SetTime is a no-op for this operator
-      hipLaunchKernelGGL(k_rk4_stage<256>, dim3(grid), dim3(256), 0, h->stream, stage, n, h->ndofs, sp_first, sp_last,
-                         dt, x, k, y, z, h->d_nan);
-      HIP_CHECK(hipGetLastError());
-      in = y;
-    }
+    if (h->d_nan) HIP_CHECK(hipMemsetAsync(h->d_nan, 0, sizeof(unsigned long long), h->stream));
+    rk4_stages(h, x, dt, nullptr);
     *time += dt;
     if (max_char_speed || nan_count) {
       hipLaunchKernelGGL(k_reduce_max<256>, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_speed);
@@ -489,6 +494,49 @@ int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double 
       if (max_char_speed) *max_char_speed = speed;
       if (nan_count) *nan_count = static_cast<int64_t>(bad);
     }
+  });
+}
+
+int tpsrhs_advance(tpsrhs_handle h, double *x, double *time, double *dt, int num_steps, int constant_dt, double cfl,
+                   double hmin, int64_t *nan_count) {
+  if (!h || !x || !time || !dt) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_advance: NULL argument");
+  if (num_steps < 0 || !(*dt > 0.0) || (!constant_dt && !(cfl > 0.0 && hmin > 0.0)))
+    return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_advance: needs num_steps >= 0, dt > 0 and (constant dt or cfl, hmin > 0)");
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(h->device));
+    if (!constant_dt && h->topo.num_shared > 0 && !h->reduce)
+      throw std::runtime_error("halo: a variable time step on a partitioned mesh needs runtime.reduce");
+    if (!h->d_ctl) h->d_ctl = dev_alloc<double>(3);
+    const double ctl0[3] = {*dt, *time, 0.0};
+    HIP_CHECK(hipMemcpyAsync(h->d_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));  // ctl0 lives on this stack frame
+    if (h->d_nan) HIP_CHECK(hipMemsetAsync(h->d_nan, 0, sizeof(unsigned long long), h->stream));
+    h->nr_dt_dev = h->d_ctl;
+    try {
+      for (int step = 0; step < num_steps; step++) {
+        rk4_stages(h, x, 0.0, h->d_ctl);
+        hipLaunchKernelGGL(k_step_end<256>, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_ctl,
+                           constant_dt ? 1 : 0, cfl * hmin / static_cast<double>(h->dim));
+        HIP_CHECK(hipGetLastError());
+        if (!constant_dt && h->reduce) {  // MPI_Allreduce(MIN) of src/M2ulPhyS.cpp:2015
+          if (h->reduce(h->reduce_ctx, h->d_ctl, 1, TPSRHS_REDUCE_MIN, h->stream) != 0)
+            throw std::runtime_error("halo: reduce callback failed");
+        }
+      }
+    } catch (...) {
+      h->nr_dt_dev = nullptr;
+      throw;
+    }
+    h->nr_dt_dev = nullptr;
+    double ctl[3] = {0, 0, 0};
+    unsigned long long bad = 0;
+    HIP_CHECK(hipMemcpyAsync(ctl, h->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
+    if (h->d_nan) HIP_CHECK(hipMemcpyAsync(&bad, h->d_nan, sizeof(bad), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    *dt = ctl[0];
+    *time = ctl[1];
+    h->nr_dt = ctl[0];
+    if (nan_count) *nan_count = static_cast<int64_t>(bad);
   });
 }
 

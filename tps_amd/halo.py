@@ -75,21 +75,23 @@ class HaloExchange:
             self.error = exc
             return 1
 
-    def reduce_callback(self, ctx, values, count, stream):
-        """``tpsrhs_reduce_fn``: in-place sum over the ranks of ``count`` device doubles (boundary means of the
-        non-reflecting conditions: the reference's ``MPI_Allreduce`` of ``src/outletBC.cpp:533-540``)."""
+    def reduce_callback(self, ctx, values, count, op, stream):
+        """``tpsrhs_reduce_fn``: in-place reduction over the ranks of ``count`` device doubles -- SUM for the
+        boundary means of the non-reflecting conditions (the reference's ``MPI_Allreduce`` of
+        ``src/outletBC.cpp:533-540``), MIN for the time step (``src/M2ulPhyS.cpp:2015``)."""
+        rop = dist.ReduceOp.MIN if op == 1 else dist.ReduceOp.SUM
         try:
             if self.host_buffers or not torch.cuda.is_available():
                 t = self._view(values, count)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(t, op=rop, group=self.group)
                 return 0
             with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0), device=self.device)):
                 t = self._view(values, count)
                 if self.backend == "nccl":
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                    dist.all_reduce(t, op=rop, group=self.group)
                 else:  # device buffer over a CPU backend
                     h = t.cpu()
-                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                    dist.all_reduce(h, op=rop, group=self.group)
                     t.copy_(h)
             return 0
         except Exception as exc:  # never let an exception cross the C boundary

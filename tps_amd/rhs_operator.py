@@ -139,6 +139,17 @@ class RHSoperator:
             self.nan_count = bad.value
         return t.value
 
+    def advance(self, x: torch.Tensor, time: float, dt: float, num_steps: int, constant_dt=True, cfl=0.0, hmin=0.0):
+        """``num_steps`` times ``M2ulPhyS::solveStep`` (``src/M2ulPhyS.cpp:2004-2019``) with dt, time and the NaN
+        census on the device; returns ``(time, next dt, NaN count)`` after ONE synchronisation at the end."""
+        self._check(x)
+        t, d, bad = C.c_double(time), C.c_double(dt), C.c_int64(0)
+        st = self._lib.tpsrhs_advance(self._h, C.c_void_p(x.data_ptr()), C.byref(t), C.byref(d), int(num_steps),
+                                      1 if constant_dt else 0, float(cfl), float(hmin), C.byref(bad))
+        if st != 0:
+            raise TpsRhsError(st, "tpsrhs_advance")
+        return t.value, d.value, bad.value
+
     def setDt(self, dt: float):
         """The ``dt`` the non-reflecting boundary conditions advance their boundary state with in every
         ``Mult`` (the reference's ``BoundaryCondition::dt`` is a reference to ``M2ulPhyS::dt``)."""
