@@ -189,7 +189,8 @@ def test_plasma_non_ambipolar_ternary(order, two_t, transport):
 
 
 @pytest.mark.parametrize("geo,order,transport", [("axisym", 3, capi.CONSTANT), ("3d", 2, capi.ARGON_MIXTURE),
-                                                  ("3d", 1, capi.CONSTANT), ("axisym", 2, capi.ARGON_MIXTURE)])
+                                                  ("3d", 1, capi.CONSTANT), ("axisym", 2, capi.ARGON_MIXTURE),
+                                                  ("3d", 1, capi.ARGON_MIXTURE)])  # four elements per wave
 def test_plasma_six_species(geo, order, transport):
     """Ar, E, Ar.+1, Ar_m, Ar_r, Ar_p, two-temperature, not ambipolar: the mixture of the reference's torch
     input (test/inputs/plasma.ini:158-275), 11 equations"""

@@ -21,7 +21,7 @@ t0 = time.time()
 for it in range(ncases):
     fluid = rng.choice(["dry", "argon3", "argon3n", "argon6"], p=[0.35, 0.35, 0.1, 0.2])
     geo = rng.choice(["cyl3d", "box3d", "box2d", "axisym"])
-    order = int(rng.integers(1, 5 if fluid == "dry" else 4))
+    order = int(rng.integers(1, (6 if geo != "axisym" else 5) if fluid == "dry" else 4))
     eq = capi.NS if rng.random() < 0.85 else capi.EULER
     wall = int(rng.choice([capi.INV, capi.VISC_ADIAB, capi.VISC_ISOTH]))
     seed = int(rng.integers(1, 1000))

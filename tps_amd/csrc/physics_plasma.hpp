@@ -96,11 +96,6 @@ __device__ inline double table_eval(const TableDev &t, double xe) {  // src/tabl
   return ft;
 }
 
-// exp / log as real calls (double in, double out: registers only): the inlined library bodies carry ~30 literal
-// coefficients that the compiler hoists out of the point loops into SGPRs and then spills through VGPR lanes
-__device__ __attribute__((noinline)) inline double nexp(double x) { return exp(x); }
-__device__ __attribute__((noinline)) inline double nlog(double x) { return log(x); }
-
 namespace coll {  // collision-integral fits, src/collision_integrals.cpp
 // c0 log(1 + c1 Tp^c2)^c3 / Tp^2 with the powers taken through exp/log of the argument's logarithm,
 // which the fits of one point share (the reference calls pow twice per fit; the results agree to a few
@@ -110,12 +105,12 @@ struct Arg {
 };
 __device__ inline Arg arg(double Tp) {
   Arg a;
-  a.ln = nlog(Tp);
+  a.ln = log(Tp);
   a.inv2 = 1.0 / (Tp * Tp);
   return a;
 }
 __device__ inline double cfit(double c0, double c1, double c2, double c3, const Arg &a) {
-  return c0 * nexp(c3 * nlog(nlog(1.0 + c1 * nexp(c2 * a.ln)))) * a.inv2;
+  return c0 * exp(c3 * log(log(1.0 + c1 * exp(c2 * a.ln)))) * a.inv2;
 }
 __device__ inline double att11(const Arg &a) { return cfit(0.2150, 5.2194, 1.0472, 1.2435, a); }
 __device__ inline double att12(const Arg &a) { return cfit(0.0991, 7.4684, 1.0155, 1.1536, a); }
@@ -136,28 +131,25 @@ __constant__ static double c_coulomb[2][2][5][4] = {
       {0.0683, 1.9774, 1.2033, 0.8264}, {0.0346, 4.5177, 1.2132, 0.9294}},
      {{0, 0, 0, 0}, {0.4128, 1.2436, 1.1830, 1.0123}, {0.2203, 1.8832, 1.2059, 0.9851}, {0.1323, 2.7248, 1.2129, 0.9847},
       {0, 0, 0, 0}}}};
-__device__ inline double ArAr11(double lnT) { return 2.2910e-18 * nexp(-0.3032 * lnT); }
+__device__ inline double ArAr11(double lnT) { return 2.2910e-18 * exp(-0.3032 * lnT); }
 __device__ inline double ArAr22(double T) { return 1.7e-18 / sqrt(sqrt(T)); }  // T^-0.25
-__device__ inline double ArAr1P11(double lnT) { return 4.574321e-18 * nexp(-0.1805 * lnT); }
-// e-Ar (1, r) fits, src/collision_integrals.cpp (eAr11 .. eAr15): coefficients in constant memory -- as 45
-// literals they would be materialised in SGPR pairs and spilled
-__constant__ static double c_eAr[5][9] = {
-    {6.36254140e-18, 1.84835040e-18, -5.87727093e-18, 3.20023027e-18, -8.50509054e-19, 1.28163820e-19,
-     -1.11712910e-20, 5.25649382e-22, -1.03296658e-23},
-    {1.91338172e-17, 5.45418129e-18, -1.78361685e-17, 9.75657946e-18, -2.61115722e-18, 3.98310268e-19,
-     -3.53503678e-20, 1.70375066e-21, -3.45211955e-23},
-    {3.04685398e-17, 8.39750994e-18, -2.88132528e-17, 1.60147037e-17, -4.34837891e-18, 6.73136845e-19,
-     -6.06704580e-20, 2.97216168e-21, -6.12760944e-23},
-    {3.90777949e-17, 1.04696956e-17, -3.73774204e-17, 2.10610498e-17, -5.79029566e-18, 9.07573157e-19,
-     -8.28466766e-20, 4.11188110e-21, -8.59225098e-23},
-    {4.41333290e-17, 1.15696010e-17, -4.25651305e-17, 2.42442440e-17, -6.73359258e-18, 1.06641697e-18,
-     -9.83933863e-20, 4.93775812e-21, -1.04362372e-22}};
+__device__ inline double ArAr1P11(double lnT) { return 4.574321e-18 * exp(-0.1805 * lnT); }
 __device__ inline double eAr1r(int r, double logT) {
-  const double *C = c_eAr[r - 1];
-  double fit = C[0] / logT, pw = 1.0;
+  const double C[5][9] = {
+      {6.36254140e-18, 1.84835040e-18, -5.87727093e-18, 3.20023027e-18, -8.50509054e-19, 1.28163820e-19,
+       -1.11712910e-20, 5.25649382e-22, -1.03296658e-23},
+      {1.91338172e-17, 5.45418129e-18, -1.78361685e-17, 9.75657946e-18, -2.61115722e-18, 3.98310268e-19,
+       -3.53503678e-20, 1.70375066e-21, -3.45211955e-23},
+      {3.04685398e-17, 8.39750994e-18, -2.88132528e-17, 1.60147037e-17, -4.34837891e-18, 6.73136845e-19,
+       -6.06704580e-20, 2.97216168e-21, -6.12760944e-23},
+      {3.90777949e-17, 1.04696956e-17, -3.73774204e-17, 2.10610498e-17, -5.79029566e-18, 9.07573157e-19,
+       -8.28466766e-20, 4.11188110e-21, -8.59225098e-23},
+      {4.41333290e-17, 1.15696010e-17, -4.25651305e-17, 2.42442440e-17, -6.73359258e-18, 1.06641697e-18,
+       -9.83933863e-20, 4.93775812e-21, -1.04362372e-22}};
+  double fit = C[r - 1][0] / logT, pw = 1.0;
 #pragma unroll
   for (int k = 1; k < 9; k++) {
-    fit += C[k] * pw;
+    fit += C[r - 1][k] * pw;
     pw *= logT;
   }
   return fit;
@@ -445,8 +437,8 @@ struct PlasmaPhys {
     c.e = coll::arg(f * Te);
     c.h = TWOT ? coll::arg(f * Th) : c.e;
     c.Th = Th;
-    c.lnTe = nlog(Te);
-    c.lnTh = TWOT ? nlog(Th) : c.lnTe;
+    c.lnTe = log(Te);
+    c.lnTh = TWOT ? log(Th) : c.lnTe;
     return c;
   }
   // GasMixtureTransport::collisionIntegral (src/gas_transport.cpp:995-1283), argon types.  (l, r) and the
@@ -564,7 +556,7 @@ struct PlasmaPhys {
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) mwp[sp] = p.mw[sp] / kAvogadro;
       const Debye d = debye(q.n, Th, Te);
-      const double lnTe = nlog(Te), lnTh = TWOT ? nlog(Th) : lnTe;
+      const double lnTe = log(Te), lnTh = TWOT ? log(Th) : lnTe;
       const double QeAr = coll::eAr1r(1, lnTe), Qatt = coll::att11(d.e) * d.circle;
       double sv[NSP];
 #pragma unroll
@@ -672,7 +664,7 @@ struct PlasmaPhys {
       const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
       const double me = p.mw[I_E] / kAvogadro;
       const Debye d = debye(q.n, Th, Te);
-      const double QeAr = coll::eAr1r(1, nlog(Te)), Qatt = coll::att11(d.e) * d.circle;
+      const double QeAr = coll::eAr1r(1, log(Te)), Qatt = coll::att11(d.e) * d.circle;
       mtfreq[I_ION] = mff * sqrt(Te / me) * q.n[I_ION] * Qatt;
       mtfreq[I_N] = mff * sqrt(Te / me) * q.n[I_N] * QeAr;
       if (p.multiply) {
