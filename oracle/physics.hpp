@@ -17,6 +17,26 @@
 
 namespace tpsoracle {
 
+// An exception must not leave an OpenMP worksharing loop: bodies that call the physics (which throws on
+// inadmissible states, as the reference exits) record the first message here; the caller rethrows after the loop.
+struct OmpGuard {
+  std::string msg;
+  bool failed = false;
+  void capture(const std::exception &e) {
+#pragma omp critical(tpsoracle_guard)
+    {
+      if (!failed) {
+        failed = true;
+        msg = e.what();
+      }
+    }
+  }
+  void rethrow() const {
+    if (failed) throw std::runtime_error(msg);
+  }
+};
+
+
 constexpr int MAXEQ = TPSRHS_MAXEQUATIONS;
 constexpr int MAXSP = TPSRHS_MAXSPECIES;
 constexpr int MAXDIM = 3;

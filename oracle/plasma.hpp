@@ -1079,8 +1079,9 @@ class SourceTerm {
     }
   }
   void updateTerms(const double *U, const double *Up, const double *gradUp, int64_t N, double *y) const {
+    OmpGuard guard;
 #pragma omp parallel for schedule(static)
-    for (int64_t n = 0; n < N; n++) {
+    for (int64_t n = 0; n < N; n++) try {
       double upn[MAXEQ], Un[MAXEQ], g[MAXEQ * MAXDIM], src[MAXEQ];
       for (int eq = 0; eq < num_equation; eq++) {
         upn[eq] = Up[n + eq * N];
@@ -1089,7 +1090,10 @@ class SourceTerm {
       }
       point(Un, upn, g, src);
       for (int eq = 0; eq < num_equation; eq++) y[n + eq * N] += src[eq];
+    } catch (const std::exception &e) {
+      guard.capture(e);
     }
+    guard.rethrow();
   }
 };
 

@@ -192,13 +192,17 @@ struct Operator {
 
   // src/rhs_operator.cpp:642-649
   void updatePrimitives(const double *x) {
+    OmpGuard guard;
 #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < ndofs; i++) {
+    for (int64_t i = 0; i < ndofs; i++) try {
       double s[MAXEQ], pr[MAXEQ];
       for (int eq = 0; eq < neq; eq++) s[eq] = x[i + eq * ndofs];
       mixture->GetPrimitivesFromConservatives(s, pr);
       for (int eq = 0; eq < neq; eq++) Up[i + eq * ndofs] = pr[eq];
+    } catch (const std::exception &e) {
+      guard.capture(e);
     }
+    guard.rethrow();
   }
 
   // per-face geometric data at a face quadrature point
@@ -393,8 +397,9 @@ struct Operator {
     const int nf = static_cast<int>(mesh.faces.size());
     std::vector<double> fbuf(static_cast<size_t>(nf) * 2 * dof * neq, 0.0);
     const int nAct = mixture->numActiveSpecies;
+    OmpGuard guard;
 #pragma omp parallel for schedule(dynamic, 16)
-    for (int f = 0; f < nf; f++) {
+    for (int f = 0; f < nf; f++) try {
       const Face &F = mesh.faces[f];
       std::vector<double> shape1(dof), shape2(dof);
       double *el1 = &fbuf[static_cast<size_t>(f) * 2 * dof * neq];
@@ -446,7 +451,10 @@ struct Operator {
             for (int k = 0; k < dof; k++) el1[k + eq * dof] -= fluxN[eq] * shape1[k];
         }
       }
+    } catch (const std::exception &e) {
+      guard.capture(e);
     }
+    guard.rethrow();
     std::fill(z.begin(), z.end(), 0.0);
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < ne; e++)
@@ -465,8 +473,9 @@ struct Operator {
     const int64_t N = ndofs;
     const int nAct = mixture->numActiveSpecies;
     double mcs_all = 0.0;
+    OmpGuard guard;
 #pragma omp parallel for schedule(static) reduction(max : mcs_all)
-    for (int64_t i = 0; i < N; i++) {
+    for (int64_t i = 0; i < N; i++) try {
       double state[MAXEQ], g[MAXEQ * MAXDIM], f[MAXEQ * MAXDIM], fv[MAXEQ * MAXDIM];
       for (int k = 0; k < neq; k++) state[k] = x[i + k * N];
       for (int sp = 0; sp < nAct; sp++) state[nvel + 2 + sp] = std::max(state[nvel + 2 + sp], 0.0);
@@ -483,7 +492,10 @@ struct Operator {
         for (int k = 0; k < neq; k++) flux[i + d * N + k * N * dim] = f[k + d * neq];
       const double mcs = mixture->ComputeMaxCharSpeed(state);
       if (mcs > mcs_all) mcs_all = mcs;
+    } catch (const std::exception &e) {
+      guard.capture(e);
     }
+    guard.rethrow();
     max_char_speed = mcs_all;
   }
 
@@ -722,8 +734,9 @@ struct Operator {
 
 void Operator::axisymmetricSource(const double *x, double *y) {
   const int64_t N = ndofs;
+  OmpGuard guard;
 #pragma omp parallel for schedule(static)
-  for (int64_t n = 0; n < N; n++) {
+  for (int64_t n = 0; n < N; n++) try {
     double U[MAXEQ], prim[MAXEQ], g[MAXEQ * MAXDIM];
     for (int eq = 0; eq < neq; eq++) {
       U[eq] = x[n + eq * N];
@@ -731,7 +744,10 @@ void Operator::axisymmetricSource(const double *x, double *y) {
       for (int d = 0; d < dim; d++) g[eq + d * neq] = gradUp[n + eq * N + d * neq * N];
     }
     axisym_source_point(*mixture, *transport, phys.eq_system, neq, dim, coords[n + 0 * N], U, prim, g, n, N, y);
+  } catch (const std::exception &e) {
+    guard.capture(e);
   }
+  guard.rethrow();
 }
 
 }  // namespace tpsoracle

@@ -252,3 +252,19 @@ def test_boundary_viscous_flux_identity_for_mixtures(kind):
         ref = (fv[:dim] * n[:dim, None]).sum(axis=0)
         got = o.bdr_viscous_flux(U, g.ravel(), n, radius=radius)
         assert np.abs(got[1:] - ref[1:]).max() < 5e-13 * np.abs(ref[1:]).max()
+
+
+def test_inadmissible_state_raises_instead_of_aborting():
+    """The reference exits on a negative background density (src/equation_of_state.cpp:643-650); the oracle throws --
+    also from inside its threaded loops -- and the binding turns that into a Python exception."""
+    import pytest
+    from oracle_lib import Oracle
+    from tps_amd import capi, cases
+
+    c = cases.argon_cyl3d(3, 8, 3, 1, False, capi.CONSTANT, "arrhenius", capi.VISC_ISOTH)
+    U = c.state(seed=1, amp=0.005)
+    U[5, 10:40] = 50.0 * U[0, 10:40]  # more ion mass than total mass
+    o = Oracle(c.mesh, c.disc, c.physics, c.bcs)
+    o.set_threads(4) if hasattr(o, "set_threads") else None
+    with pytest.raises(RuntimeError, match="[Nn]egative"):
+        o.mult(U)
