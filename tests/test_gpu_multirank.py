@@ -84,17 +84,23 @@ def _worker(rank, world, port, q, kind):
         torch.cuda.synchronize()
         out = y.cpu().numpy().reshape(U.shape)
         g = op.getGradients().cpu().numpy()
+        if kind == "dry_air_nr":  # ... and the device time loop with a CFL-controlled dt: MIN over the ranks
+            t_end, dt_next, bad = op.advance(x, 0.0, ADV[0], ADV[1], False, ADV[2], ADV[3])
+            adv = (x.cpu().numpy().reshape(U.shape), t_end, dt_next, bad)
+        else:
+            adv = None
         dist.barrier()
         op.close()
         dist.destroy_process_group()
-        q.put((rank, "ok", idx, out, g, op.max_char_speed))
+        q.put((rank, "ok", idx, out, g, op.max_char_speed, adv))
     except Exception:  # pragma: no cover
         import traceback
 
-        q.put((rank, traceback.format_exc(), None, None, None, None))
+        q.put((rank, traceback.format_exc(), None, None, None, None, None))
 
 
 NR_DT = 3.0e-4
+ADV = (2.0e-5, 3, 0.1, 0.05)  # dt0, steps, CFL, hmin of the advance() leg
 
 
 @pytest.mark.parametrize("world,kind", [(2, "dry_air"), (3, "argon_2T"), (2, "slab"), (4, "slab"), (3, "axisym_2T"),
@@ -108,6 +114,7 @@ def test_ranks_match_serial_oracle(world, kind):
         o.set_dt(NR_DT)
         o.mult(Ug)
         ref = {"y": o.mult(Ug), "gradUp": o.gradients(), "max_char_speed": o.max_char_speed}
+        ref_adv = o.advance(Ug, 0.0, ADV[0], ADV[1], False, ADV[2], ADV[3])
     else:
         ref = oracle_mult(full, capi.Disc(order, 0, 0, 1 if kind == "axisym_2T" else 0, 0), ph, bcs, Ug)
     ctx = mp.get_context("spawn")
@@ -122,11 +129,19 @@ def test_ranks_match_serial_oracle(world, kind):
     y = np.zeros_like(Ug)
     g = np.zeros_like(ref["gradUp"])
     mcs = 0.0
-    for rank, msg, idx, out, gg, speed in res:
+    xa = np.zeros_like(Ug)
+    for rank, msg, idx, out, gg, speed, adv in res:
         assert msg == "ok", f"rank {rank}: {msg}"
         y[:, idx] = out
         g[:, :, idx] = gg
         mcs = max(mcs, speed)
+        if adv is not None:
+            xa[:, idx] = adv[0]
+            assert adv[1] == pytest.approx(ref_adv[1], rel=1e-13) and adv[2] == pytest.approx(ref_adv[2], rel=1e-12)
+            assert adv[3] == 0
+    if kind == "dry_air_nr":
+        print("advance: rel err", rel_maxnorm(xa, ref_adv[0]))
+        assert rel_maxnorm(xa, ref_adv[0]).max() < 1e-13
     err = rel_maxnorm(y, ref["y"])
     print(world, "ranks: rel err", err)
     assert err.max() < (5 * RHS_RTOL if kind in ("argon_2T", "axisym_2T") else RHS_RTOL)  # plasma: 1 % perturbations
