@@ -89,3 +89,43 @@ def test_advance_keeps_the_time_loop_on_the_device(constant_dt):
     assert tg == pytest.approx(t, rel=1e-13) and dtg == pytest.approx(dt, rel=1e-12)
     assert (dtg == dt0) == constant_dt
     assert rel_maxnorm(got, ref).max() < 1e-13
+
+
+def test_advance_replays_a_captured_step(monkeypatch):
+    """On a capturable stream tpsrhs_advance turns one RK4 step into a hipGraph and replays it: same numbers as the
+    plain launch loop, bit for bit, and as the oracle."""
+    import time
+
+    import torch
+    from tps_amd.rhs_operator import RHSoperator
+
+    c = cases.cyl3d(4, 12, 3, 3, capi.NS, capi.VISC_ISOTH)
+    c.physics.dry_air.visc_mult = 100.0
+    c.bcs[1] = capi.make_bc(2, capi.OUTLET, capi.SUB_P_NR, [101000.0, 0, 0, 0, 0.0, 0.0, 1.0, 0.0])
+    U = c.state(seed=2)
+    forcing = capi.make_forcing(pressure_gradient=(2.0, 0.0, -1.0))
+    dt0, cfl, hmin, nsteps = 2.0e-5, 0.12, 0.05, 6
+    o = Oracle(c.mesh, c.disc, c.physics, c.bcs)
+    o.set_forcing(forcing)
+    ref, t, dt, _ = o.advance(U, 0.0, dt0, nsteps, False, cfl, hmin)
+    results, timings = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TPSRHS_GRAPH", mode)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            op = RHSoperator(c.mesh, c.disc, c.physics, c.bcs, stream=side)
+            op.setForcing(forcing)
+            x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
+            tg, dtg, bad = op.advance(x, 0.0, dt0, nsteps, False, cfl, hmin)
+            results[mode] = (x.cpu().numpy().reshape(U.shape), tg, dtg, bad)
+            # launch-bound regime: many steps of this 144-element mesh, with and without the graph
+            side.synchronize()
+            t0 = time.perf_counter()
+            op.advance(x, 0.0, 1e-12, 200, True)
+            timings[mode] = (time.perf_counter() - t0) / 200
+            op.close()
+    print("per RK4 step: graph %.1f us, launch loop %.1f us" % (1e6 * timings["1"], 1e6 * timings["0"]))
+    g, p = results["1"], results["0"]
+    assert np.array_equal(g[0], p[0]) and g[1:] == p[1:]
+    assert g[1] == pytest.approx(t, rel=1e-13) and g[2] == pytest.approx(dt, rel=1e-12) and g[3] == 0
+    assert rel_maxnorm(g[0], ref).max() < 1e-13

@@ -92,6 +92,17 @@ struct tpsrhs_operator {
   const double *nr_dt_dev = nullptr;  // non-NULL while tpsrhs_advance runs: the boundary conditions read dt there
   tpsrhs_reduce_fn reduce = nullptr;
   void *reduce_ctx = nullptr;
+  // one RK4 step of tpsrhs_advance as an executable graph (dt lives in device memory, so the step replays as is)
+  hipGraphExec_t step_graph = nullptr;
+  struct StepKey {
+    const void *x = nullptr;
+    int constant_dt = 0, bstate_cur = 0, epoch = 0;
+    double coef = 0.0;
+    bool operator==(const StepKey &o) const {
+      return x == o.x && constant_dt == o.constant_dt && bstate_cur == o.bstate_cur && epoch == o.epoch && coef == o.coef;
+    }
+  } step_key;
+  int config_epoch = 0;  // bumped by everything that changes what a step launches (forcing terms, ...)
   // halo
   tpsrhs_halo_fn halo = nullptr;
   void *halo_ctx = nullptr;
@@ -134,6 +145,7 @@ struct tpsrhs_operator {
     if (d_rk) (void)hipFree(d_rk);
     if (d_nan) (void)hipFree(d_nan);
     if (d_forcing) (void)hipFree(d_forcing);
+    if (step_graph) (void)hipGraphExecDestroy(step_graph);
     for (void *p : {static_cast<void *>(d_nr_faces), static_cast<void *>(d_nr_ordinal), static_cast<void *>(d_bstate[0]),
                     static_cast<void *>(d_bstate[1]), static_cast<void *>(d_bc_sums), static_cast<void *>(d_ctl)})
       if (p) (void)hipFree(p);

@@ -512,17 +512,57 @@ int tpsrhs_advance(tpsrhs_handle h, double *x, double *time, double *dt, int num
     HIP_CHECK(hipStreamSynchronize(h->stream));  // ctl0 lives on this stack frame
     if (h->d_nan) HIP_CHECK(hipMemsetAsync(h->d_nan, 0, sizeof(unsigned long long), h->stream));
     h->nr_dt_dev = h->d_ctl;
-    try {
-      for (int step = 0; step < num_steps; step++) {
-        rk4_stages(h, x, 0.0, h->d_ctl);
-        hipLaunchKernelGGL(k_step_end<256>, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_ctl,
-                           constant_dt ? 1 : 0, cfl * hmin / static_cast<double>(h->dim));
-        HIP_CHECK(hipGetLastError());
-        if (!constant_dt && h->reduce) {  // MPI_Allreduce(MIN) of src/M2ulPhyS.cpp:2015
-          if (h->reduce(h->reduce_ctx, h->d_ctl, 1, TPSRHS_REDUCE_MIN, h->stream) != 0)
-            throw std::runtime_error("halo: reduce callback failed");
-        }
+    auto one_step = [&] {
+      rk4_stages(h, x, 0.0, h->d_ctl);
+      hipLaunchKernelGGL(k_step_end<256>, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_ctl,
+                         constant_dt ? 1 : 0, cfl * hmin / static_cast<double>(h->dim));
+      HIP_CHECK(hipGetLastError());
+      if (!constant_dt && h->reduce && h->topo.num_shared > 0) {  // MPI_Allreduce(MIN) of src/M2ulPhyS.cpp:2015
+        if (h->reduce(h->reduce_ctx, h->d_ctl, 1, TPSRHS_REDUCE_MIN, h->stream) != 0)
+          throw std::runtime_error("halo: reduce callback failed");
       }
+    };
+    // On one rank a step is a fixed sequence of ~17 launches whose arguments do not change from step to step (dt
+    // and the time are in device memory; the two boundary-state buffers swap four times per step): captured once
+    // into a hipGraph and replayed -- the launch overhead matters on small meshes.  Needs a capturable stream (not
+    // the NULL stream), no host callbacks in the step (partitioned meshes keep the plain loop), no timing events.
+    const char *genv = std::getenv("TPSRHS_GRAPH");
+    const bool use_graph = h->stream != nullptr && h->topo.num_shared == 0 && !h->timing && num_steps >= 3 &&
+                           !(genv && genv[0] == '0');
+    try {
+      int step = 0;
+      if (use_graph) {
+        one_step();  // first step outside the graph: allocations, initial boundary state
+        step = 1;
+        tpsrhs_operator::StepKey key;
+        key.x = x;
+        key.constant_dt = constant_dt ? 1 : 0;
+        key.bstate_cur = h->bstate_cur;
+        key.epoch = h->config_epoch;
+        key.coef = cfl * hmin / static_cast<double>(h->dim);
+        if (!h->step_graph || !(h->step_key == key)) {
+          if (h->step_graph) {
+            HIP_CHECK(hipGraphExecDestroy(h->step_graph));
+            h->step_graph = nullptr;
+          }
+          hipGraph_t g = nullptr;
+          HIP_CHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+          try {
+            one_step();
+          } catch (...) {
+            (void)hipStreamEndCapture(h->stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            throw;
+          }
+          HIP_CHECK(hipStreamEndCapture(h->stream, &g));
+          const hipError_t ie = hipGraphInstantiate(&h->step_graph, g, nullptr, nullptr, 0);
+          (void)hipGraphDestroy(g);
+          HIP_CHECK(ie);
+          h->step_key = key;
+        }
+        for (; step < num_steps; step++) HIP_CHECK(hipGraphLaunch(h->step_graph, h->stream));
+      }
+      for (; step < num_steps; step++) one_step();
     } catch (...) {
       h->nr_dt_dev = nullptr;
       throw;
@@ -612,6 +652,7 @@ int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *in) {
       }
     }
     h->forcing = f;
+    h->config_epoch++;
     upload_forcing(h);
   });
 }
@@ -622,6 +663,7 @@ int tpsrhs_set_joule_heating(tpsrhs_handle h, const double *joule_heating) {
     // JouleHeating::updateTerms asserts nvel == 3 (src/forcing_terms.cpp:444)
     if (joule_heating && h->nvel != 3) throw Unsupported("JouleHeating needs three velocity components (3-D or axisymmetric)");
     h->forcing.joule = joule_heating;
+    h->config_epoch++;
     upload_forcing(h);
   });
 }
