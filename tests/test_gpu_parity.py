@@ -230,3 +230,30 @@ def test_roe_flux_unsupported_in_3d():
     with pytest.raises(TpsRhsError) as e:
         RHSoperator(c.mesh, c.disc, c.physics, c.bcs)
     assert "UNSUPPORTED" in str(e.value)
+
+
+@pytest.mark.parametrize("levels,ambipolar,geo,order,two_t,transport", [
+    (1, True, "3d", 2, False, capi.ARGON_MIXTURE),   # four species, ambipolar (the count of perfectGas.argon.ini)
+    (2, True, "axisym", 3, True, capi.CONSTANT),     # five species, ambipolar (the count of perfectGas.air.ini)
+    (2, False, "3d", 1, True, capi.ARGON_MIXTURE),   # five species with an electron equation (input.malamas.test.ini)
+    (2, False, "2d", 3, True, capi.CONSTANT),
+    (1, True, "2d", 2, True, capi.ARGON_MIXTURE),
+])
+def test_plasma_four_and_five_species(levels, ambipolar, geo, order, two_t, transport):
+    ph = capi.argon_levels_physics(levels, ambipolar, capi.NS, transport, two_t, True, radiation=(geo == "axisym"),
+                                   third_order_ke=False)
+    _boost_transport(ph, 30.0)
+    amp = 0.005 if order == 1 else 0.01
+    if geo == "axisym":
+        c = cases.argon_axisym(6, 8, order, physics=ph, r_in=0.0)
+        U = c.state(seed=9, amp=amp)
+        mesh, disc, bcs = c.mesh, c.disc, c.bcs
+    elif geo == "3d":
+        c = cases.argon_cyl3d(4, 12, 3, order, physics=ph)
+        U = c.state(seed=9, amp=amp)
+        mesh, disc, bcs = c.mesh, c.disc, c.bcs
+    else:
+        mesh = meshgen.scramble_orientations(meshgen.box_quad(6, 5, lengths=(1.0, 0.7), warp=0.08), 3)
+        disc, bcs = capi.Disc(order, 0, 0, 0, 0), []
+        U = cases.plasma_state(node_coordinates(mesh, order), ph, nvel=2, seed=9, amp=amp)
+    _compare(mesh, disc, ph, bcs, U, tol=_tol(amp))

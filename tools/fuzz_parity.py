@@ -19,7 +19,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = 0.0
 t0 = time.time()
 for it in range(ncases):
-    fluid = rng.choice(["dry", "argon3", "argon3n", "argon6"], p=[0.35, 0.35, 0.1, 0.2])
+    fluid = rng.choice(["dry", "argon3", "argon3n", "argon6", "argon4a", "argon5a", "argon5"],
+                       p=[0.25, 0.25, 0.08, 0.15, 0.09, 0.09, 0.09])
     geo = rng.choice(["cyl3d", "box3d", "box2d", "axisym"])
     order = int(rng.integers(1, (6 if geo != "axisym" else 5) if fluid == "dry" else 4))
     eq = capi.NS if rng.random() < 0.85 else capi.EULER
@@ -32,10 +33,11 @@ for it in range(ncases):
         ph = capi.dry_air_physics(eq, visc_mult=float(rng.choice([1.0, 50.0, 1000.0])), bulk_visc_mult=float(rng.random()))
     else:
         two_t = bool(rng.random() < 0.5)
-        if fluid == "argon6":
-            ph = capi.argon_six_species_physics(eq, int(rng.choice([capi.CONSTANT, capi.ARGON_MIXTURE])), two_t,
-                                                bool(rng.random() < 0.7), radiation=bool(rng.random() < 0.5),
-                                                third_order_ke=False)
+        if fluid in ("argon6", "argon4a", "argon5a", "argon5"):
+            levels, ambi = {"argon6": (3, False), "argon4a": (1, True), "argon5a": (2, True), "argon5": (2, False)}[fluid]
+            ph = capi.argon_levels_physics(levels, ambi, eq, int(rng.choice([capi.CONSTANT, capi.ARGON_MIXTURE])), two_t,
+                                           bool(rng.random() < 0.7), radiation=bool(rng.random() < 0.5),
+                                           third_order_ke=False)
         else:
             tr = int(rng.choice([capi.CONSTANT, capi.ARGON_MINIMAL, capi.ARGON_MIXTURE]))
             ph = capi.argon_ternary_physics(eq, two_t, tr, rng.choice(["arrhenius", "tabulated", "balance", None]),

@@ -277,23 +277,27 @@ def argon_ternary_physics(eq_system=NS, two_temperature=False, transport=ARGON_M
     return ph
 
 
-def argon_six_species_physics(eq_system=NS, transport=CONSTANT, two_temperature=True, reactions=True,
-                              radiation=False, third_order_ke=True) -> Physics:
-    """The mixture of the reference's torch input test/inputs/plasma.ini:200-275: Ar (background), E, Ar.+1 and
-    the excited levels Ar_m, Ar_r, Ar_p; NOT ambipolar (the electron density has its own equation),
-    two-temperature.  Mixture order: Ar.+1, Ar_m, Ar_r, Ar_p, E, Ar.  Transport: constant coefficients or
-    the argon collision table (every neutral-neutral pair AR_AR, neutral-ion AR_AR1P, neutral-electron AR_E)."""
+def argon_levels_physics(levels=3, ambipolar=False, eq_system=NS, transport=CONSTANT, two_temperature=True, reactions=True,
+                         radiation=False, third_order_ke=True) -> Physics:
+    """Argon with `levels` (0..3) excited neutral levels: mixture order Ar.+1, [Ar_m, Ar_r, Ar_p][:levels], E, Ar.
+    levels = 3, not ambipolar: the mixture of the reference's torch input test/inputs/plasma.ini:200-275;
+    levels = 2, not ambipolar: the five species of test/inputs/input.malamas.test.ini; the ambipolar variants drop
+    the electron equation (four species: the count of test/inputs/perfectGas.argon.ini).  Transport: constant
+    coefficients or the argon collision table (every neutral-neutral pair AR_AR, neutral-ion AR_AR1P,
+    neutral-electron AR_E)."""
     ph = Physics()
     ph.eq_system = eq_system
     ph.working_fluid = USER_DEFINED
     m_ar, m_e = 39.948e-3, 5.48579908782496e-7
-    nsp = 6
+    nsp = 3 + levels
+    ie, ib = nsp - 2, nsp - 1
     mx = ph.mixture
-    mx.num_species, mx.is_electron_included, mx.ambipolar, mx.two_temperature = nsp, 1, 0, int(two_temperature)
-    mw = [m_ar - m_e, m_ar, m_ar, m_ar, m_e, m_ar]
-    charge = [1.0, 0.0, 0.0, 0.0, -1.0, 0.0]
-    eform = [1520571.3883, 1116860.96186, 1130867.391486, 1269949.8858896866, 0.0, 0.0]
-    degen = [4.0, 6.0, 6.0, 36.0, 1.0, 1.0]
+    mx.num_species, mx.is_electron_included, mx.ambipolar, mx.two_temperature = nsp, 1, int(ambipolar), int(two_temperature)
+    lv = list(range(1, 1 + levels))  # mixture indices of the excited levels
+    mw = [m_ar - m_e] + [m_ar] * levels + [m_e, m_ar]
+    charge = [1.0] + [0.0] * levels + [-1.0, 0.0]
+    eform = [1520571.3883] + [1116860.96186, 1130867.391486, 1269949.8858896866][:levels] + [0.0, 0.0]
+    degen = [4.0] + [6.0, 6.0, 36.0][:levels] + [1.0, 1.0]
     for sp in range(nsp):
         mx.gas_params[sp + SPECIES_MW * nsp] = mw[sp]
         mx.gas_params[sp + SPECIES_CHARGES * nsp] = charge[sp]
@@ -304,13 +308,13 @@ def argon_six_species_physics(eq_system=NS, transport=CONSTANT, two_temperature=
     ct = ph.constant_transport
     ct.viscosity, ct.bulk_viscosity = 5.0e-5, 1.0e-5
     ct.thermal_conductivity, ct.electron_thermal_conductivity = 0.05, 0.2
-    for sp, (d, f) in enumerate([(3.0e-3, 1.0e9), (2.6e-3, 3.0e8), (2.7e-3, 3.5e8), (2.8e-3, 3.2e8), (2.0e-1, 0.0),
-                                 (2.5e-3, 4.0e8)]):
+    df = [(3.0e-3, 1.0e9)] + [(2.6e-3, 3.0e8), (2.7e-3, 3.5e8), (2.8e-3, 3.2e8)][:levels] + [(2.0e-1, 0.0), (2.5e-3, 4.0e8)]
+    for sp, (d, f) in enumerate(df):
         ct.diffusivity[sp], ct.mt_freq[sp] = d, f
-    ct.electron_index = 4
+    ct.electron_index = ie
     gt = ph.gas_transport
-    gt.neutral_index, gt.ion_index, gt.electron_index = 5, 0, 4
-    kinds = ["ion", "n", "n", "n", "e", "n"]
+    gt.neutral_index, gt.ion_index, gt.electron_index = ib, 0, ie
+    kinds = ["ion"] + ["n"] * levels + ["e", "n"]
     rule = {("ion", "ion"): CLMB_REP, ("ion", "n"): AR_AR1P, ("ion", "e"): CLMB_ATT, ("n", "n"): AR_AR, ("n", "e"): AR_E,
             ("e", "e"): CLMB_REP, ("n", "ion"): AR_AR1P, ("e", "ion"): CLMB_ATT, ("e", "n"): AR_E}
     for i in range(nsp):
@@ -322,22 +326,24 @@ def argon_six_species_physics(eq_system=NS, transport=CONSTANT, two_temperature=
         gt.flux_trns_multiplier[k] = 1.0
     gt.spcs_trns_multiplier[0] = gt.diff_mult = gt.mobil_mult = 1.0
     ch = ph.chemistry
-    ch.electron_index = 4
+    ch.electron_index = ie
     ch.minimum_temperature = 2000.0
     if reactions:
-        # (reactants, products) in mixture order (Ar.+1, Ar_m, Ar_r, Ar_p, E, Ar); Arrhenius A, b, E; energy
-        rxn = [((0, 0, 0, 0, 1, 1), (1, 0, 0, 0, 2, 0), (74072.331348, 1.511, 1176329.772504), 1520571.3883, 0),
-               ((0, 0, 0, 0, 1, 1), (0, 1, 0, 0, 1, 0), (2.1e4, 1.2, 9.1e5), 1116860.96186, 1),
-               ((0, 1, 0, 0, 1, 0), (1, 0, 0, 0, 2, 0), (5.6e5, 0.9, 3.3e5), 403710.42644, 0),
-               ((0, 0, 1, 0, 0, 1), (0, 1, 0, 0, 0, 1), (3.0e2, 0.5, 2.0e4), -14006.429626, 0)]
+        # species by name -> stoichiometry in mixture order; Arrhenius A, b, E; energy; detailed balance
+        names = ["ion"] + ["m", "r", "p"][:levels] + ["e", "ar"]
+        rxn = [({"e": 1, "ar": 1}, {"ion": 1, "e": 2}, (74072.331348, 1.511, 1176329.772504), 1520571.3883, 0),
+               ({"e": 1, "ar": 1}, {"m": 1, "e": 1}, (2.1e4, 1.2, 9.1e5), 1116860.96186, 1),
+               ({"m": 1, "e": 1}, {"ion": 1, "e": 2}, (5.6e5, 0.9, 3.3e5), 403710.42644, 0),
+               ({"r": 1, "ar": 1}, {"m": 1, "ar": 1}, (3.0e2, 0.5, 2.0e4), -14006.429626, 0)]
+        rxn = [r for r in rxn if all(k in names for k in list(r[0]) + list(r[1]))]
         ch.num_reactions = len(rxn)
         for r, (re_, pr, abe, en, db) in enumerate(rxn):
             ch.reaction_energies[r] = en
             ch.detailed_balance[r] = db
             ch.reaction_models[r] = ARRHENIUS
             for sp in range(nsp):
-                ch.reactant_stoich[sp + r * nsp] = re_[sp]
-                ch.product_stoich[sp + r * nsp] = pr[sp]
+                ch.reactant_stoich[sp + r * nsp] = re_.get(names[sp], 0)
+                ch.product_stoich[sp + r * nsp] = pr.get(names[sp], 0)
             for k in range(3):
                 ch.rate_params[k + r * MAXCHEMPARAMS] = abe[k]
             if db:
@@ -350,6 +356,13 @@ def argon_six_species_physics(eq_system=NS, transport=CONSTANT, two_temperature=
         ph.radiation.nec_table = make_table(T, 1.0e9 * np.exp(-8.0e4 / T), False, False, keep)
     ph._keep = keep
     return ph
+
+
+def argon_six_species_physics(eq_system=NS, transport=CONSTANT, two_temperature=True, reactions=True,
+                              radiation=False, third_order_ke=True) -> Physics:
+    """The mixture of the reference's torch input test/inputs/plasma.ini:200-275: Ar (background), E, Ar.+1 and
+    the excited levels Ar_m, Ar_r, Ar_p; NOT ambipolar (the electron density has its own equation)."""
+    return argon_levels_physics(3, False, eq_system, transport, two_temperature, reactions, radiation, third_order_ke)
 
 
 def make_bc(attribute, category, bc_type, data=()) -> BC:

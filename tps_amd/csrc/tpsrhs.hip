@@ -15,6 +15,9 @@
 DECL(pick_plasma_3d_n3a); DECL(pick_plasma_3d_n3); DECL(pick_plasma_3d_n6);
 DECL(pick_plasma_2d_n3a); DECL(pick_plasma_2d_n3); DECL(pick_plasma_2d_n6);
 DECL(pick_plasma_axi_n3a); DECL(pick_plasma_axi_n3); DECL(pick_plasma_axi_n6);
+DECL(pick_plasma_3d_n4a); DECL(pick_plasma_3d_n5a); DECL(pick_plasma_3d_n5);
+DECL(pick_plasma_2d_n4a); DECL(pick_plasma_2d_n5a); DECL(pick_plasma_2d_n5);
+DECL(pick_plasma_axi_n4a); DECL(pick_plasma_axi_n5a); DECL(pick_plasma_axi_n5);
 #undef DECL
 void pick_dryair_axisym(tpsrhs_operator *op);
 
@@ -203,10 +206,12 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   if (plasma) {
     const tpsrhs_perfect_mixture &mx = phys->mixture;
     if (!mx.is_electron_included) throw Unsupported("USER_DEFINED fluids without electrons are not built");
-    const bool fam = (mx.num_species == 3) || (mx.num_species == 6 && !mx.ambipolar);
+    const bool fam = (mx.num_species == 3) || (mx.num_species == 6 && !mx.ambipolar) || (mx.num_species == 4 && mx.ambipolar) ||
+                     (mx.num_species == 5);
     if (!fam)
-      throw Unsupported("USER_DEFINED fluids: built species counts are 3 (ambipolar or not) and 6 (not ambipolar)");
-    if (mx.num_species == 6 && phys->transport_model == TPSRHS_ARGON_MINIMAL)
+      throw Unsupported("USER_DEFINED fluids: built species counts are 3 and 5 (ambipolar or not), 4 (ambipolar) and "
+                        "6 (not ambipolar)");
+    if (mx.num_species != 3 && phys->transport_model == TPSRHS_ARGON_MINIMAL)
       throw Unsupported("argon_minimal transport is the ternary (Ar, Ar.+1, E) model");
     if (phys->transport_model != TPSRHS_CONSTANT && phys->transport_model != TPSRHS_ARGON_MINIMAL &&
         phys->transport_model != TPSRHS_ARGON_MIXTURE)
@@ -244,19 +249,25 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   if (plasma) {
     const int nsp = phys->mixture.num_species;
     const bool ambi = phys->mixture.ambipolar != 0, two_t = phys->mixture.two_temperature != 0;
-    if (nsp == 3)
-      fill_plasma_params<3>(op, disc, phys, num_bcs, bcs);
-    else
-      fill_plasma_params<6>(op, disc, phys, num_bcs, bcs);
+    switch (nsp) {
+      case 3: fill_plasma_params<3>(op, disc, phys, num_bcs, bcs); break;
+      case 4: fill_plasma_params<4>(op, disc, phys, num_bcs, bcs); break;
+      case 5: fill_plasma_params<5>(op, disc, phys, num_bcs, bcs); break;
+      default: fill_plasma_params<6>(op, disc, phys, num_bcs, bcs); break;
+    }
     const int tr = (phys->transport_model == TPSRHS_CONSTANT)
                        ? TRANSPORT_CONSTANT
                        : (phys->transport_model == TPSRHS_ARGON_MINIMAL ? TRANSPORT_ARGON_MINIMAL : TRANSPORT_ARGON_MIXTURE);
     typedef void (*pick_fn)(tpsrhs_operator *, bool, int);
-    const pick_fn table[3][3] = {{pick_plasma_3d_n3a, pick_plasma_3d_n3, pick_plasma_3d_n6},
-                                 {pick_plasma_2d_n3a, pick_plasma_2d_n3, pick_plasma_2d_n6},
-                                 {pick_plasma_axi_n3a, pick_plasma_axi_n3, pick_plasma_axi_n6}};
+    // families: 3 species (ambipolar / not), 6 (not), and the other counts of the reference's M2ulPhyS inputs --
+    // 4 ambipolar (test/inputs/perfectGas.argon.ini), 5 ambipolar (perfectGas.air.ini), 5 not (input.malamas.test.ini)
+    const pick_fn table[3][6] = {
+        {pick_plasma_3d_n3a, pick_plasma_3d_n3, pick_plasma_3d_n6, pick_plasma_3d_n4a, pick_plasma_3d_n5a, pick_plasma_3d_n5},
+        {pick_plasma_2d_n3a, pick_plasma_2d_n3, pick_plasma_2d_n6, pick_plasma_2d_n4a, pick_plasma_2d_n5a, pick_plasma_2d_n5},
+        {pick_plasma_axi_n3a, pick_plasma_axi_n3, pick_plasma_axi_n6, pick_plasma_axi_n4a, pick_plasma_axi_n5a,
+         pick_plasma_axi_n5}};
     const int geo = (op->dim == 3) ? 0 : (disc->axisymmetric ? 2 : 1);
-    const int fam = (nsp == 6) ? 2 : (ambi ? 0 : 1);
+    const int fam = (nsp == 6) ? 2 : (nsp == 4) ? 3 : (nsp == 5) ? (ambi ? 4 : 5) : (ambi ? 0 : 1);
     table[geo][fam](op, two_t, tr);
   } else {
     DryAirParams &d = *new (op->params) DryAirParams;
