@@ -292,9 +292,10 @@ __device__ inline void face_geometry(const double *V, const Tab<C> &tab, int s, 
 // traces on both faces of direction D of NFLD nodal fields F[fld][NODES]: one lane per line
 template <class C, int D, int NFLD>
 __device__ inline void trace_lines(const double *F, double *T, const Tables1D &ct, int tid) {
-  constexpr int sd = stride_of<C>(D);
-  constexpr int sa = stride_of<C>(tan_a<C>(D));
-  constexpr int sb = (C::DIM == 3) ? stride_of<C>(tan_b<C>(D)) : 0;
+  constexpr int DD = ((TPSRHS_ABLATE & 64) && C::DIM == 3 && D == 1) ? 2 : D;  // timing experiment: conflict-free pattern
+  constexpr int sd = stride_of<C>(DD);
+  constexpr int sa = stride_of<C>(tan_a<C>(DD));
+  constexpr int sb = (C::DIM == 3) ? stride_of<C>(tan_b<C>(DD)) : 0;
   for (int item = tid; item < NFLD * C::LN; item += C::BLOCK) {
     const int fld = item / C::LN, r = item - fld * C::LN;
     const int le = r / C::NF, ln = r - le * C::NF;
@@ -931,8 +932,9 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
       double dr[DIM];
 #pragma unroll
       for (int mm = 0; mm < DIM; mm++) {
-        const int sd = stride_of<C>(mm);
-        const double *F = &sUp[eq * C::NODES + le_n * C::NPE + nd - idx[mm] * sd];
+        const int m2 = ((TPSRHS_ABLATE & 128) && DIM == 3) ? 2 : mm;  // timing experiment
+        const int sd = stride_of<C>(m2);
+        const double *F = &sUp[eq * C::NODES + le_n * C::NPE + nd - idx[m2] * sd];
         double acc = 0.0;
 #pragma unroll
         for (int a = 0; a < C::N1; a++) acc += Dr[mm][a] * ldsr(&F[a * sd]);
@@ -1641,8 +1643,9 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
       double acc = 0.0;
 #pragma unroll
       for (int mm = 0; mm < DIM; mm++) {
-        const int sd = stride_of<C>(mm);
-        const double *F = &sGf[(eq + mm * NEQ) * C::NODES + le_n * C::NPE + nd - idx[mm] * sd];
+        const int m2 = ((TPSRHS_ABLATE & 128) && DIM == 3) ? 2 : mm;  // timing experiment
+        const int sd = stride_of<C>(m2);
+        const double *F = &sGf[(eq + mm * NEQ) * C::NODES + le_n * C::NPE + nd - idx[m2] * sd];
 #pragma unroll
         for (int a = 0; a < C::N1; a++) acc += Dc[mm][a] * ldsr(&F[a * sd]);
       }
