@@ -210,6 +210,25 @@ def main():
         ktimes = op.kernel_times()  # ms, averaged over the timed Mults
         op.enable_kernel_timing(False)
         finite = bool(torch.isfinite(y).all().item())
+        comm_exposed_ms = None
+        if world > 1 and halo is not None:
+            # exposed communication: the same partitioned launches with the exchange switched off
+            # (stale halo traces: timing only), max over ranks like the main number
+            halo.skip = True
+            for _ in range(2):
+                op.Mult(x, y)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                op.Mult(x, y)
+            torch.cuda.synchronize()
+            barrier()
+            dt_nc = time.perf_counter() - t1
+            halo.skip = False
+            t = torch.tensor([dt_nc], dtype=torch.float64, device=op.device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            comm_exposed_ms = 1e3 * (dt - float(t.item())) / steps
         rk4 = None
         if world == 1 and wname == args.workload:
             # next row of the scope table: the RK4 time loop on the device (tpsrhs_advance),
@@ -246,7 +265,8 @@ def main():
                                     f"p={order}, GL basis + GL rule, {description}"),
                        "elements_per_gpu": mesh.num_elements, "nodes_per_gpu": ndofs, "num_equation": neq,
                        "partition": "spanwise slabs, RCCL send/recv of face traces" if world > 1 else "single GPU"},
-            "rhs_evals_per_s": evals_per_s, "kernel_ms": ktimes, "finite": finite, "time_loop": rk4,
+            "rhs_evals_per_s": evals_per_s, "mnodes_per_s": world * ndofs * evals_per_s / 1e6, "kernel_ms": ktimes,
+            "finite": finite, "time_loop": rk4, "comm_exposed_ms": comm_exposed_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_node": alg[dom],
@@ -272,11 +292,14 @@ def main():
             "value": res["value"], "unit": "MDOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "config": res["config"],
-            "rhs_evals_per_s": res["rhs_evals_per_s"], "kernel_ms": res["kernel_ms"], "finite": res["finite"],
+            "rhs_evals_per_s": res["rhs_evals_per_s"], "mnodes_per_s": res["mnodes_per_s"], "kernel_ms": res["kernel_ms"],
+            "finite": res["finite"],
             "roofline": res["roofline"],
         }
         if res.get("time_loop"):
             out["time_loop"] = res["time_loop"]
+        if res.get("comm_exposed_ms") is not None:
+            out["comm_exposed_ms"] = res["comm_exposed_ms"]  # ms_per_step minus the same launches without the exchange
         if others:
             out["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:

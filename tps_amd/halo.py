@@ -37,6 +37,7 @@ class HaloExchange:
         self.host_buffers = host_buffers  # True: pointers handed to callback are HOST memory (CPU rehearsal)
         self.bytes_sent = 0
         self.calls = 0
+        self.skip = False  # timing experiments only: return without exchanging (the halo then holds stale traces)
         self._plans = {}
 
     def _view(self, ptr, n):
@@ -49,6 +50,8 @@ class HaloExchange:
         """Everything is enqueued on `stream` (the operator's communication stream): the pack kernel ran
         there, the sends/receives are ordered after it, and the operator makes its compute stream wait
         for an event recorded after this returns -- no host synchronisation with the nccl backend."""
+        if self.skip:
+            return 0
         try:
             if not self.host_buffers and torch.cuda.is_available():
                 with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0), device=self.device)):
