@@ -60,3 +60,51 @@ def manufactured(X, viscous=True, visc_mult=1.0, bulk_mult=0.0, lengths=(1.0, 1.
 
 def observed_order(err_coarse, err_fine):
     return np.log2(np.asarray(err_coarse) / np.asarray(err_fine))
+
+
+@functools.lru_cache(maxsize=None)
+def _build_axisym(visc_mult, bulk_mult, lz):
+    """Compressible Navier-Stokes in cylindrical coordinates (r, z) with swirl; state order of the reference's
+    axisymmetric formulation: rho, rho u_r, rho u_z, rho u_theta, rho E."""
+    import sympy as sp
+
+    r, z = sp.symbols("r z", positive=True)
+    k = 2 * sp.pi / lz
+    rho = 1.2 + 0.10 * sp.sin(k * z) * sp.cos(9.0 * r) + 0.05 * sp.sin(14.0 * r)
+    ur = 4.0 * sp.sin(11.0 * r) * sp.cos(k * z + 0.3)
+    uz = 30.0 + 8.0 * sp.cos(8.0 * r) * sp.sin(k * z)
+    ut = 6.0 * sp.sin(7.0 * r + 0.4) * (1 + 0.3 * sp.cos(k * z))
+    p = 101300.0 * (1 + 0.04 * sp.cos(10.0 * r - 0.4) * sp.sin(k * z))
+    T = p / (rho * RG)
+    E = p / (GAMMA - 1) + rho * (ur * ur + uz * uz + ut * ut) / 2
+    mu = C1 * visc_mult * T ** sp.Rational(3, 2) / (T + S0)
+    mub = bulk_mult * mu - sp.Rational(2, 3) * mu
+    kap = mu * GAMMA * RG / ((GAMMA - 1) * PR)
+    div = sp.diff(r * ur, r) / r + sp.diff(uz, z)
+    trr = 2 * mu * sp.diff(ur, r) + mub * div
+    tzz = 2 * mu * sp.diff(uz, z) + mub * div
+    ttt = 2 * mu * ur / r + mub * div
+    trz = mu * (sp.diff(ur, z) + sp.diff(uz, r))
+    trt = mu * (sp.diff(ut, r) - ut / r)
+    tzt = mu * sp.diff(ut, z)
+
+    def dv(fr, fz):  # divergence of an (r, z) flux in cylindrical coordinates
+        return sp.diff(r * fr, r) / r + sp.diff(fz, z)
+
+    rhs = [-dv(rho * ur, rho * uz),
+           -dv(rho * ur * ur + p - trr, rho * ur * uz - trz) + (p - ttt + rho * ut * ut) / r,
+           -dv(rho * ur * uz - trz, rho * uz * uz + p - tzz),
+           -dv(rho * ur * ut - trt, rho * uz * ut - tzt) - (rho * ur * ut - trt) / r,
+           -dv(ur * (E + p) - (trr * ur + trz * uz + trt * ut) - kap * sp.diff(T, r),
+               uz * (E + p) - (trz * ur + tzz * uz + tzt * ut) - kap * sp.diff(T, z))]
+    U = [rho, rho * ur, rho * uz, rho * ut, E]
+    return sp.lambdify((r, z), U, "numpy"), sp.lambdify((r, z), rhs, "numpy")
+
+
+def manufactured_axisym(X, visc_mult=1.0, bulk_mult=0.0, lz=1.0):
+    """X: (r, z) node coordinates (2, N) -> (U, exact dU/dt), both (5, N)"""
+    fu, fr = _build_axisym(float(visc_mult), float(bulk_mult), float(lz))
+    bc = np.zeros(X.shape[1])
+    U = np.array([np.asarray(v, dtype=np.float64) + bc for v in fu(X[0], X[1])])
+    R = np.array([np.asarray(v, dtype=np.float64) + bc for v in fr(X[0], X[1])])
+    return U, R

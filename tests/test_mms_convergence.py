@@ -74,3 +74,55 @@ def test_hip_converges_to_the_pde(dim, order, eq, n, warp):
     # O(h^p) for the equations as a set; a single equation may lag at high order on these coarse pairs (the BR1
     # treatment of the heat flux in the energy equation at p = 5: 3.7)
     assert np.median(rate) > order - 0.35 and rate.min() > order - 1.5
+
+
+def _axisym_errors(run, order, n, visc_mult, eq=capi.NS):
+    """Annulus r in [0.1, 0.4], periodic in z; inviscid walls at both radii.  The residual of an element depends on
+    its neighbours' neighbours at most, so the elements three or more layers away from the walls see only the
+    scheme and the manufactured state."""
+    lz = 0.5
+    attrs = {(0, 0): 3, (0, 1): 3}
+    mesh = meshgen.box_quad(n, n, lengths=(0.3, lz), periodic=(False, True), bdr_attr=attrs, origin=(0.1, 0.0))
+    from mms_util import manufactured_axisym
+
+    X = node_coordinates(mesh, order)
+    U, R = manufactured_axisym(X, visc_mult, 0.6, lz)
+    ph = capi.dry_air_physics(eq, visc_mult=visc_mult, bulk_visc_mult=0.6)
+    y = run(mesh, capi.Disc(order, 0, 0, 1, 0), ph, [capi.make_bc(3, capi.WALL, capi.INV)], U)
+    h = 0.3 / n
+    inner = (X[0] > 0.1 + 3 * h) & (X[0] < 0.4 - 3 * h)
+    return np.sqrt(((y - R)[:, inner] ** 2).mean(axis=1) / (R[:, inner] ** 2).mean(axis=1))
+
+
+@pytest.mark.parametrize("order,n", [(1, 12), (2, 8)])
+def test_oracle_axisymmetric_converges_to_the_cylindrical_equations(order, n):
+    from oracle_lib import Oracle
+
+    def run(mesh, disc, ph, bcs, U):
+        return Oracle(mesh, disc, ph, bcs).mult(U)
+
+    e1, e2 = _axisym_errors(run, order, n, 3.0e4), _axisym_errors(run, order, 2 * n, 3.0e4)
+    rate = observed_order(e1, e2)
+    print("relative RMS errors", e1, "->", e2, "observed order", rate)
+    assert np.median(rate) > order - 0.35 and rate.min() > order - 0.8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order,n", [(1, 16), (2, 12), (3, 10), (4, 8)])
+def test_hip_axisymmetric_converges_to_the_cylindrical_equations(order, n):
+    import torch
+    from tps_amd.rhs_operator import RHSoperator
+
+    def run(mesh, disc, ph, bcs, U):
+        op = RHSoperator(mesh, disc, ph, bcs)
+        x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
+        y = torch.empty_like(x)
+        op.Mult(x, y)
+        y = y.cpu().numpy().reshape(U.shape)
+        op.close()
+        return y
+
+    e1, e2 = _axisym_errors(run, order, n, 3.0e4), _axisym_errors(run, order, 2 * n, 3.0e4)
+    rate = observed_order(e1, e2)
+    print("relative RMS errors", e1, "->", e2, "observed order", rate)
+    assert np.median(rate) > order - 0.35 and rate.min() > order - 1.0
