@@ -231,6 +231,7 @@ typedef struct tpsrhs_bc {
    *   face (src/outletBC.cpp:160-172; all zero: the library takes an edge of its own first face of the patch --
    *   the boundary term does not depend on the choice for a planar patch) and data[7] = the total patch area
    *   `area_` over all ranks (src/outletBC.cpp:329-343; mass-flow types only).
+   * wall INV, SLIP, VISC_ADIAB: no data                    (src/wallBC.cpp:277-469)
    * wall VISC_ISOTH:    T_wall                             (src/wallBC.cpp:96-111)
    * wall VISC_GNRL:     T_h, T_e, heavy thermal condition, electron thermal condition (WallData,
    *                     src/dataStructures.hpp:564-570; tpsrhs_thermal_condition)  (src/wallBC.cpp:112-148) */

@@ -679,6 +679,13 @@ class BoundaryCondition {
             if (m->twoTemperature) bcFlux.primFluxIdxs[numSpecies + nvel + 1] = true;
           }
           break;
+        case TPSRHS_SLIP:  // src/wallBC.cpp:77-85
+          for (int i = 0; i < numSpecies; i++) bcFlux.primFluxIdxs[i] = true;
+          if (axisym) {
+            bcFlux.primFluxIdxs[numSpecies + nvel] = true;
+            if (m->twoTemperature) bcFlux.primFluxIdxs[numSpecies + nvel + 1] = true;
+          }
+          break;
         case TPSRHS_VISC_ADIAB:
           for (int i = 0; i < numSpecies; i++) bcFlux.primFluxIdxs[i] = true;
           bcFlux.primFluxIdxs[numSpecies + nvel] = true;
@@ -916,6 +923,73 @@ class BoundaryCondition {
       return;
     }
     switch (type) {
+      case TPSRHS_SLIP: {  // computeSlipWallFlux, src/wallBC.cpp:326-428: mirror the normal velocity in a wall frame
+        double vel[MAXDIM];
+        for (int d = 0; d < nvel; d++) vel[d] = stateIn[1 + d] / stateIn[0];
+        const double sml = 1.0e-15;
+        double unitNorm[3] = {0, 0, 0}, tangent1[3] = {0, 0, 0}, tangent2[3] = {0, 0, 0};
+        double normN = 0.;
+        for (int d = 0; d < dim; d++) normN += normal[d] * normal[d];
+        normN = std::sqrt(std::max(normN, sml));
+        for (int d = 0; d < dim; d++) unitNorm[d] = normal[d] / normN;
+        int dir = 0;
+        if (dim == 3) {
+          if (std::abs(unitNorm[0]) >= std::abs(unitNorm[1]) && std::abs(unitNorm[0]) >= std::abs(unitNorm[2])) dir = 0;
+          if (std::abs(unitNorm[1]) >= std::abs(unitNorm[0]) && std::abs(unitNorm[1]) >= std::abs(unitNorm[2])) dir = 1;
+          if (std::abs(unitNorm[2]) >= std::abs(unitNorm[0]) && std::abs(unitNorm[2]) >= std::abs(unitNorm[1])) dir = 2;
+        } else {
+          if (std::abs(unitNorm[0]) >= std::abs(unitNorm[1])) dir = 0;
+          if (std::abs(unitNorm[1]) >= std::abs(unitNorm[0])) dir = 1;
+        }
+        const int next_dir = (dir + 1) % dim, previous_dir = (dir + 2) % dim;
+        tangent1[next_dir] = +1.;
+        tangent1[previous_dir] = -1.;  // (2-D: previous_dir == dir, overwritten below, as in the reference)
+        tangent1[dir] = unitNorm[previous_dir] * tangent1[previous_dir] + unitNorm[next_dir] * tangent1[next_dir];
+        tangent1[dir] *= -1. / unitNorm[dir];
+        double mod = 0.;
+        for (int d = 0; d < dim; d++) mod += tangent1[d] * tangent1[d];
+        for (int d = 0; d < dim; d++) tangent1[d] *= 1. / std::max(std::sqrt(mod), sml);
+        if (dim == 3) {
+          tangent2[0] = +(unitNorm[1] * tangent1[2] - unitNorm[2] * tangent1[1]);
+          tangent2[1] = -(unitNorm[0] * tangent1[2] - unitNorm[2] * tangent1[0]);
+          tangent2[2] = +(unitNorm[0] * tangent1[1] - unitNorm[1] * tangent1[0]);
+          mod = 0.;
+          for (int d = 0; d < dim; d++) mod += tangent2[d] * tangent2[d];
+          for (int d = 0; d < dim; d++) tangent2[d] *= 1. / std::max(std::sqrt(mod), sml);
+        }
+        double M[9] = {0}, invM[9] = {0}, nVel[3] = {0, 0, 0};  // row-major M(i, d)
+        for (int d = 0; d < dim; d++) {
+          M[0 * dim + d] = unitNorm[d];
+          M[1 * dim + d] = tangent1[d];
+          if (dim == 3) M[2 * dim + d] = tangent2[d];
+        }
+        for (int i = 0; i < dim; i++)
+          for (int d = 0; d < dim; d++) nVel[i] += M[i * dim + d] * vel[d];
+        nVel[0] = -nVel[0];  // mirror normal component
+        if (dim == 2) {
+          const double det = M[0] * M[3] - M[1] * M[2];
+          invM[0] = M[3] / det;
+          invM[1] = -M[1] / det;
+          invM[2] = -M[2] / det;
+          invM[3] = M[0] / det;
+        } else {
+          const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+          const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+          const double inv[9] = {c00, M[2] * M[7] - M[1] * M[8], M[1] * M[5] - M[2] * M[4],
+                                 c01, M[0] * M[8] - M[2] * M[6], M[2] * M[3] - M[0] * M[5],
+                                 c02, M[1] * M[6] - M[0] * M[7], M[0] * M[4] - M[1] * M[3]};
+          for (int k = 0; k < 9; k++) invM[k] = inv[k] / det;
+        }
+        double gVel[3] = {0, 0, 0};
+        for (int i = 0; i < dim; i++)
+          for (int d = 0; d < dim; d++) gVel[i] += invM[i * dim + d] * nVel[d];
+        double state2[MAXEQ];
+        for (int eq = 0; eq < num_equation; eq++) state2[eq] = stateIn[eq];
+        state2[1] = stateIn[0] * gVel[0];
+        state2[2] = stateIn[0] * gVel[1];
+        if (dim == 3) state2[3] = stateIn[0] * gVel[2];
+        rsolver->Eval(stateIn, state2, normal, bdrFlux);
+      } break;
       case TPSRHS_INV: {  // src/wallBC.cpp:277-320
         double vel[MAXDIM];
         for (int d = 0; d < nvel; d++) vel[d] = stateIn[1 + d] / stateIn[0];

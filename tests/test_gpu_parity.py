@@ -257,3 +257,34 @@ def test_plasma_four_and_five_species(levels, ambipolar, geo, order, two_t, tran
         disc, bcs = capi.Disc(order, 0, 0, 0, 0), []
         U = cases.plasma_state(node_coordinates(mesh, order), ph, nvel=2, seed=9, amp=amp)
     _compare(mesh, disc, ph, bcs, U, tol=_tol(amp))
+
+
+# ---- slip wall (computeSlipWallFlux, src/wallBC.cpp:326-428): Riemann flux against the velocity mirrored in the
+# reference's wall frame, no viscous term; in 2-D that frame is skewed (see slip_ghost_momentum_2d)
+@pytest.mark.parametrize("kind,order", [("cyl3d", 3), ("chan2d", 2), ("axisym", 3), ("plasma3d", 2), ("plasma_axisym", 2)])
+def test_slip_wall(kind, order):
+    if kind == "cyl3d":
+        c = cases.cyl3d(4, 12, 3, order, capi.NS, capi.SLIP)
+        c.physics.dry_air.visc_mult = 2000.0
+        mesh, disc, ph, bcs, U = c.mesh, c.disc, c.physics, c.bcs, c.state(seed=3)
+    elif kind == "chan2d":
+        attrs = {(0, 0): 1, (0, 1): 2, (1, 0): 3, (1, 1): 3}
+        mesh = meshgen.scramble_orientations(
+            meshgen.box_quad(6, 5, lengths=(1.0, 0.7), periodic=(False, False), bdr_attr=attrs, warp=0.08), 2)
+        disc, ph = capi.Disc(order, 0, 0, 0, 0), capi.dry_air_physics(capi.NS, visc_mult=300.0)
+        bcs = [capi.make_bc(1, capi.INLET, capi.SUB_DENS_VEL, [1.2, 20.0, 0.0, 0.0]),
+               capi.make_bc(2, capi.OUTLET, capi.SUB_P, [101300.0]), capi.make_bc(3, capi.WALL, capi.SLIP)]
+        U = cases.dry_air_state(node_coordinates(mesh, order), seed=4)
+    elif kind == "axisym":
+        c = cases.dry_air_axisym(6, 9, order, capi.NS, capi.SLIP, r_in=0.01, warp=0.06)
+        c.physics.dry_air.visc_mult = 200.0
+        mesh, disc, ph, bcs, U = c.mesh, c.disc, c.physics, c.bcs, c.state(seed=5)
+    elif kind == "plasma3d":
+        c = cases.argon_cyl3d(4, 12, 3, order, True, capi.CONSTANT, "arrhenius", capi.SLIP)
+        _boost_transport(c.physics)
+        mesh, disc, ph, bcs, U = c.mesh, c.disc, c.physics, c.bcs, c.state(seed=6, amp=0.01)
+    else:
+        c = cases.argon_axisym(6, 9, order, True, capi.CONSTANT, "arrhenius", True, capi.SLIP, r_in=0.0)
+        _boost_transport(c.physics, 30.0)
+        mesh, disc, ph, bcs, U = c.mesh, c.disc, c.physics, c.bcs, c.state(seed=7, amp=0.01)
+    _compare(mesh, disc, ph, bcs, U, tol=_tol(0.01) if kind.startswith("plasma") else RHS_RTOL)

@@ -139,3 +139,38 @@ def test_roe_flux_known_answers():
     c3.disc.use_roe = 1
     with pytest.raises(RuntimeError):
         Oracle(c3.mesh, c3.disc, c3.physics, c3.bcs)
+
+
+def test_slip_wall_is_the_inviscid_mirror_in_3d_and_a_skewed_mirror_in_2d():
+    """computeSlipWallFlux (src/wallBC.cpp:326-428).  In 3-D its wall frame is orthonormal, so the ghost is the
+    mirror state of the inviscid wall and, with zero gradients, the two boundary fluxes coincide.  In 2-D the
+    reference's tangent is not orthogonal to the normal: the ghost solves n.g = -n.v, t.g = t.v in that frame."""
+    c = cases.cyl3d(3, 8, 3, 1, capi.NS, capi.SLIP)
+    o_slip = Oracle(c.mesh, c.disc, c.physics, c.bcs)
+    c2 = cases.cyl3d(3, 8, 3, 1, capi.NS, capi.INV)
+    o_inv = Oracle(c2.mesh, c2.disc, c2.physics, c2.bcs)
+    U = o_slip.cons(np.array([1.1, 30.0, -4.0, 2.0, 310.0]))
+    n = np.array([0.3, -0.2, 0.5])
+    f_slip = o_slip.bdr_flux(3, n, U, np.zeros((3, 5)))
+    f_inv = o_inv.bdr_flux(3, n, U, np.zeros((3, 5)))
+    np.testing.assert_allclose(f_slip, f_inv, rtol=1e-12, atol=1e-9)
+    # a slip wall has no viscous term: gradients do not matter
+    g = np.random.default_rng(0).standard_normal((3, 5))
+    np.testing.assert_allclose(o_slip.bdr_flux(3, n, U, g), f_slip, rtol=1e-14)
+    # 2-D: closed form of the skewed frame for n = (3, 4)/5: dir = 1, t ~ (1, 1 - 0.6/0.8)
+    from tps_amd import meshgen
+
+    attrs = {(0, 0): 3, (0, 1): 3, (1, 0): 3, (1, 1): 3}
+    mesh = meshgen.box_quad(3, 3, periodic=(False, False), bdr_attr=attrs)
+    o2 = Oracle(mesh, capi.Disc(1, 0, 0, 0, 0), capi.dry_air_physics(capi.EULER), [capi.make_bc(3, capi.WALL, capi.SLIP)])
+    U2 = o2.cons(np.array([1.2, 25.0, -7.0, 300.0]))
+    n2 = np.array([3.0, 4.0])
+    u = n2 / 5.0
+    t = np.array([1.0, 1.0 - u[0] / u[1]])
+    t /= np.linalg.norm(t)
+    v = U2[1:3] / U2[0]
+    gvel = np.linalg.solve(np.array([u, t]), np.array([-u @ v, t @ v]))
+    ghost = U2.copy()
+    ghost[1:3] = U2[0] * gvel
+    np.testing.assert_allclose(o2.bdr_flux(3, n2, U2, np.zeros((2, 4))), o2.lf(U2, ghost, n2), rtol=1e-12)
+    assert abs(u @ t) > 0.1  # the frame really is skewed

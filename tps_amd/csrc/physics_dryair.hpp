@@ -67,6 +67,28 @@ struct DryAirParams {
   BcDev bc[MAXBC];
 };
 
+// Slip wall in 2-D (computeSlipWallFlux, src/wallBC.cpp:326-428): the reference mirrors the velocity component
+// along its first frame vector in the frame (n, t) where its "arbitrary tangent" t is, for dim = 2, NOT orthogonal
+// to n (previous_dir coincides with dir there); the ghost momentum g solves  n.g = -n.v,  t.g = t.v  in that
+// skewed frame.  In 3-D the frame is orthonormal and the result is the plain mirror state of the inviscid wall.
+__device__ inline void slip_ghost_momentum_2d(const double *n, const double *U, double *Ug) {
+  const double sml = 1.0e-15;
+  const double nn = sqrt(fmax(n[0] * n[0] + n[1] * n[1], sml));
+  const double u[2] = {n[0] / nn, n[1] / nn};
+  const int dir = (fabs(u[1]) >= fabs(u[0])) ? 1 : 0, nd = 1 - dir;
+  double t[2];
+  t[nd] = 1.0;
+  t[dir] = (u[dir] * -1.0 + u[nd] * 1.0) * (-1.0 / u[dir]);
+  const double tm = fmax(sqrt(t[0] * t[0] + t[1] * t[1]), sml);
+  t[0] /= tm;
+  t[1] /= tm;
+  const double v[2] = {U[1] / U[0], U[2] / U[0]};
+  const double a = -(u[0] * v[0] + u[1] * v[1]), b = t[0] * v[0] + t[1] * v[1];
+  const double det = u[0] * t[1] - u[1] * t[0];
+  Ug[1] = U[0] * (t[1] * a - u[1] * b) / det;
+  Ug[2] = U[0] * (-t[0] * a + u[0] * b) / det;
+}
+
 __host__ __device__ inline bool is_non_reflecting(int category, int type) {
   return (category == TPSRHS_INLET && (type == TPSRHS_SUB_DENS_VEL_NR || type == TPSRHS_SUB_VEL_CONST_ENT)) ||
          (category == TPSRHS_OUTLET && (type == TPSRHS_SUB_P_NR || type == TPSRHS_SUB_MF_NR || type == TPSRHS_SUB_MF_NR_PW));
@@ -231,7 +253,7 @@ struct DryAirPhys {
   __device__ static inline void riemann_bc(const Params &p, const BcDev &bc, const double *U1, const double *Ug,
                                            const double *n, double *F) {
     if constexpr (DIM == 2) {
-      if (p.use_roe && bc.category == TPSRHS_WALL && bc.type == TPSRHS_INV) {
+      if (p.use_roe && bc.category == TPSRHS_WALL && (bc.type == TPSRHS_INV || bc.type == TPSRHS_SLIP)) {
         roe(p, U1, Ug, n, F);
         return;
       }
@@ -562,7 +584,8 @@ struct DryAirPhys {
       for (int d = 0; d < NVEL; d++) k += U[1 + d] * U[1 + d];
       k *= 0.5 / U[0];
       Ug[1 + NVEL] = bc.data[0] / (p.gamma - 1.0) + k;
-    } else if (bc.type == TPSRHS_INV) {  // mirrored normal momentum, src/wallBC.cpp:277-301
+    } else if (bc.type == TPSRHS_INV || bc.type == TPSRHS_SLIP) {  // mirrored normal momentum, src/wallBC.cpp:277-301
+      // (SLIP, :326-428, builds the same mirror state through a wall-aligned frame)
       double nm = 0.0;
 #pragma unroll
       for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
@@ -572,6 +595,7 @@ struct DryAirPhys {
       for (int d = 0; d < DIM; d++) vn += (U[1 + d] / U[0]) * (n[d] / nm);
 #pragma unroll
       for (int d = 0; d < DIM; d++) Ug[1 + d] = U[0] * (U[1 + d] / U[0] - 2.0 * vn * (n[d] / nm));
+      if (DIM == 2 && bc.type == TPSRHS_SLIP) slip_ghost_momentum_2d(n, U, Ug);
     } else if (bc.type == TPSRHS_VISC_ADIAB) {  // computeStagnationState, :367-378
       const double pres = pressure(p, U);
 #pragma unroll
@@ -595,7 +619,7 @@ struct DryAirPhys {
                                              const double *n, double *out) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) out[eq] = 0.0;
-    if (bc.category != TPSRHS_WALL || p.eq_system == TPSRHS_EULER) return;
+    if (bc.category != TPSRHS_WALL || p.eq_system == TPSRHS_EULER || bc.type == TPSRHS_SLIP) return;  // slip: Riemann flux only
     double nm = 0.0;
 #pragma unroll
     for (int d = 0; d < DIM; d++) nm += n[d] * n[d];

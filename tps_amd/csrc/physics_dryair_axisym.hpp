@@ -155,11 +155,12 @@ struct DryAirAxiPhys {
       Ug[ITH] = s.p / (p.gamma - 1.0) + ke;
     } else if (bc.category == TPSRHS_OUTLET) {
       Ug[ITH] = bc.data[0] / (p.gamma - 1.0) + 0.5 * s.k;
-    } else if (bc.type == TPSRHS_INV) {
+    } else if (bc.type == TPSRHS_INV || bc.type == TPSRHS_SLIP) {
       const double nm = sqrt(n[0] * n[0] + n[1] * n[1]);
       const double vn = s.vel[0] * (n[0] / nm) + s.vel[1] * (n[1] / nm);
 #pragma unroll
       for (int d = 0; d < DIM; d++) Ug[1 + d] = U[0] * (s.vel[d] - 2.0 * vn * (n[d] / nm));
+      if (bc.type == TPSRHS_SLIP) slip_ghost_momentum_2d(n, U, Ug);
     } else if (bc.type == TPSRHS_VISC_ADIAB) {  // computeStagnationState, src/equation_of_state.cpp:367-378
 #pragma unroll
       for (int d = 0; d < NVEL; d++) Ug[1 + d] = 0.0;
@@ -186,7 +187,7 @@ struct DryAirAxiPhys {
       return;
     }
     const BcDev &bc = p.bc[-nb - 1];
-    if (bc.category != TPSRHS_WALL) return;
+    if (bc.category != TPSRHS_WALL || bc.type == TPSRHS_SLIP) return;  // slip wall: Riemann flux only (src/wallBC.cpp:326-428)
     double Uw[NEQ], f[NEQ];
     bool adiabatic = false;
     if (bc.type == TPSRHS_INV) {

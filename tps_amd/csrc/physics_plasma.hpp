@@ -972,7 +972,7 @@ struct PlasmaPhys {
       energy_for_pressure(p, s2, pres, true, Ug);
     } else if (bc.category == TPSRHS_OUTLET) {  // src/outletBC.cpp:731-737
       energy_for_pressure(p, U, bc.data[0], false, Ug);
-    } else if (bc.type == TPSRHS_INV) {  // src/wallBC.cpp:277-301
+    } else if (bc.type == TPSRHS_INV || bc.type == TPSRHS_SLIP) {  // src/wallBC.cpp:277-301 (SLIP :326-428: same mirror state)
       double nm = 0.0;
 #pragma unroll
       for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
@@ -982,6 +982,7 @@ struct PlasmaPhys {
       for (int d = 0; d < DIM; d++) vn += (U[1 + d] / U[0]) * (n[d] / nm);
 #pragma unroll
       for (int d = 0; d < DIM; d++) Ug[1 + d] = U[0] * (U[1 + d] / U[0] - 2.0 * vn * (n[d] / nm));
+      if (DIM == 2 && bc.type == TPSRHS_SLIP) slip_ghost_momentum_2d(n, U, Ug);
     } else if (bc.type == TPSRHS_VISC_ADIAB) {  // GasMixture::computeStagnationState, :100-115
       double ke = 0.0;
 #pragma unroll
@@ -1015,7 +1016,7 @@ struct PlasmaPhys {
     double twall = 0.0;
     if (nb < 0) {
       const BcDev &bc = p.bc[-nb - 1];
-      if (bc.category != TPSRHS_WALL) return;
+      if (bc.category != TPSRHS_WALL || bc.type == TPSRHS_SLIP) return;  // slip wall: Riemann flux only
       type = bc.type;
       twall = bc.data[0];
     }

@@ -182,7 +182,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     const bool ok = nr || (b.category == TPSRHS_INLET && b.type == TPSRHS_SUB_DENS_VEL) ||
                     (b.category == TPSRHS_OUTLET && b.type == TPSRHS_SUB_P) ||
                     (b.category == TPSRHS_WALL &&
-                     (b.type == TPSRHS_INV || b.type == TPSRHS_VISC_ADIAB || b.type == TPSRHS_VISC_ISOTH ||
+                     (b.type == TPSRHS_INV || b.type == TPSRHS_SLIP || b.type == TPSRHS_VISC_ADIAB || b.type == TPSRHS_VISC_ISOTH ||
                       (b.type == TPSRHS_VISC_GNRL && plasma)));
     if (!ok) throw Unsupported("boundary condition type outside the hot-path scope (attribute " + std::to_string(b.attribute) + ")");
     if (b.category == TPSRHS_WALL && b.type == TPSRHS_VISC_GNRL) {
