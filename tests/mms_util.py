@@ -108,3 +108,43 @@ def manufactured_axisym(X, visc_mult=1.0, bulk_mult=0.0, lz=1.0):
     U = np.array([np.asarray(v, dtype=np.float64) + bc for v in fu(X[0], X[1])])
     R = np.array([np.asarray(v, dtype=np.float64) + bc for v in fr(X[0], X[1])])
     return U, R
+
+
+@functools.lru_cache(maxsize=None)
+def _build_ternary(dim, lengths):
+    """Inviscid, frozen, single-temperature ambipolar ternary plasma (Ar.+1, E, Ar): PerfectMixture closure of
+    SURVEY.md appendix A.3 -- n_e = n_i, p = R (n_i + n_e + n_B) T, rho E = sum n c_v T + n_i E_f + rho |u|^2 / 2 --
+    state rho, rho u, rho E, rho Y_ion."""
+    import sympy as sp
+
+    R_U = 8.3144598
+    m_ar, m_e, e_form, cv = 39.948e-3, 5.4858e-7, 1520571.3883, 1.5 * R_U
+    m_i = m_ar - m_e
+    X = sp.symbols("x y z")[:dim]
+    k = [2 * sp.pi / L for L in lengths]
+    T = 8000.0 * (1 + 0.10 * sp.sin(k[0] * X[0]) * sp.cos(k[1] * X[1]))
+    nB = 1.4 * (1 + 0.08 * sp.cos(k[0] * X[0] + 0.2) * sp.sin(k[1] * X[1]) + (0.04 * sp.sin(k[2] * X[2]) if dim == 3 else 0))
+    ni = 2.0e-3 * (1 + 0.30 * sp.sin(k[0] * X[0] - 0.5) * sp.sin(k[1] * X[1] + 0.1))
+    vel = [300.0 + 60.0 * sp.sin(k[0] * X[0] + 0.3) * sp.cos(k[1] * X[1]), -100.0 + 40.0 * sp.cos(k[0] * X[0]) * sp.sin(k[1] * X[1])]
+    if dim == 3:
+        vel.append(50.0 + 30.0 * sp.sin(k[2] * X[2] + 0.2) * sp.cos(k[0] * X[0]))
+    ne = ni
+    rho = m_i * ni + m_e * ne + m_ar * nB
+    p = R_U * (ni + ne + nB) * T
+    E = cv * (ni + ne + nB) * T + e_form * ni + rho * sum(v * v for v in vel) / 2
+    U = [rho] + [rho * v for v in vel] + [E, m_i * ni]
+    rhs = [-sum(sp.diff(U[0] * vel[d], X[d]) for d in range(dim))]
+    for i in range(dim):
+        rhs.append(-sum(sp.diff(U[1 + i] * vel[d] + (p if i == d else 0), X[d]) for d in range(dim)))
+    rhs.append(-sum(sp.diff(vel[d] * (E + p), X[d]) for d in range(dim)))
+    rhs.append(-sum(sp.diff(m_i * ni * vel[d], X[d]) for d in range(dim)))
+    return sp.lambdify(X, U, "numpy"), sp.lambdify(X, rhs, "numpy")
+
+
+def manufactured_ternary(X, lengths=(1.0, 1.0, 1.0)):
+    dim = X.shape[0]
+    fu, fr = _build_ternary(dim, tuple(lengths[:dim]))
+    bc = np.zeros(X.shape[1])
+    U = np.array([np.asarray(v, dtype=np.float64) + bc for v in fu(*X)])
+    R = np.array([np.asarray(v, dtype=np.float64) + bc for v in fr(*X)])
+    return U, R

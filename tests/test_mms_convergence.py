@@ -126,3 +126,49 @@ def test_hip_axisymmetric_converges_to_the_cylindrical_equations(order, n):
     rate = observed_order(e1, e2)
     print("relative RMS errors", e1, "->", e2, "observed order", rate)
     assert np.median(rate) > order - 0.35 and rate.min() > order - 1.0
+
+
+def _ternary_errors(run, dim, order, n):
+    from mms_util import manufactured_ternary
+
+    mesh = (meshgen.box_hex(n, n, n, lengths=LENGTHS, warp=0.04) if dim == 3 else meshgen.box_quad(n, n, lengths=LENGTHS[:2], warp=0.04))
+    X = node_coordinates(mesh, order)
+    U, R = manufactured_ternary(X, LENGTHS)
+    ph = capi.argon_ternary_physics(capi.EULER, False, capi.CONSTANT, None, third_order_ke=False)
+    y = run(mesh, capi.Disc(order, 0, 0, 0, 0), ph, [], U)
+    return np.sqrt(((y - R) ** 2).mean(axis=1) / (R ** 2).mean(axis=1))
+
+
+@pytest.mark.parametrize("dim,order,n", [(2, 1, 8), (2, 2, 6), (3, 1, 4)])
+def test_oracle_ternary_plasma_converges_to_the_pde(dim, order, n):
+    """PerfectMixture thermodynamics + species convection of the frozen inviscid ternary plasma vs the exact PDE"""
+    from oracle_lib import Oracle
+
+    def run(mesh, disc, ph, bcs, U):
+        return Oracle(mesh, disc, ph, bcs).mult(U)
+
+    e1, e2 = _ternary_errors(run, dim, order, n), _ternary_errors(run, dim, order, 2 * n)
+    rate = observed_order(e1, e2)
+    print("relative RMS errors", e1, "->", e2, "observed order", rate)
+    assert np.median(rate) > order - 0.35 and rate.min() > order - 0.8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,order,n", [(2, 3, 6), (3, 2, 5), (3, 3, 4)])
+def test_hip_ternary_plasma_converges_to_the_pde(dim, order, n):
+    import torch
+    from tps_amd.rhs_operator import RHSoperator
+
+    def run(mesh, disc, ph, bcs, U):
+        op = RHSoperator(mesh, disc, ph, bcs)
+        x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
+        y = torch.empty_like(x)
+        op.Mult(x, y)
+        y = y.cpu().numpy().reshape(U.shape)
+        op.close()
+        return y
+
+    e1, e2 = _ternary_errors(run, dim, order, n), _ternary_errors(run, dim, order, 2 * n)
+    rate = observed_order(e1, e2)
+    print("relative RMS errors", e1, "->", e2, "observed order", rate)
+    assert np.median(rate) > order - 0.35 and rate.min() > order - 1.0
