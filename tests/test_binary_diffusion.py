@@ -1,0 +1,100 @@
+"""The reference's analytic test of the species-diffusion path (test/argon_minimal.binary.test with
+test/inputs/argonMinimal.binary_mixture.ini and utils/binary_mixture_ic.cpp): a sinusoidal Ar+/Ar composition wave in
+a uniform stream decays as exp(-k^2 D t) and is convected by u0; after 1000 RK4 steps of dt = 6e-5 TPS must reproduce
+rho Y_Ar+ within a RELATIVE 2e-4 of the closed form (h5diff --relative=2e-4).  Same physics, same numbers here:
+non-ambipolar ternary mixture with the input's masses (electron 1e-16 kg/mol, no electrons present), argon-minimal
+transport with its Ar-Ar+ collision integral, p = 1.0133 Pa, T = 300 K, u0 = 1 m/s, 5 x 1 periodic domain, 15 x 3
+quads of order 3 (the 45 elements of beam-quad-o3-s5-p.mesh), wavenumber 2.  The reference runs it on the GLL basis;
+this library runs the collocated Gauss-Legendre pair."""
+import numpy as np
+import pytest
+
+from tps_amd import capi, meshgen
+from tps_amd.rhs_operator import node_coordinates
+
+R_U, N_A = 8.3144598, 6.0221409e23
+M_AR, M_E = 39.948e-3, 1.0e-16
+P0, T0, U0, LX, LY, KX, T_END, NSTEPS, DT = 1.0133, 300.0, 1.0, 5.0, 1.0, 2.0, 0.06, 1000, 6.0e-5
+
+
+def _physics():
+    ph = capi.argon_ternary_physics(capi.NS, False, capi.ARGON_MINIMAL, None, third_order_ke=True, ambipolar=False)
+    mx, nsp = ph.mixture, 3
+    for sp, m in enumerate((M_AR - M_E, M_E, M_AR)):  # mixture order Ar.+1, E, Ar
+        mx.gas_params[sp + capi.SPECIES_MW * nsp] = m
+        mx.gas_params[sp + capi.FORMATION_ENERGY * nsp] = 0.0
+    return ph
+
+
+def _setup(nx=15):
+    mesh = meshgen.box_quad(nx, 3, lengths=(LX, LY))
+    X = node_coordinates(mesh, 3)
+    n_tot = P0 / (R_U * T0)
+    rho = n_tot * M_AR
+    rho_e = n_tot * 1.5 * R_U * T0 + 0.5 * rho * U0 * U0
+
+    def state(decay, shift):
+        Y = 0.5 + 0.45 * decay * np.cos(2 * np.pi * KX * (X[0] - shift) / LX)
+        U = np.zeros((6, X.shape[1]))
+        U[0], U[1], U[3], U[4] = rho, rho * U0, rho_e, rho * Y
+        return U
+
+    # binary diffusivity of utils/binary_mixture_ic.cpp: GasMinimalTransport::computeMixtureAverageDiffusivity
+    # (src/gas_transport.cpp:498-590) for the ion with no electrons: D = f sqrt(T / mu_in) / n / Q11_ArAr+(T)
+    k_b = R_U / N_A
+    f = 3.0 / 16.0 * np.sqrt(2.0 * np.pi * k_b) / N_A
+    m_n, m_i = M_AR / N_A, (M_AR - M_E) / N_A
+    q11 = 4.574321e-18 * T0 ** -0.1805  # collision::argon::ArAr1P11
+    d_ia = f * np.sqrt(T0 / (m_n * m_i / (m_n + m_i))) / n_tot / q11
+    decay = np.exp(-(4 * np.pi ** 2 * KX ** 2 / LX ** 2) * d_ia * T_END)
+    return mesh, state(1.0, 0.0), state(decay, U0 * T_END), decay
+
+
+def test_oracle_residual_carries_the_analytic_convection_and_decay_rates():
+    """CPU: the oracle's d(rho Y)/dt of the initial wave, projected on the two modes of the closed form
+    -u0 d/dx(rho Y) - k^2 D (rho Y - rho/2): convection speed u0 and decay rate k^2 D with the diffusivity of
+    utils/binary_mixture_ic.cpp (the pointwise residual of a DG operator oscillates around them)."""
+    from oracle_lib import Oracle
+
+    mesh, Ustart, _, decay = _setup()
+    o = Oracle(mesh, capi.Disc(3, 0, 0, 0, 0), _physics(), [])
+    y = o.mult(Ustart)
+    assert np.isfinite(y).all()
+    X = node_coordinates(mesh, 3)
+    k = 2 * np.pi * KX / LX
+    d_ia = -np.log(decay) / (k * k * T_END)
+    rho = Ustart[0, 0]
+    conv = rho * 0.45 * U0 * k * np.sin(k * X[0])
+    diff = -rho * 0.45 * k * k * d_ia * np.cos(k * X[0])
+    c = np.linalg.lstsq(np.stack([conv, diff], 1), y[4], rcond=None)[0]
+    print("projection on (convection, diffusion):", c)
+    assert abs(c[0] - 1) < 1e-4 and abs(c[1] - 1) < 1e-2
+    # nothing else moves: total density, momentum, energy, the (absent) electrons
+    assert np.abs(y[[0, 1, 2, 3, 5]]).max() < 1e-10
+
+
+@pytest.mark.gpu
+def test_binary_diffusion_matches_the_analytic_solution_of_the_reference_test():
+    import torch
+    from tps_amd.rhs_operator import RHSoperator
+
+    errs = {}
+    for nx in (15, 30):
+        mesh, Ustart, Uref, decay = _setup(nx)
+        assert 0.2 < decay < 0.9  # the wave has decayed visibly but is far from gone
+        op = RHSoperator(mesh, capi.Disc(3, 0, 0, 0, 0), _physics(), [])
+        x = torch.tensor(np.ascontiguousarray(Ustart).ravel(), dtype=torch.float64, device=op.device)
+        sub = 1 if nx == 15 else 4  # the explicit diffusion limit shrinks with h^2: smaller steps on the finer mesh
+        t, _, bad = op.advance(x, 0.0, DT / sub, NSTEPS * sub, True)
+        got = x.cpu().numpy().reshape(Ustart.shape)
+        op.close()
+        assert bad == 0 and t == pytest.approx(T_END, rel=1e-12)
+        errs[nx] = (np.abs(got[4] - Uref[4]) / np.abs(Uref[4])).max()
+        # the carrier state is untouched
+        assert np.abs(got[0] - Uref[0]).max() < 1e-10 * Uref[0, 0] and np.abs(got[5]).max() == 0.0
+    print("decay factor", decay, "max relative difference of rho Y_Ar+ (15 and 30 elements along x):", errs)
+    # The reference (GLL nodes, over-integrated) passes --relative=2e-4 on the 15 x 3 mesh.  The collocated
+    # Gauss-Legendre pair this library implements has a somewhat larger constant there (5.7e-4, at the nodes
+    # where Y is smallest); it is discretisation error -- one refinement takes it well under the reference's bound.
+    assert errs[15] < 1.0e-3
+    assert errs[30] < 2.0e-4 and errs[30] < errs[15] / 6
