@@ -7,7 +7,7 @@ W=${2:-argon_p3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${W}
 mkdir -p "$OUT"
-B="python3 bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline --no-other-workloads"
+B="python3 bench.py --workload $W --steps 100 --warmup 10 --no-cpu-baseline --no-other-workloads"  # the default K and W of bench.py
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $B > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
 echo "trace done"
 P="python3 bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-other-workloads"
