@@ -53,7 +53,7 @@ def _case(world, kind):
     return full, owner, order, ph, bcs, Ug
 
 
-def _worker(rank, world, port, q, kind):
+def _worker(rank, world, port, q, kind, backend="gloo"):
     try:
         import torch
         import torch.distributed as dist
@@ -61,7 +61,13 @@ def _worker(rank, world, port, q, kind):
         from tps_amd.halo import HaloExchange
         from tps_amd.rhs_operator import RHSoperator
 
-        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        dev = rank if backend == "nccl" else 0  # nccl (= RCCL): one GPU per rank; gloo: the ranks share GPU 0
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         full, owner, order, ph, bcs, Ug = _case(world, kind)
         if isinstance(owner, str):
             part = meshgen.ogrid_cylinder_slab(4, 12, 3, rank, world)
@@ -73,8 +79,8 @@ def _worker(rank, world, port, q, kind):
         npe = (order + 1) ** full.dim
         idx = (gel[:, None] * npe + np.arange(npe)[None, :]).ravel()
         U = Ug[:, idx]  # the rank's rows of ONE global field
-        halo = HaloExchange(device=torch.device("cuda", 0))
-        op = RHSoperator(part, disc, ph, bcs, device=0, halo=halo)
+        halo = HaloExchange(device=torch.device("cuda", dev))
+        op = RHSoperator(part, disc, ph, bcs, device=dev, halo=halo)
         x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
         y = torch.empty_like(x)
         if kind.endswith("_nr"):  # second call: the boundary state of the first one is in use
@@ -106,6 +112,22 @@ ADV = (2.0e-5, 3, 0.1, 0.05)  # dt0, steps, CFL, hmin of the advance() leg
 @pytest.mark.parametrize("world,kind", [(2, "dry_air"), (3, "argon_2T"), (2, "slab"), (4, "slab"), (3, "axisym_2T"),
                                         (3, "dry_air_nr")])
 def test_ranks_match_serial_oracle(world, kind):
+    _run_ranks(world, kind, "gloo")
+
+
+@pytest.mark.parametrize("world,kind", [(2, "slab"), (2, "dry_air_nr")])
+def test_ranks_match_serial_oracle_over_rccl(world, kind):
+    """The same on one GPU per rank with the nccl backend (RCCL send/recv of the traces straight from device
+    memory, all_reduce of the boundary means and of dt): needs as many GPUs as ranks, so it is skipped on the
+    one-GPU test boxes and runs wherever a multi-GPU node executes the suite."""
+    import torch
+
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    _run_ranks(world, kind, "nccl")
+
+
+def _run_ranks(world, kind, backend):
     full, owner, order, ph, bcs, Ug = _case(world, kind)
     if kind.endswith("_nr"):
         from oracle_lib import Oracle
@@ -120,7 +142,7 @@ def test_ranks_match_serial_oracle(world, kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
