@@ -129,3 +129,29 @@ def test_advance_replays_a_captured_step(monkeypatch):
     assert np.array_equal(g[0], p[0]) and g[1:] == p[1:]
     assert g[1] == pytest.approx(t, rel=1e-13) and g[2] == pytest.approx(dt, rel=1e-12) and g[3] == 0
     assert rel_maxnorm(g[0], ref).max() < 1e-13
+
+
+def test_time_loop_is_fourth_order_in_dt():
+    """RK4 through tpsrhs_advance: halving dt divides the time-integration error by 16 (the spatial operator is the
+    same in all runs, so the differences between them are purely temporal)."""
+    import torch
+    from tps_amd import meshgen
+    from tps_amd.rhs_operator import RHSoperator, node_coordinates
+
+    mesh = meshgen.box_hex(3, 3, 3, lengths=(1.0, 0.8, 1.2), warp=0.05)
+    ph = capi.dry_air_physics(capi.NS, visc_mult=2.0e3)
+    U = cases.dry_air_state(node_coordinates(mesh, 2), seed=5)
+    op = RHSoperator(mesh, capi.Disc(2, 0, 0, 0, 0), ph, [])
+    t_end, base = 4.0e-4, 10
+
+    def run(nsteps):
+        x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
+        t, _, bad = op.advance(x, 0.0, t_end / nsteps, nsteps, True)
+        assert bad == 0 and t == pytest.approx(t_end, rel=1e-12)
+        return x.cpu().numpy()
+
+    ref = run(16 * base)
+    e1, e2, e3 = (np.abs(run(k * base) - ref).max() for k in (1, 2, 4))
+    op.close()
+    print("errors", e1, e2, e3, "orders", np.log2(e1 / e2), np.log2(e2 / e3))
+    assert 3.6 < np.log2(e1 / e2) < 4.4 and 3.5 < np.log2(e2 / e3) < 4.5
