@@ -288,3 +288,29 @@ def test_slip_wall(kind, order):
         _boost_transport(c.physics, 30.0)
         mesh, disc, ph, bcs, U = c.mesh, c.disc, c.physics, c.bcs, c.state(seed=7, amp=0.01)
     _compare(mesh, disc, ph, bcs, U, tol=_tol(0.01) if kind.startswith("plasma") else RHS_RTOL)
+
+
+# ---- structural invariant of the scheme, checked on the HIP result itself: on a periodic mesh without sources
+# the residual integrates to zero equation by equation (what leaves one element enters its neighbour)
+@pytest.mark.parametrize("kind,order", [("dry3d", 3), ("dry2d", 4), ("ternary3d", 2)])
+def test_hip_residual_is_conservative(kind, order):
+    from oracle_lib import Oracle
+
+    if kind == "dry2d":
+        mesh = meshgen.scramble_orientations(meshgen.box_quad(6, 5, lengths=(1.0, 0.7), warp=0.1), 3)
+    else:
+        mesh = meshgen.scramble_orientations(meshgen.box_hex(4, 3, 3, lengths=(1.0, 0.8, 1.2), warp=0.1), 3)
+    if kind == "ternary3d":
+        ph = capi.argon_ternary_physics(capi.NS, False, capi.CONSTANT, None, third_order_ke=False)
+        _boost_transport(ph)
+        U = cases.plasma_state(node_coordinates(mesh, order), ph, nvel=3, seed=3, amp=0.01)
+    else:
+        ph = capi.dry_air_physics(capi.NS, visc_mult=800.0, bulk_visc_mult=1.0)
+        U = cases.dry_air_state(node_coordinates(mesh, order), seed=3)
+    disc = capi.Disc(order, 0, 0, 0, 0)
+    got = hip_mult(mesh, disc, ph, [], U, want_grad=False)["y"]
+    o = Oracle(mesh, disc, ph, [])  # only its quadrature: integral of a nodal field
+    for eq in range(U.shape[0]):
+        total, scale = o.integral(got[eq]), o.integral(np.abs(got[eq]))
+        print(kind, "equation", eq, "integral", total, "of", scale)
+        assert abs(total) < 1e-11 * scale
