@@ -174,10 +174,8 @@ def main():
         order, physics, make_bcs, make_state, description, sample_case = workload(wname)
         order = args.order or order
         axisym = wname in ("cfg5", "torch6")
-        if axisym:
-            if world > 1:
-                raise SystemExit("the axisymmetric workloads are benchmarked on one GPU (no partitioned generator for the (r, z) block yet)")
-            mesh = cases.argon_axisym(400, 500, order).mesh  # geometry only; physics and BCs come from workload()
+        if axisym:  # (r, z) tube 0.05 x 0.25 per rank, 400 x 500 quads; axial slabs at N > 1 (weak scaling)
+            mesh = meshgen.annulus_quad_slab(400, 500, rank, world, r_in=0.0, r_out=0.05, length_local=0.25)
         else:
             mesh = meshgen.ogrid_cylinder_slab(args.nr, args.ntheta, args.nz, rank, world)
         disc = capi.Disc(order, 0, 0, 1 if axisym else 0, 0)

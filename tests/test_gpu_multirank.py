@@ -30,6 +30,12 @@ def _case(world, kind):
         bcs = cases.cylinder_bcs(capi.VISC_ISOTH)
         Ug = cases.dry_air_state(node_coordinates(full, order), seed=5)
         return full, "slab", order, ph, bcs, Ug
+    if kind == "axisym_slab":  # bench.py's partition of the axisymmetric workloads: axial slabs of the (r, z) block
+        ph = capi.argon_ternary_physics(capi.NS, True, capi.CONSTANT, "arrhenius", radiation=True)
+        full = meshgen.annulus_quad(6, 3 * world, r_out=0.05, length=0.08 * world)
+        c = cases.argon_axisym(6, 3, 2, physics=ph)  # boundary conditions of the tube
+        Ug = cases.plasma_state(node_coordinates(full, 2), ph, nvel=3, seed=8, amp=0.01, vel0=(1.0, 20.0, 3.0))
+        return full, "axislab", 2, ph, c.bcs, Ug
     if kind == "axisym_2T":  # 2-D shared edges, axisymmetric two-temperature plasma, three contiguous parts
         c = cases.argon_axisym(6, 9, 2, True, capi.CONSTANT, "arrhenius", True, capi.VISC_ISOTH, r_in=0.0)
         full = meshgen.scramble_orientations(c.mesh, 5)
@@ -70,12 +76,15 @@ def _worker(rank, world, port, q, kind, backend="gloo"):
             dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         full, owner, order, ph, bcs, Ug = _case(world, kind)
         if isinstance(owner, str):
-            part = meshgen.ogrid_cylinder_slab(4, 12, 3, rank, world)
+            if owner == "axislab":
+                part = meshgen.annulus_quad_slab(6, 3, rank, world, r_out=0.05, length_local=0.08)
+            else:
+                part = meshgen.ogrid_cylinder_slab(4, 12, 3, rank, world)
             gel = np.arange(part.num_elements) + rank * part.num_elements
         else:
             part = meshgen.partition(full, world, owner)[rank]
             gel = part.global_elements
-        disc = capi.Disc(order, 0, 0, 1 if kind == "axisym_2T" else 0, 0)
+        disc = capi.Disc(order, 0, 0, 1 if kind.startswith("axisym") else 0, 0)
         npe = (order + 1) ** full.dim
         idx = (gel[:, None] * npe + np.arange(npe)[None, :]).ravel()
         U = Ug[:, idx]  # the rank's rows of ONE global field
@@ -110,7 +119,7 @@ ADV = (2.0e-5, 3, 0.1, 0.05)  # dt0, steps, CFL, hmin of the advance() leg
 
 
 @pytest.mark.parametrize("world,kind", [(2, "dry_air"), (3, "argon_2T"), (2, "slab"), (4, "slab"), (3, "axisym_2T"),
-                                        (3, "dry_air_nr")])
+                                        (3, "dry_air_nr"), (3, "axisym_slab")])
 def test_ranks_match_serial_oracle(world, kind):
     _run_ranks(world, kind, "gloo")
 
@@ -138,7 +147,7 @@ def _run_ranks(world, kind, backend):
         ref = {"y": o.mult(Ug), "gradUp": o.gradients(), "max_char_speed": o.max_char_speed}
         ref_adv = o.advance(Ug, 0.0, ADV[0], ADV[1], False, ADV[2], ADV[3])
     else:
-        ref = oracle_mult(full, capi.Disc(order, 0, 0, 1 if kind == "axisym_2T" else 0, 0), ph, bcs, Ug)
+        ref = oracle_mult(full, capi.Disc(order, 0, 0, 1 if kind.startswith("axisym") else 0, 0), ph, bcs, Ug)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -166,6 +175,6 @@ def _run_ranks(world, kind, backend):
         assert rel_maxnorm(xa, ref_adv[0]).max() < 1e-13
     err = rel_maxnorm(y, ref["y"])
     print(world, "ranks: rel err", err)
-    assert err.max() < (5 * RHS_RTOL if kind in ("argon_2T", "axisym_2T") else RHS_RTOL)  # plasma: 1 % perturbations
+    assert err.max() < (5 * RHS_RTOL if kind in ("argon_2T", "axisym_2T", "axisym_slab") else RHS_RTOL)  # plasma: 1 % perturbations
     assert np.abs(g - ref["gradUp"]).max() < RHS_RTOL * np.abs(ref["gradUp"]).max()
     assert abs(mcs - ref["max_char_speed"]) < 1e-12 * mcs

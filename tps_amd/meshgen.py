@@ -258,6 +258,45 @@ def annulus_quad(nr, nz, r_in=0.0, r_out=1.0, length=2.0, bdr_attr=None):
     return _structured(2, (nr, nz), xyz, (False, False), bdr_attr)
 
 
+def annulus_quad_slab(nr, nz_local, rank, nparts, r_in=0.0, r_out=1.0, length_local=2.0, bdr_attr=None):
+    """Rank ``rank``'s axial slab of an (r, z) block with ``nparts * nz_local`` cells along z (not periodic): the
+    structured equivalent of :func:`partition` for the weak-scaling runs of the axisymmetric workloads, built
+    without forming the global mesh.  Patch 1 (z = 0) belongs to rank 0, patch 2 (z = L) to the last rank; the
+    interfaces in between are shared with ranks ``rank - 1`` and ``rank + 1``."""
+    if bdr_attr is None:
+        bdr_attr = {(0, 0): 4, (0, 1): 3, (1, 0): 1, (1, 1): 2}
+    if nparts == 1:
+        return annulus_quad(nr, nz_local, r_in, r_out, length_local, bdr_attr)
+    k0 = rank * nz_local
+    attrs = dict(bdr_attr)
+    if rank > 0:
+        attrs.pop((1, 0))
+    if rank < nparts - 1:
+        attrs.pop((1, 1))
+
+    def xyz(i, j):
+        return np.stack([r_in + (r_out - r_in) * i / nr, length_local * (j + k0) / nz_local], axis=-1).astype(np.float64)
+
+    m = _structured(2, (nr, nz_local), xyz, (False, False), attrs)
+    nvi = nr + 1  # local vertex id = i + (nr + 1) * j; the global id uses the global layer index
+    i = np.arange(nr)
+    sv, sr, keys = [], [], []
+    for jl, nbr in ((0, rank - 1), (nz_local, rank + 1)):
+        if nbr < 0 or nbr >= nparts:
+            continue
+        ci = np.stack([i, i + 1], axis=1)
+        loc = ci + nvi * jl
+        glo = ci + nvi * (k0 + jl)
+        sv.append(loc)  # already sorted by global id along each edge
+        keys.append(glo)
+        sr.append(np.full(nr, nbr))
+    sv, keys, sr = np.concatenate(sv), np.concatenate(keys), np.concatenate(sr)
+    srt = np.lexsort((keys[:, 1], keys[:, 0], sr))  # by neighbour rank, then by the global key: identical on both sides
+    m.shared_vertices = sv[srt].astype(np.int32)
+    m.shared_neighbor_rank = sr[srt].astype(np.int32)
+    return m
+
+
 # --------------------------------------------------------------------------------------------
 def partition(mesh: HostMesh, nparts: int, owner: np.ndarray | None = None):
     """Split ``mesh`` into ``nparts`` sub-meshes (contiguous element blocks unless ``owner`` is
