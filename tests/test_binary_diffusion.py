@@ -98,3 +98,49 @@ def test_binary_diffusion_matches_the_analytic_solution_of_the_reference_test():
     # where Y is smallest); it is discretisation error -- one refinement takes it well under the reference's bound.
     assert errs[15] < 1.0e-3
     assert errs[30] < 2.0e-4 and errs[30] < errs[15] / 6
+
+
+# ---- test/diffusion_wall.test (test/inputs/argonMinimal.diffusion_wall.ini): the same wave between two isothermal
+# walls (x = 0 and x = 5, T_wall = the gas temperature), periodic in y; the cosine has zero slope at the walls, so the
+# walls' zero species flux is compatible with the closed form.  500 steps of 1e-4 s, tolerance --relative=7e-3.
+def _wall_setup(n=10):
+    lx = ly = 5.0
+    kx, ky, p0, t_end = 1.5, 1.0, 3.0133e-1, 0.05
+    attrs = {(0, 0): 2, (0, 1): 4}
+    mesh = meshgen.box_quad(n, n, lengths=(lx, ly), periodic=(False, True), bdr_attr=attrs)
+    X = node_coordinates(mesh, 3)
+    n_tot = p0 / (R_U * T0)
+    rho = n_tot * M_AR
+    rho_e = n_tot * 1.5 * R_U * T0
+    k_b = R_U / N_A
+    f = 3.0 / 16.0 * np.sqrt(2.0 * np.pi * k_b) / N_A
+    m_n, m_i = M_AR / N_A, (M_AR - M_E) / N_A
+    d_ia = f * np.sqrt(T0 / (m_n * m_i / (m_n + m_i))) / n_tot / (4.574321e-18 * T0 ** -0.1805)
+    decay = np.exp(-(4 * np.pi ** 2 * (kx ** 2 / lx ** 2 + ky ** 2 / ly ** 2)) * d_ia * t_end)
+
+    def state(dec):
+        Y = 0.5 + 0.45 * dec * np.cos(2 * np.pi * kx * X[0] / lx) * np.cos(2 * np.pi * ky * X[1] / ly)
+        U = np.zeros((6, X.shape[1]))
+        U[0], U[3], U[4] = rho, rho_e, rho * Y
+        return U
+
+    bcs = [capi.make_bc(2, capi.WALL, capi.VISC_ISOTH, [T0]), capi.make_bc(4, capi.WALL, capi.VISC_ISOTH, [T0])]
+    return mesh, bcs, state(1.0), state(decay), decay, t_end
+
+
+@pytest.mark.gpu
+def test_diffusion_between_isothermal_walls_matches_the_analytic_solution_of_the_reference_test():
+    import torch
+    from tps_amd.rhs_operator import RHSoperator
+
+    mesh, bcs, Ustart, Uref, decay, t_end = _wall_setup()
+    assert 0.2 < decay < 0.9
+    op = RHSoperator(mesh, capi.Disc(3, 0, 0, 0, 0), _physics(), bcs)
+    x = torch.tensor(np.ascontiguousarray(Ustart).ravel(), dtype=torch.float64, device=op.device)
+    t, _, bad = op.advance(x, 0.0, 1.0e-4, 500, True)
+    got = x.cpu().numpy().reshape(Ustart.shape)
+    op.close()
+    assert bad == 0 and t == pytest.approx(t_end, rel=1e-12)
+    rel = (np.abs(got[4] - Uref[4]) / np.abs(Uref[4])).max()
+    print("decay factor", decay, "max relative difference of rho Y_Ar+", rel)
+    assert rel < 7e-3  # the tolerance of test/diffusion_wall.test
