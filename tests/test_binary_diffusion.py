@@ -144,3 +144,63 @@ def test_diffusion_between_isothermal_walls_matches_the_analytic_solution_of_the
     rel = (np.abs(got[4] - Uref[4]) / np.abs(Uref[4])).max()
     print("decay factor", decay, "max relative difference of rho Y_Ar+", rel)
     assert rel < 7e-3  # the tolerance of test/diffusion_wall.test
+
+
+# ---- test/inflow_outflow.test (test/inputs/argonMinimal.inflow_outflow.ini, utils/tanh_ic.cpp): a tanh composition
+# front of an ambipolar ternary mixture without transport is convected at u0 = 10 m/s out of a 10 x 1 channel
+# (subsonic inlet with the upstream composition, pressure outlet), order 2, 500 RK4 steps of 1e-5 s; rho Y_Ar+ must
+# match the shifted front within --relative=3e-3.
+def _front_setup():
+    lx, ly, nx, ny = 10.0, 1.0, 30, 3
+    m_e, e_f = 5.49e-7, 1520.57e3
+    rho, u0, p0, t_end = 1.6228, 10.0, 1.01272e5, 5.0e-3
+    offset, scale = 10.0, 0.5
+    ph = capi.argon_ternary_physics(capi.NS, False, capi.CONSTANT, None, third_order_ke=False, ambipolar=True)
+    mx, nsp = ph.mixture, 3
+    for sp, (m, ef) in enumerate(((M_AR - m_e, e_f), (m_e, 0.0), (M_AR, 0.0))):
+        mx.gas_params[sp + capi.SPECIES_MW * nsp] = m
+        mx.gas_params[sp + capi.FORMATION_ENERGY * nsp] = ef
+    ct = ph.constant_transport
+    ct.viscosity = ct.bulk_viscosity = ct.thermal_conductivity = ct.electron_thermal_conductivity = 0.0
+    for sp in range(nsp):
+        ct.diffusivity[sp] = 0.0
+    attrs = {(0, 0): 4, (0, 1): 2}
+    mesh = meshgen.box_quad(nx, ny, lengths=(lx, ly), periodic=(False, True), bdr_attr=attrs)
+    X = node_coordinates(mesh, 2)
+
+    def conserved(rho_yi):
+        """modifyEnergyForPressure(sol, sol, p0, false): T from p0 = R (n_i + n_e + n_B) T, energy from T"""
+        n_i = rho_yi / (M_AR - m_e)
+        n_e = n_i
+        n_b = (rho - n_i * (M_AR - m_e) - n_e * m_e) / M_AR
+        T = p0 / (R_U * (n_i + n_e + n_b))
+        e = 1.5 * R_U * (n_i + n_e + n_b) * T + e_f * n_i + 0.5 * rho * u0 * u0
+        return np.array([rho, rho * u0, 0.0, e, rho_yi])
+
+    s1, s2 = conserved(0.16228), conserved(0.0)
+
+    def state(shift):
+        f = 0.5 + 0.5 * np.tanh((X[0] - shift - offset) / scale)
+        return s1[:, None] * (1.0 - f) + s2[:, None] * f
+
+    bcs = [capi.make_bc(4, capi.INLET, capi.SUB_DENS_VEL, [rho, u0, 0.0, 0.0, 0.16228]),
+           capi.make_bc(2, capi.OUTLET, capi.SUB_P, [p0])]
+    return mesh, ph, bcs, state(0.0), state(u0 * t_end), t_end
+
+
+@pytest.mark.gpu
+def test_front_convected_through_the_outlet_matches_the_analytic_solution_of_the_reference_test():
+    import torch
+    from tps_amd.rhs_operator import RHSoperator
+
+    mesh, ph, bcs, Ustart, Uref, t_end = _front_setup()
+    op = RHSoperator(mesh, capi.Disc(2, 0, 0, 0, 0), ph, bcs)
+    x = torch.tensor(np.ascontiguousarray(Ustart).ravel(), dtype=torch.float64, device=op.device)
+    t, _, bad = op.advance(x, 0.0, 1.0e-5, 500, True)
+    got = x.cpu().numpy().reshape(Ustart.shape)
+    op.close()
+    assert bad == 0 and t == pytest.approx(t_end, rel=1e-12)
+    rel = (np.abs(got[4] - Uref[4]) / np.abs(Uref[4])).max()
+    moved = (np.abs(Ustart[4] - Uref[4]) / np.abs(Uref[4])).max()
+    print("front moved by (max relative change)", moved, "max relative difference of rho Y_Ar+", rel)
+    assert rel < 3e-3 < moved  # the tolerance of test/inflow_outflow.test
