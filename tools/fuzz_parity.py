@@ -24,7 +24,7 @@ for it in range(ncases):
     geo = rng.choice(["cyl3d", "box3d", "box2d", "axisym"])
     order = int(rng.integers(1, (6 if geo != "axisym" else 5) if fluid == "dry" else 4))
     eq = capi.NS if rng.random() < 0.85 else capi.EULER
-    wall = int(rng.choice([capi.INV, capi.VISC_ADIAB, capi.VISC_ISOTH]))
+    wall = int(rng.choice([capi.INV, capi.SLIP, capi.VISC_ADIAB, capi.VISC_ISOTH]))
     seed = int(rng.integers(1, 1000))
     amp = 0.05 if fluid == "dry" else (0.005 if order == 1 else 0.01)
     tol = RHS_RTOL * 0.05 / amp
