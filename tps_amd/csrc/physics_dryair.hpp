@@ -14,31 +14,9 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/tpsrhs.h"
+#include "fastmath.hpp"
 
 namespace tpsrhs {
-
-// Reciprocal and square root to ~1 ulp without the IEEE corner-case handling of the compiler's
-// expansions (12-15 instructions each): hardware seed (v_rcp_f64 / v_rsq_f64, about 2^-23 relative
-// error) plus two Newton/Goldschmidt steps.  Arguments on the hot path are positive, normal numbers
-// (densities, temperatures, squared lengths); the 1e-11 parity tolerance leaves 4 digits of margin.
-__device__ inline double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-}
-__device__ inline double fast_sqrt(double x) {
-  if (x <= 0.0) return 0.0;
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  return fma(fma(-g, g, x), h, g);
-}
 
 #ifndef TPSRHS_MINW_GRAD
 #define TPSRHS_MINW_GRAD 1

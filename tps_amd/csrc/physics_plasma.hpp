@@ -58,6 +58,9 @@ constexpr int PLASMA_MAXBC = 8;
 template <int NSP>
 struct PlasmaParams {
   double mw[NSP], charge[NSP], eform[NSP], cv[NSP], cp[NSP];
+  // derived on the host (fill_plasma_params): reciprocal molar masses; per-particle masses m = mw / N_A, their
+  // roots, k_f / m; sqrt(reduced mass of a pair) / d_fc of the binary diffusivities (src/gas_transport.cpp:291-310)
+  double imw[NSP], mwp[NSP], sq_mwp[NSP], kf_imwp[NSP], sq_muw_idfc[NSP * NSP];
   // constant transport
   double c_visc, c_bulk, c_k, c_ke, c_diff[NSP], c_mtfreq[NSP];
   int c_eidx;
@@ -90,27 +93,30 @@ __device__ inline double table_eval(const TableDev &t, double xe) {  // src/tabl
   }
   first = max(1, min(t.n - 1, first));
   const int idx = first - 1;
-  const double xt = t.x_log ? log(xe) : xe;
+  const double xt = t.x_log ? flog(xe) : xe;
   double ft = t.a[idx] + t.b[idx] * xt;
-  if (t.f_log) ft = exp(ft);
+  if (t.f_log) ft = fexp(ft);
   return ft;
 }
 
 namespace coll {  // collision-integral fits, src/collision_integrals.cpp
 // c0 log(1 + c1 Tp^c2)^c3 / Tp^2 with the powers taken through exp/log of the argument's logarithm,
 // which the fits of one point share (the reference calls pow twice per fit; the results agree to a few
-// ulp, far inside the stated tolerance, at a third of the FP64 instructions)
+// ulp, far inside the stated tolerance), and exp / log from fastmath.hpp: 2 x (23 + 33) FP64 instructions
+// per fit where two pow() calls of the device library are 450
 struct Arg {
   double ln, inv2;  // log(Tp), 1/Tp^2
 };
 __device__ inline Arg arg(double Tp) {
   Arg a;
-  a.ln = log(Tp);
-  a.inv2 = 1.0 / (Tp * Tp);
+  a.ln = flog(Tp);
+  const double r = fast_rcp(Tp);
+  a.inv2 = r * r;
   return a;
 }
 __device__ inline double cfit(double c0, double c1, double c2, double c3, const Arg &a) {
-  return c0 * exp(c3 * log(log(1.0 + c1 * exp(c2 * a.ln)))) * a.inv2;
+  // 1 + c1 Tp^c2 >= 1: the inner logarithm needs no special cases (a NaN passes through)
+  return c0 * fexp(c3 * flog(flog_pos(1.0 + c1 * fexp(c2 * a.ln)))) * a.inv2;
 }
 __device__ inline double att11(const Arg &a) { return cfit(0.2150, 5.2194, 1.0472, 1.2435, a); }
 __device__ inline double att12(const Arg &a) { return cfit(0.0991, 7.4684, 1.0155, 1.1536, a); }
@@ -131,9 +137,10 @@ __constant__ static double c_coulomb[2][2][5][4] = {
       {0.0683, 1.9774, 1.2033, 0.8264}, {0.0346, 4.5177, 1.2132, 0.9294}},
      {{0, 0, 0, 0}, {0.4128, 1.2436, 1.1830, 1.0123}, {0.2203, 1.8832, 1.2059, 0.9851}, {0.1323, 2.7248, 1.2129, 0.9847},
       {0, 0, 0, 0}}}};
-__device__ inline double ArAr11(double lnT) { return 2.2910e-18 * exp(-0.3032 * lnT); }
-__device__ inline double ArAr22(double T) { return 1.7e-18 / sqrt(sqrt(T)); }  // T^-0.25
-__device__ inline double ArAr1P11(double lnT) { return 4.574321e-18 * exp(-0.1805 * lnT); }
+__device__ inline double ArAr11(double lnT) { return 2.2910e-18 * fexp(-0.3032 * lnT); }
+__device__ inline double ArAr22(double T) { return 1.7e-18 * fast_rsqrt(fast_sqrt(T)); }  // T^-0.25
+__device__ inline double iArAr22(double sqrtT) { return fast_sqrt(sqrtT) * (1.0 / 1.7e-18); }  // 1 / ArAr22, from sqrt(T)
+__device__ inline double ArAr1P11(double lnT) { return 4.574321e-18 * fexp(-0.1805 * lnT); }
 __device__ inline double eAr1r(int r, double logT) {
   const double C[5][9] = {
       {6.36254140e-18, 1.84835040e-18, -5.87727093e-18, 3.20023027e-18, -8.50509054e-19, 1.28163820e-19,
@@ -146,7 +153,8 @@ __device__ inline double eAr1r(int r, double logT) {
        -8.28466766e-20, 4.11188110e-21, -8.59225098e-23},
       {4.41333290e-17, 1.15696010e-17, -4.25651305e-17, 2.42442440e-17, -6.73359258e-18, 1.06641697e-18,
        -9.83933863e-20, 4.93775812e-21, -1.04362372e-22}};
-  double fit = C[r - 1][0] / logT, pw = 1.0;
+  // summed in the reference's order (the terms cancel to 1e-3 of their size: the order is part of the result)
+  double fit = C[r - 1][0] * fast_rcp(logT), pw = 1.0;
 #pragma unroll
   for (int k = 1; k < 9; k++) {
     fit += C[r - 1][k] * pw;
@@ -156,6 +164,9 @@ __device__ inline double eAr1r(int r, double logT) {
 }
 }  // namespace coll
 
+#ifndef TPSRHS_PLASMA_MINW_GRAD3
+#define TPSRHS_PLASMA_MINW_GRAD3 2
+#endif
 enum { TRANSPORT_CONSTANT = 0, TRANSPORT_ARGON_MINIMAL = 1, TRANSPORT_ARGON_MIXTURE = 2 };
 
 template <int DIM_, int NVEL_, int NSP_, bool AMBI, bool TWOT, int TRANSPORT>
@@ -171,7 +182,7 @@ struct PlasmaPhys {
   static constexpr bool HAS_NR_BC = false;  // the reference's non-reflecting conditions are perfect-gas algebra
   static constexpr bool VISC_USES_GRAD_RHO = true;  // mole-fraction gradients need grad(rho)
   static constexpr bool AXISYM = NVEL_ > DIM_;  // dim 2 with (r, z, theta) velocity components
-  static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : 2, MINW_FLUX = 2;  // waves per SIMD asked of the allocator
+  static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : TPSRHS_PLASMA_MINW_GRAD3, MINW_FLUX = 2;  // waves per SIMD asked of the allocator
   typedef PlasmaParams<NSP_> Params;
   struct Transport {};
 
@@ -186,7 +197,7 @@ struct PlasmaPhys {
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++) n[sp] = 0.0;
 #pragma unroll
-    for (int sp = 0; sp < NACTIVE; sp++) n[sp] = U[NVEL + 2 + sp] / p.mw[sp];
+    for (int sp = 0; sp < NACTIVE; sp++) n[sp] = U[NVEL + 2 + sp] * p.imw[sp];
     double rhoB = U[0];
 #pragma unroll
     for (int sp = 0; sp < NACTIVE; sp++) rhoB -= p.mw[sp] * n[sp];
@@ -198,7 +209,7 @@ struct PlasmaPhys {
       n[IE] = ne;
       rhoB -= ne * p.mw[IE];
     }
-    n[IB] = rhoB / p.mw[IB];
+    n[IB] = rhoB * p.imw[IB];
   }
   __device__ static inline double heavies_cv(const Params &p, const double *n) {  // :576-584
     double c = 0.0;
@@ -217,7 +228,7 @@ struct PlasmaPhys {
   __device__ static inline State make_state(const Params &p, const double *U) {
     State s;
     number_densities(p, U, s.n);
-    s.ir = 1.0 / U[0];
+    s.ir = fast_rcp(U[0]);
     double m2 = 0.0;
 #pragma unroll
     for (int d = 0; d < NVEL; d++) {
@@ -234,15 +245,15 @@ struct PlasmaPhys {
     for (int sp = 0; sp < NSP - 2; sp++) e -= s.n[sp] * p.eform[sp];
     double Th = -0.5 * s.k + e;
     if (TWOT) Th -= U[ITE];
-    s.Th = Th / ctot;
-    s.Te = TWOT ? U[ITE] / s.n[IE] / p.cv[IE] : s.Th;
+    s.Th = Th * fast_rcp(ctot);
+    s.Te = TWOT ? U[ITE] * fast_rcp(s.n[IE] * p.cv[IE]) : s.Th;
     // computePressureBase, :1044-1062
     const double nh = heavies_n(s.n);
     s.pe = s.n[IE] * kRgas * s.Te;
     s.p = kRgas * (nh * s.Th + s.n[IE] * s.Te);
     // speed of sound: heavies' heat ratio, :1311-1340
-    const double gamma = 1.0 + nh * kRgas / chv;
-    s.c = sqrt(gamma * s.p * s.ir);
+    const double gamma = 1.0 + nh * kRgas * fast_rcp(chv);
+    s.c = fast_sqrt(gamma * s.p * s.ir);
     return s;
   }
   __device__ static inline double pressure(const Params &p, const double *U) { return make_state(p, U).p; }
@@ -252,7 +263,7 @@ struct PlasmaPhys {
     const State s = make_state(p, U);
     Up[0] = U[0];
 #pragma unroll
-    for (int d = 0; d < NVEL; d++) Up[1 + d] = U[1 + d] / U[0];
+    for (int d = 0; d < NVEL; d++) Up[1 + d] = s.vel[d];
     Up[ITH] = s.Th;
 #pragma unroll
     for (int sp = 0; sp < NACTIVE; sp++) Up[NVEL + 2 + sp] = s.n[sp];
@@ -264,7 +275,7 @@ struct PlasmaPhys {
     for (int sp = 0; sp < NACTIVE; sp++) U[NVEL + 2 + sp] = fmax(U[NVEL + 2 + sp], 0.0);
   }
   __device__ static inline double max_char_speed(const Params &, const double *, const State &s) {  // :1359-1373
-    return sqrt(s.k * s.ir) + s.c;
+    return fast_sqrt(s.k * s.ir) + s.c;
   }
   __device__ static inline double max_char_speed(const Params &p, const double *U) {
     return max_char_speed(p, U, make_state(p, U));
@@ -297,7 +308,7 @@ struct PlasmaPhys {
     double nm = 0.0;
 #pragma unroll
     for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
-    const double hl = 0.5 * lam * sqrt(nm);
+    const double hl = 0.5 * lam * fast_sqrt(nm);
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) F[eq] = 0.5 * (f1[eq] + f2[eq]) - hl * (U2[eq] - U1[eq]);
   }
@@ -312,19 +323,19 @@ struct PlasmaPhys {
   }
   // ---- species primitives and mole-fraction gradient --------------------------------------
   struct Species {
-    double X[NSP], Y[NSP], n[NSP], ntot;
+    double X[NSP], Y[NSP], n[NSP], ntot, intot;
   };
   // computeSpeciesPrimitives (:882-927): its own number densities (electrons not clamped, background
   // from the mass-fraction remainder), kept apart from computeNumberDensities as in the reference
   __device__ static inline Species species(const Params &p, const double *U) {
     Species q;
-    const double ir = 1.0 / U[0];
+    const double ir = fast_rcp(U[0]);
     double n = 0.0, ne = 0.0, Yb = 1.0;
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++) q.n[sp] = 0.0;
 #pragma unroll
     for (int sp = 0; sp < NACTIVE; sp++) {
-      q.n[sp] = U[NVEL + 2 + sp] / p.mw[sp];
+      q.n[sp] = U[NVEL + 2 + sp] * p.imw[sp];
       n += q.n[sp];
       if (AMBI) ne += p.charge[sp] * q.n[sp];
       q.Y[sp] = U[NVEL + 2 + sp] * ir;
@@ -337,15 +348,16 @@ struct PlasmaPhys {
       Yb -= q.Y[IE];
     }
     q.Y[IB] = Yb;
-    q.n[IB] = Yb * U[0] / p.mw[IB];
+    q.n[IB] = Yb * U[0] * p.imw[IB];
     n += q.n[IB];
     q.ntot = n;
+    q.intot = fast_rcp(n);
 #pragma unroll
-    for (int sp = 0; sp < NSP; sp++) q.X[sp] = q.n[sp] / n;
+    for (int sp = 0; sp < NSP; sp++) q.X[sp] = q.n[sp] * q.intot;
     return q;
   }
-  __device__ static inline void mole_fraction_grad(const Params &p, const double *n, double ntot, const double *g,
-                                                   double *gX) {  // :1534-1592
+  __device__ static inline void mole_fraction_grad(const Params &p, const double *n, double in, const double *g,
+                                                   double *gX) {  // :1534-1592; in = 1 / total number density
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
       double ne = 0.0, nb = g[0 + d * NEQ], nt = 0.0;
@@ -357,10 +369,9 @@ struct PlasmaPhys {
         nt += gs;
       }
       if (AMBI) nb -= p.mw[IE] * ne;
-      nb /= p.mw[IB];
+      nb *= p.imw[IB];
       if (AMBI) nt += ne;
       nt += nb;
-      const double in = 1.0 / ntot;
 #pragma unroll
       for (int sp = 0; sp < NACTIVE; sp++)
         gX[sp + d * NSP] = g[(NVEL + 2 + sp) + d * NEQ] * in - n[sp] * in * in * nt;
@@ -382,19 +393,22 @@ struct PlasmaPhys {
     double circle;
     coll::Arg e, h;  // nondimensional electron / heavy temperatures
   };
-  __device__ static inline Debye debye(const double *n, double Th, double Te) {
+  // iTe, iTh = 1 / T_e, 1 / T_h
+  __device__ static inline Debye debye(const double *n, double Th, double Te, double iTh, double iTe) {
     const double dfac = kBoltz * kEps0 / kQe / kQe;
-    const double nOverT = (n[I_E] + kXeps) / Te + (n[I_ION] + kXeps) / Th;
-    const double length = sqrt(dfac / kAvogadro / nOverT);
+    const double nOverT = (n[I_E] + kXeps) * iTe + (n[I_ION] + kXeps) * iTh;
+    const double len2 = (dfac / kAvogadro) * fast_rcp(nOverT);
+    const double length = fast_sqrt(len2);
     Debye d;
-    d.circle = kPi * length * length;
-    const double f = length * 4.0 * kPi * dfac;
+    d.circle = kPi * len2;
+    const double f = length * (4.0 * kPi * dfac);
     d.e = coll::arg(f * Te);
     d.h = TWOT ? coll::arg(f * Th) : d.e;
     return d;
   }
-  __device__ static inline double third_order_ke(const double *X, const Debye &d, double Te, double lnTe, double att11c,
-                                                 double me, double vf, double kf) {  // :400-489
+  // sTe = sqrt(T_e), c_ke = v_f k_f sqrt(2 / m_e)
+  __device__ static inline double third_order_ke(const double *X, const Debye &d, double sTe, double lnTe, double att11c,
+                                                 double c_ke) {  // :400-489
     const double Q2[3] = {d.circle * coll::rep22(d.e), d.circle * coll::rep23(d.e), d.circle * coll::rep24(d.e)};
     const double QI[5] = {att11c, d.circle * coll::att12(d.e), d.circle * coll::att13(d.e), d.circle * coll::att14(d.e),
                           d.circle * coll::att15(d.e)};
@@ -406,7 +420,7 @@ struct PlasmaPhys {
     auto L22ea = [](const double *Q) {
       return 19.140625 * Q[0] - 91.875 * Q[1] + 199.5 * Q[2] - 210. * Q[3] + 90. * Q[4];
     };
-    const double s2 = sqrt(2.0);
+    constexpr double s2 = 1.4142135623730951;  // sqrt(2)
     double L11 = s2 * X[I_E] * Q2[0];
     L11 += X[I_ION] * L11ea(QI);
     L11 += X[I_N] * L11ea(QN);
@@ -416,7 +430,7 @@ struct PlasmaPhys {
     double L22 = s2 * X[I_E] * (4.8125 * Q2[0] - 7.0 * Q2[1] + 5. * Q2[2]);
     L22 += X[I_ION] * L22ea(QI);
     L22 += X[I_N] * L22ea(QN);
-    return vf * kf * sqrt(2.0 * Te / me) * X[I_E] / (L11 - L12 * L12 / L22);
+    return c_ke * sTe * X[I_E] * fast_rcp(L11 - L12 * L12 * fast_rcp(L22));
   }
 
   // collisionInputs of the mixture transport (src/gas_transport.cpp:185-204): the Debye length sums
@@ -428,17 +442,19 @@ struct PlasmaPhys {
   __device__ static inline MixColl mix_inputs(const Params &p, const double *n, double Th, double Te) {
     const double dfac = kBoltz * kEps0 / kQe / kQe;
     double nOverT = 0.0;
+    const double iTe = fast_rcp(Te);
 #pragma unroll
-    for (int sp = 0; sp < NSP; sp++) nOverT += (n[sp] + kXeps) / Te * p.charge[sp] * p.charge[sp];
-    const double length = sqrt(dfac / kAvogadro / nOverT);
+    for (int sp = 0; sp < NSP; sp++) nOverT += (n[sp] + kXeps) * iTe * p.charge[sp] * p.charge[sp];
+    const double len2 = (dfac / kAvogadro) * fast_rcp(nOverT);
+    const double length = fast_sqrt(len2);
     MixColl c;
-    c.circle = kPi * length * length;
-    const double f = length * 4.0 * kPi * dfac;
+    c.circle = kPi * len2;
+    const double f = length * (4.0 * kPi * dfac);
     c.e = coll::arg(f * Te);
     c.h = TWOT ? coll::arg(f * Th) : c.e;
     c.Th = Th;
-    c.lnTe = log(Te);
-    c.lnTh = TWOT ? log(Th) : c.lnTe;
+    c.lnTe = flog(Te);
+    c.lnTh = TWOT ? flog(Th) : c.lnTe;
     return c;
   }
   // GasMixtureTransport::collisionIntegral (src/gas_transport.cpp:995-1283), argon types.  (l, r) and the
@@ -461,6 +477,13 @@ struct PlasmaPhys {
 
   // ComputeFluxTransportProperties of the selected model; E-field = 0 (src/fluxes.cpp:200-201).
   // `diffusion` = false skips the diffusion velocities (walls prescribe zero species fluxes).
+  //
+  // Algebra of the collision-integral models, arranged for few FP64 divisions (the reference's order of
+  // operations divides ~90 times per point; each division is 10 instructions, a product with a reciprocal 1):
+  //   sqrt(m T) = sqrt(m) sqrt(T), sqrt(T / mu) = sqrt(T) / sqrt(mu) with the mass factors from the host;
+  //   1 / D_ij = n Q_ij sqrt(mu_ij) / (d_fc sqrt(T)) directly (CurtissHirschfelder only ever divides by D_ij);
+  //   one reciprocal each of T_e, T_h, n, X_sp + eps, shared by everything that divides by them.
+  // Results differ from the reference's order by rounding (a few ulp).
   __device__ static inline void transport(const Params &p, const double *U, double Th, double Te, const double *g,
                                           bool diffusion, Trans &t) {
     const Species q = species(p, U);
@@ -469,6 +492,8 @@ struct PlasmaPhys {
 #pragma unroll
     for (int k = 0; k < NSP * DIM; k++) t.V[k] = 0.0;
     double diff[NSP], mob[NSP];
+    const double iTe = fast_rcp(Te), iTh = TWOT ? fast_rcp(Th) : iTe;
+    const double vf = 5. / 16. * sqrt(kPi * kBoltz), kf = 15. / 4. * kBoltz;  // folded at compile time
     if (TRANSPORT == TRANSPORT_CONSTANT) {
       t.visc = p.c_visc;
       t.bulk = p.c_bulk;
@@ -477,26 +502,23 @@ struct PlasmaPhys {
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) {
         diff[sp] = p.c_diff[sp];
-        const double temp = (sp == p.c_eidx) ? Te : Th;
-        mob[sp] = (kQe / kBoltz) * p.charge[sp] / temp * diff[sp];
+        const double itemp = (sp == p.c_eidx) ? iTe : iTh;
+        mob[sp] = (kQe / kBoltz) * p.charge[sp] * itemp * diff[sp];
       }
     } else if (TRANSPORT == TRANSPORT_ARGON_MIXTURE) {  // GasMixtureTransport, src/gas_transport.cpp:1285-1407
-      const double vf = 5. / 16. * sqrt(kPi * kBoltz), kf = 15. / 4. * kBoltz;
-      const double dfc = 3. / 16. * sqrt(2.0 * kPi * kBoltz) / kAvogadro;
-      double mwp[NSP];
-#pragma unroll
-      for (int sp = 0; sp < NSP; sp++) mwp[sp] = p.mw[sp] / kAvogadro;
       const MixColl c = mix_inputs(p, q.n, Th, Te);
+      const double sTe = fast_sqrt(Te), sTh = TWOT ? fast_sqrt(Th) : sTe;
       t.visc = t.bulk = t.k = 0.0;
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) {
         if (sp == IE) continue;
-        const double sv = vf * sqrt(mwp[sp] * Th) / collision<2, 2>(p, sp, sp, c);
+        const double sv = vf * p.sq_mwp[sp] * sTh * fast_rcp(collision<2, 2>(p, sp, sp, c));
         t.visc += q.X[sp] * sv;
-        t.k += q.X[sp] * (sv * kf / mwp[sp]);
+        t.k += q.X[sp] * (sv * p.kf_imwp[sp]);
       }
+      const double ke_fac = vf * kf * sTe * q.X[IE] * fast_rsqrt(p.mwp[IE]);  // v_f k_f sqrt(T_e / m_e) X_e
       if (p.third_order) {  // :1388-1407
-        const double s2 = sqrt(2.0);
+        constexpr double s2 = 1.4142135623730951;
         const double Q22 = collision<2, 2>(p, IE, IE, c), Q23 = collision<2, 3>(p, IE, IE, c),
                      Q24 = collision<2, 4>(p, IE, IE, c);
         double L11 = s2 * q.X[IE] * Q22;
@@ -511,31 +533,29 @@ struct PlasmaPhys {
           L12 += q.X[sp] * (10.9375 * Q1[0] - 39.375 * Q1[1] + 57. * Q1[2] - 30. * Q1[3]);
           L22 += q.X[sp] * (19.140625 * Q1[0] - 91.875 * Q1[1] + 199.5 * Q1[2] - 210. * Q1[3] + 90. * Q1[4]);
         }
-        t.ke = vf * kf * sqrt(2.0 * Te / mwp[IE]) * q.X[IE] / (L11 - L12 * L12 / L22);
+        t.ke = s2 * ke_fac * fast_rcp(L11 - L12 * L12 * fast_rcp(L22));
       } else {
-        t.ke = vf * kf * sqrt(Te / mwp[IE]) * q.X[IE] / collision<2, 2>(p, IE, IE, c);
+        t.ke = ke_fac * fast_rcp(collision<2, 2>(p, IE, IE, c));
       }
       if (diffusion) {
-        double bd[NSP * NSP];
+        double ibd[NSP * NSP];  // 1 / D_ij
 #pragma unroll
-        for (int i = 0; i < NSP * NSP; i++) bd[i] = 0.0;
+        for (int i = 0; i < NSP * NSP; i++) ibd[i] = 0.0;
+        const double nrsTe = q.ntot * (sTe * iTe), nrsTh = TWOT ? q.ntot * (sTh * iTh) : nrsTe;  // n / sqrt(T)
 #pragma unroll
         for (int i = 0; i < NSP - 1; i++)
 #pragma unroll
-          for (int j = i + 1; j < NSP; j++) {
-            const double temp = (i == IE || j == IE) ? Te : Th;
-            const double muw = mwp[i] * mwp[j] / (mwp[i] + mwp[j]);
-            bd[i + j * NSP] = bd[j + i * NSP] = dfc * sqrt(temp / muw) / q.ntot / collision<1, 1>(p, i, j, c);
-          }
+          for (int j = i + 1; j < NSP; j++)
+            ibd[i + j * NSP] = ibd[j + i * NSP] =
+                ((i == IE || j == IE) ? nrsTe : nrsTh) * p.sq_muw_idfc[i + j * NSP] * collision<1, 1>(p, i, j, c);
 #pragma unroll
         for (int i = 0; i < NSP; i++) {
           double a = 0.0;
 #pragma unroll
           for (int j = 0; j < NSP; j++)
-            if (i != j) a += (q.X[j] + kXeps) / bd[i + j * NSP];
-          diff[i] = (1.0 - q.Y[i]) / a;
-          const double temp = (i == IE) ? Te : Th;
-          mob[i] = (kQe / kBoltz) * p.charge[i] / temp * diff[i];
+            if (i != j) a += (q.X[j] + kXeps) * ibd[i + j * NSP];
+          diff[i] = (1.0 - q.Y[i]) * fast_rcp(a);
+          mob[i] = (kQe / kBoltz) * p.charge[i] * ((i == IE) ? iTe : iTh) * diff[i];
         }
       }
       if (p.multiply) {
@@ -549,50 +569,40 @@ struct PlasmaPhys {
           mob[sp] *= p.mult_mobil;
         }
       }
-    } else {
-      const double vf = 5. / 16. * sqrt(kPi * kBoltz), kf = 15. / 4. * kBoltz;
-      const double dfc = 3. / 16. * sqrt(2.0 * kPi * kBoltz) / kAvogadro;
-      double mwp[NSP];  // per-particle masses
-#pragma unroll
-      for (int sp = 0; sp < NSP; sp++) mwp[sp] = p.mw[sp] / kAvogadro;
-      const Debye d = debye(q.n, Th, Te);
-      const double lnTe = log(Te), lnTh = TWOT ? log(Th) : lnTe;
+    } else {  // GasMinimalTransport::ComputeFluxTransportProperties, src/gas_transport.cpp:206-398
+      const double sTe = fast_sqrt(Te), sTh = TWOT ? fast_sqrt(Th) : sTe;
+      const Debye d = debye(q.n, Th, Te, iTh, iTe);
+      const double lnTe = flog(Te), lnTh = TWOT ? flog(Th) : lnTe;
       const double QeAr = coll::eAr1r(1, lnTe), Qatt = coll::att11(d.e) * d.circle;
-      double sv[NSP];
-#pragma unroll
-      for (int sp = 0; sp < NSP; sp++) sv[sp] = 0.0;
-      sv[I_ION] = vf * sqrt(mwp[I_ION] * Th) / (coll::rep22(d.h) * d.circle);
-      sv[I_N] = vf * sqrt(mwp[I_N] * Th) / coll::ArAr22(Th);
-      t.visc = t.bulk = t.k = 0.0;
-#pragma unroll
-      for (int sp = 0; sp < NSP; sp++) {
-        t.visc += q.X[sp] * sv[sp];
-        t.k += q.X[sp] * (sv[sp] * kf / mwp[sp]);
-      }
+      const double rep22h = coll::rep22(d.h) * d.circle;
+      const double sv_ion = vf * p.sq_mwp[I_ION] * sTh * fast_rcp(rep22h);
+      const double sv_n = vf * p.sq_mwp[I_N] * sTh * coll::iArAr22(sTh);
+      t.bulk = 0.0;
+      t.visc = q.X[I_ION] * sv_ion + q.X[I_N] * sv_n;
+      t.k = q.X[I_ION] * (sv_ion * p.kf_imwp[I_ION]) + q.X[I_N] * (sv_n * p.kf_imwp[I_N]);
+      const double ke_fac = vf * kf * fast_rsqrt(p.mwp[I_E]);  // uniform: v_f k_f / sqrt(m_e)
       if (p.third_order)
-        t.ke = third_order_ke(q.X, d, Te, lnTe, Qatt, mwp[I_E], vf, kf);
+        t.ke = third_order_ke(q.X, d, sTe, lnTe, Qatt, 1.4142135623730951 * ke_fac);
       else
-        t.ke = vf * kf * sqrt(Te / mwp[I_E]) * q.X[I_E] / (coll::rep22(d.e) * d.circle);
+        t.ke = ke_fac * sTe * q.X[I_E] * fast_rcp(TWOT ? coll::rep22(d.e) * d.circle : rep22h);
       __builtin_amdgcn_sched_barrier(0);  // the collision integrals of k_e are dead here: keep it that way
       if (diffusion) {
-        auto muw = [&](int i, int j) { return mwp[i] * mwp[j] / (mwp[i] + mwp[j]); };
-        double bd[NSP * NSP];
+        const double nrsTe = q.ntot * (sTe * iTe), nrsTh = TWOT ? q.ntot * (sTh * iTh) : nrsTe;  // n / sqrt(T)
+        double ibd[NSP * NSP];  // 1 / D_ij (:291-310)
 #pragma unroll
-        for (int i = 0; i < NSP * NSP; i++) bd[i] = 0.0;
-        bd[I_E + I_N * NSP] = bd[I_N + I_E * NSP] = dfc * sqrt(Te / muw(I_E, I_N)) / q.ntot / QeAr;
-        bd[I_N + I_ION * NSP] = bd[I_ION + I_N * NSP] =
-            dfc * sqrt(Th / muw(I_N, I_ION)) / q.ntot / coll::ArAr1P11(lnTh);
-        bd[I_E + I_ION * NSP] = bd[I_ION + I_E * NSP] = dfc * sqrt(Te / muw(I_ION, I_E)) / q.ntot / Qatt;
+        for (int i = 0; i < NSP * NSP; i++) ibd[i] = 0.0;
+        ibd[I_E + I_N * NSP] = ibd[I_N + I_E * NSP] = nrsTe * p.sq_muw_idfc[I_E + I_N * NSP] * QeAr;
+        ibd[I_N + I_ION * NSP] = ibd[I_ION + I_N * NSP] = nrsTh * p.sq_muw_idfc[I_N + I_ION * NSP] * coll::ArAr1P11(lnTh);
+        ibd[I_E + I_ION * NSP] = ibd[I_ION + I_E * NSP] = nrsTe * p.sq_muw_idfc[I_E + I_ION * NSP] * Qatt;
         // CurtissHirschfelder, src/transport_properties.cpp:188-201
 #pragma unroll
         for (int i = 0; i < NSP; i++) {
           double a = 0.0;
 #pragma unroll
           for (int j = 0; j < NSP; j++)
-            if (i != j) a += (q.X[j] + kXeps) / bd[i + j * NSP];
-          diff[i] = (1.0 - q.Y[i]) / a;
-          const double temp = (i == I_E) ? Te : Th;
-          mob[i] = (kQe / kBoltz) * p.charge[i] / temp * diff[i];
+            if (i != j) a += (q.X[j] + kXeps) * ibd[i + j * NSP];
+          diff[i] = (1.0 - q.Y[i]) * fast_rcp(a);
+          mob[i] = (kQe / kBoltz) * p.charge[i] * ((i == I_E) ? iTe : iTh) * diff[i];
         }
       }
       if (p.multiply) {
@@ -614,16 +624,20 @@ struct PlasmaPhys {
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++) mho += mob[sp] * q.n[sp] * p.charge[sp];
     double gX[NSP * DIM];
-    mole_fraction_grad(p, q.n, q.ntot, g, gX);
+    mole_fraction_grad(p, q.n, q.intot, g, gX);
+    double dX[NSP];  // D / (X + eps)
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) dX[sp] = diff[sp] * fast_rcp(q.X[sp] + kXeps);
+    const double imho = AMBI ? fast_rcp(mho + kXeps) : 0.0;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
 #pragma unroll
-      for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] = -diff[sp] * gX[sp + d * NSP] / (q.X[sp] + kXeps);
+      for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] = -dX[sp] * gX[sp + d * NSP];
       if (AMBI) {
         double ambE = 0.0;
 #pragma unroll
         for (int sp = 0; sp < NSP; sp++) ambE -= t.V[sp + d * NSP] * q.n[sp] * p.charge[sp];
-        ambE /= (mho + kXeps);
+        ambE *= imho;
 #pragma unroll
         for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] += mob[sp] * ambE;
       }
@@ -652,21 +666,21 @@ struct PlasmaPhys {
       for (int sp = 0; sp < NSP; sp++) mtfreq[sp] = p.c_mtfreq[sp];
     } else if (TRANSPORT == TRANSPORT_ARGON_MIXTURE) {  // src/gas_transport.cpp:1445-1459
       const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
-      const double me = p.mw[IE] / kAvogadro;
       const MixColl c = mix_inputs(p, q.n, Th, Te);
+      const double vth = mff * fast_sqrt(Te) * fast_rsqrt(p.mwp[IE]);  // mff sqrt(T_e / m_e)
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) {
         if (sp == IE) continue;
-        mtfreq[sp] = mff * sqrt(Te / me) * q.n[sp] * collision<1, 1>(p, sp, IE, c);
+        mtfreq[sp] = vth * q.n[sp] * collision<1, 1>(p, sp, IE, c);
         if (p.multiply) mtfreq[sp] *= p.mult_spcs;
       }
     } else {
       const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
-      const double me = p.mw[I_E] / kAvogadro;
-      const Debye d = debye(q.n, Th, Te);
-      const double QeAr = coll::eAr1r(1, log(Te)), Qatt = coll::att11(d.e) * d.circle;
-      mtfreq[I_ION] = mff * sqrt(Te / me) * q.n[I_ION] * Qatt;
-      mtfreq[I_N] = mff * sqrt(Te / me) * q.n[I_N] * QeAr;
+      const Debye d = debye(q.n, Th, Te, fast_rcp(Th), fast_rcp(Te));
+      const double QeAr = coll::eAr1r(1, flog(Te)), Qatt = coll::att11(d.e) * d.circle;
+      const double vth = mff * fast_sqrt(Te) * fast_rsqrt(p.mwp[I_E]);  // mff sqrt(T_e / m_e)
+      mtfreq[I_ION] = vth * q.n[I_ION] * Qatt;
+      mtfreq[I_N] = vth * q.n[I_N] * QeAr;
       if (p.multiply) {
 #pragma unroll
         for (int sp = 0; sp < NSP; sp++) mtfreq[sp] *= p.mult_spcs;
@@ -976,7 +990,7 @@ struct PlasmaPhys {
       double nm = 0.0;
 #pragma unroll
       for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
-      nm = sqrt(nm);
+      nm = fast_sqrt(nm);
       double vn = 0.0;
 #pragma unroll
       for (int d = 0; d < DIM; d++) vn += (U[1 + d] / U[0]) * (n[d] / nm);
@@ -1035,7 +1049,7 @@ struct PlasmaPhys {
           double nm = 0.0, vn = 0.0;
 #pragma unroll
           for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
-          nm = sqrt(nm);
+          nm = fast_sqrt(nm);
 #pragma unroll
           for (int d = 0; d < DIM; d++) vn += (U[1 + d] / U[0]) * (n[d] / nm);
 #pragma unroll
@@ -1058,7 +1072,7 @@ struct PlasmaPhys {
           double nm = 0.0;
 #pragma unroll
           for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
-          w.nm = sqrt(nm);
+          w.nm = fast_sqrt(nm);
           if (ec == TPSRHS_SHTH) sheath(p, Us, w);
         }
       }
@@ -1099,7 +1113,7 @@ struct PlasmaPhys {
       visc = 0.0;
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++)
-        if (sp != IE) visc += q.X[sp] * (vf * sqrt(p.mw[sp] / kAvogadro * Th) / collision<2, 2>(p, sp, sp, c));
+        if (sp != IE) visc += q.X[sp] * (vf * p.sq_mwp[sp] * fast_sqrt(Th) * fast_rcp(collision<2, 2>(p, sp, sp, c)));
       bulk = 0.0;
       if (p.multiply) {
         visc *= p.mult_flux[0];
@@ -1107,9 +1121,10 @@ struct PlasmaPhys {
       }
       return;
     }
-    const Debye d = debye(q.n, Th, Te);
-    const double sv_ion = vf * sqrt(p.mw[I_ION] / kAvogadro * Th) / (coll::rep22(d.h) * d.circle);
-    const double sv_n = vf * sqrt(p.mw[I_N] / kAvogadro * Th) / coll::ArAr22(Th);
+    const Debye d = debye(q.n, Th, Te, fast_rcp(Th), fast_rcp(Te));
+    const double sTh = fast_sqrt(Th);
+    const double sv_ion = vf * p.sq_mwp[I_ION] * sTh * fast_rcp(coll::rep22(d.h) * d.circle);
+    const double sv_n = vf * p.sq_mwp[I_N] * sTh * coll::iArAr22(sTh);
     visc = q.X[I_ION] * sv_ion + q.X[I_N] * sv_n;
     bulk = 0.0;
     if (p.multiply) {
@@ -1208,10 +1223,10 @@ struct PlasmaPhys {
         const double A = c.rate[0 + r * 3], b = c.rate[1 + r * 3], E = c.rate[2 + r * 3];
         double kf;
         if (c.model[r] == TPSRHS_ARRHENIUS) {  // A T^b exp(-E/RT) in one exponential
-          kf = A * exp(b * log(temp) - E / kRgas / temp);
+          kf = A * fexp(b * flog(temp) - E / kRgas / temp);
         } else if (c.model[r] == TPSRHS_HOFFERTLIEN) {
           const double tf = E / kBoltz / temp;
-          kf = A * (tf + 2.0) * exp(b * log(temp) - tf);
+          kf = A * (tf + 2.0) * fexp(b * flog(temp) - tf);
         } else {
           kf = table_eval(c.table[r], temp);
         }
@@ -1219,7 +1234,7 @@ struct PlasmaPhys {
 #pragma unroll
         for (int sp = 0; sp < NSP; sp++) rate *= ipow(t.n[sp], c.reactant[sp + r * NSP]);
         if (c.detailed_balance[r]) {
-          const double kc = c.keq[0 + r * 3] * exp(c.keq[1 + r * 3] * log(temp) - c.keq[2 + r * 3] / temp);
+          const double kc = c.keq[0 + r * 3] * fexp(c.keq[1 + r * 3] * flog(temp) - c.keq[2 + r * 3] / temp);
           double bwd = 1.0;
 #pragma unroll
           for (int sp = 0; sp < NSP; sp++) bwd *= ipow(t.n[sp], c.product[sp + r * NSP]);

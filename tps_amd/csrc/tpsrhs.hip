@@ -65,6 +65,16 @@ void fill_plasma_params(tpsrhs_operator *op, const tpsrhs_disc *disc, const tpsr
     p.eform[sp] = mx.gas_params[sp + TPSRHS_FORMATION_ENERGY * NSP];
     p.cv[sp] = mx.molar_cv[sp] * kRgas;
     p.cp[sp] = p.cv[sp] + kRgas;
+    p.imw[sp] = 1.0 / p.mw[sp];
+    p.mwp[sp] = p.mw[sp] / kAvogadro;
+    p.sq_mwp[sp] = std::sqrt(p.mwp[sp]);
+    p.kf_imwp[sp] = (15. / 4. * kBoltz) / p.mwp[sp];
+  }
+  {  // sqrt(m_i m_j / (m_i + m_j)) / d_fc of the binary diffusivities (src/gas_transport.cpp:291-310,1353-1365)
+    const double dfc = 3. / 16. * std::sqrt(2.0 * kPi * kBoltz) / kAvogadro;
+    for (int i = 0; i < NSP; i++)
+      for (int j = 0; j < NSP; j++)
+        p.sq_muw_idfc[i + j * NSP] = std::sqrt(p.mwp[i] * p.mwp[j] / (p.mwp[i] + p.mwp[j])) / dfc;
   }
   // PerfectMixture::PerfectMixture consistency checks, src/equation_of_state.cpp:505-530
   if (p.charge[NSP - 1] != 0.0 || p.eform[NSP - 2] != 0.0 || p.eform[NSP - 1] != 0.0)
