@@ -1,21 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: RHSoperator::Mult on the 3-D p=3 cylinder workloads.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload argon_p3|cfg2|cfg3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload argon_p3|cfg2|cfg3|cfg5|torch6]
 
 A "step" is one ``Mult`` (one explicit DG right-hand-side evaluation) over state resident in HBM.
-The mesh of every workload is the 28x112x16 = 50 176-hex O-grid cylinder of BASELINE.json
+The mesh of the 3-D workloads is the 28x112x16 = 50 176-hex O-grid cylinder of BASELINE.json
 configs[1]/[2] per GPU.  Workloads:
-  cfg2 (default)  configs[1], the 3-D p=3 cylinder configuration the metric is quoted on for one GPU:
-                  perfect-gas Navier-Stokes, 5 equations, 3 211 264 nodes
-  cfg3            configs[2]: reacting argon ternary plasma (ambipolar, single temperature, argon-minimal
-                  transport, 2 Arrhenius reactions) at p=2, 6 equations
+  argon_p3 (default)  the metric's "3D p=3 reacting cyl": the reacting argon ternary plasma of configs[2]
+                  (ambipolar, single temperature, argon-minimal collision-integral transport with third-order
+                  electron conductivity, 2 Arrhenius reactions) at the order and on the mesh of configs[1];
+                  6 equations, 3 211 264 nodes
+  cfg2            configs[1]: perfect-gas Navier-Stokes, p=3, 5 equations, 3 211 264 nodes
+  cfg3            configs[2] itself: the same plasma at p=2
   cfg5            configs[4] on one GPU: axisymmetric 400x500 quads, p=3, two-temperature argon plasma with
                   constant transport, reactions and the NEC radiation source, 7 equations
   torch6          the mixture of the reference's torch input (plasma.ini): six species, two temperatures, not
                   ambipolar, 11 equations, on the axisymmetric 400x500 mesh of cfg5
-  argon_p3        the metric's "3D p=3 reacting cyl" read literally: the physics of configs[2] at the
-                  order of configs[1] (no entry of `configs` is both)
 At N = 1 the JSON line also carries the workloads that were not selected, under `other_workloads`.
 N > 1 (launched by ``torch.distributed.run``, one rank per GPU): every rank owns one such block --
 spanwise slabs of an N-times longer cylinder -- and exchanges the traces of its two shared planes
@@ -36,6 +36,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0
+# FP64 vector issue: 1024 SIMDs x 2.4 GHz / 4 cycles per wave-instruction (measured issue interval of
+# v_fma_f64 / v_mul_f64 / v_add_f64 with two waves per SIMD: tools/microbench/fp64_issue.hip, 3.5-4.2 cycles)
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0
 
 
 def algorithmic_bytes_per_node(neq, dim, p):
@@ -90,32 +93,39 @@ def workload(name):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(neq, order, sample_case, budget_s=12.0):
-    """The oracle (CPU restatement, reference-faithful dense formulation) timed on this host on a
-    bounded sample of the same workload: a 7x28x4 = 784-element O-grid block of the cylinder at the
-    same order, physics and boundary conditions."""
-    import numpy as np
+def cpu_baseline(neq, order, sample_case, budget_s=10.0):
+    """The oracle (CPU restatement, reference-faithful dense formulation: kind "port") timed on this host on
+    a bounded sample of the same workload -- a 7x28x4 = 784-element O-grid block of the cylinder at the same
+    order, physics and boundary conditions -- on all cores of the GPU's share of the host and on one thread
+    (one MPI rank of the reference), SURVEY 8(d).  About `budget_s` seconds each."""
     from oracle_lib import Oracle
 
-    from tps_amd import capi, cases
-
     c = sample_case(order)
+    U = c.state()
+    ndofs = U.shape[1]
+
+    def timed(threads):
+        o = Oracle(c.mesh, c.disc, c.physics, c.bcs, threads=threads)
+        o.mult(U)  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or (time.perf_counter() - t0 < budget_s and n < 2000):
+            o.mult(U)
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+        return {"value": ndofs * neq / dt / 1e6, "unit": "MDOF/s", "cores": threads, "mult_calls": n,
+                "evals_per_s_on_sample": 1.0 / dt}
+
     # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe
     threads = min(len(os.sched_getaffinity(0)), 16)
-    o = Oracle(c.mesh, c.disc, c.physics, c.bcs, threads=threads)
-    U = c.state()
-    o.mult(U)  # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 2000):
-        o.mult(U)
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    ndofs = U.shape[1]
-    return {"value": ndofs * neq / dt / 1e6, "unit": "MDOF/s", "cores": threads, "kind": "port",
+    allc, one = timed(threads), timed(1)
+    return {"value": allc["value"], "unit": "MDOF/s", "cores": threads, "kind": "port",
             "sample": f"cyl3d O-grid 7x28x4 = {c.mesh.num_elements} hexes, p={order}, {c.description}, "
-                      f"{ndofs} nodes, {n} Mult calls, OpenMP over elements/faces/nodes",
-            "evals_per_s_on_sample": 1.0 / dt}
+                      f"{ndofs} nodes, {allc['mult_calls']} Mult calls on {threads} threads (OpenMP over "
+                      f"elements/faces/nodes) and {one['mult_calls']} on one thread",
+            "evals_per_s_on_sample": allc["evals_per_s_on_sample"],
+            "single_thread": {"value": one["value"], "unit": "MDOF/s", "cores": 1,
+                              "evals_per_s_on_sample": one["evals_per_s_on_sample"]}}
 
 
 def main():
@@ -127,7 +137,7 @@ def main():
     ap.add_argument("--ntheta", type=int, default=112)
     ap.add_argument("--nz", type=int, default=16)
     ap.add_argument("--order", type=int, default=0, help="override the workload's polynomial order")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "argon_p3", "cfg5", "torch6"])
+    ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3", "cfg5", "torch6"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the multi-rank path on a one-GPU box (traces staged via host)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses device 0")
@@ -206,6 +216,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         ktimes = op.kernel_times()  # ms, averaged over the timed Mults
+        mult_ms = sorted(op.mult_times())  # device time of each timed Mult (the last 128 at most)
         op.enable_kernel_timing(False)
         finite = bool(torch.isfinite(y).all().item())
         comm_exposed_ms = None
@@ -249,13 +260,23 @@ def main():
         alg = algorithmic_bytes_per_node(neq, mesh.dim, order)
         dom = max((k for k in ktimes if k in alg), key=lambda k: ktimes[k])
         achieved = alg[dom] * ndofs / (ktimes[dom] * 1e-3) / 1e9
-        traffic = valu = None
+        traffic = valu_insts = None
         try:  # written by tools/profile_summary.py from the rocprofv3 --pmc passes of this workload
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(wname, {})
             if tj.get("nodes") == ndofs and dom in tj.get("bytes_per_launch", {}):
                 traffic = tj["bytes_per_launch"][dom]
+            if tj.get("nodes") == ndofs:
+                valu_insts = tj.get("valu_insts_per_launch", {}).get(dom)
         except Exception:
             traffic = None
+        # second roofline of a kernel that is not bandwidth-bound: FP64 vector issue.  achieved = VALU
+        # wave-instructions per launch (SQ_INSTS_VALU of the committed PMC pass) / the live kernel time.
+        valu = None
+        if valu_insts:
+            ginst = valu_insts / (ktimes[dom] * 1e-3) / 1e9
+            valu = {"bound": "fp64-valu-issue", "kernel": dom, "achieved": ginst, "peak": VALU_PEAK_GINST,
+                    "unit": "G wave-instructions/s", "frac": ginst / VALU_PEAK_GINST,
+                    "valu_insts_per_launch": valu_insts}
         res = {
             "value": value, "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
             "config": {"workload": (f"{wname}: " + ("" if axisym else f"cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} "
@@ -264,7 +285,8 @@ def main():
                        "elements_per_gpu": mesh.num_elements, "nodes_per_gpu": ndofs, "num_equation": neq,
                        "partition": "spanwise slabs, RCCL send/recv of face traces" if world > 1 else "single GPU"},
             "rhs_evals_per_s": evals_per_s, "mnodes_per_s": world * ndofs * evals_per_s / 1e6, "kernel_ms": ktimes,
-            "finite": finite, "time_loop": rk4, "comm_exposed_ms": comm_exposed_ms,
+            "ms_per_mult_median_events": mult_ms[len(mult_ms) // 2] if mult_ms else None,
+            "finite": finite, "time_loop": rk4, "comm_exposed_ms": comm_exposed_ms, "roofline_valu": valu,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_node": alg[dom],
@@ -275,7 +297,7 @@ def main():
     r = run(args.workload, args.steps, args.warmup)
     others = {}
     if world == 1 and not args.no_other_workloads:
-        for wname in ("cfg2", "argon_p3", "cfg3", "cfg5", "torch6"):
+        for wname in ("argon_p3", "cfg2", "cfg3", "cfg5", "torch6"):
             if wname != args.workload:
                 o, _ = run(wname, max(args.steps // 2, 5), min(args.warmup, 3))
                 others[wname] = {k: o[k] for k in ("value", "ms_per_step", "rhs_evals_per_s", "kernel_ms", "finite")}
@@ -292,8 +314,11 @@ def main():
             "dtype": "f64", "data": "synthetic", "config": res["config"],
             "rhs_evals_per_s": res["rhs_evals_per_s"], "mnodes_per_s": res["mnodes_per_s"], "kernel_ms": res["kernel_ms"],
             "finite": res["finite"],
+            "ms_per_mult_median_events": res["ms_per_mult_median_events"],
             "roofline": res["roofline"],
         }
+        if res.get("roofline_valu"):
+            out["roofline_valu"] = res["roofline_valu"]
         if res.get("time_loop"):
             out["time_loop"] = res["time_loop"]
         if res.get("comm_exposed_ms") is not None:

@@ -311,6 +311,9 @@ int tpsrhs_num_equation(tpsrhs_handle h);
  * written (<= capacity).  With a halo callback the k_gradient / k_flux intervals include it. */
 int tpsrhs_enable_kernel_timing(tpsrhs_handle h, int enable);
 int tpsrhs_kernel_times(tpsrhs_handle h, int capacity, const char **names, double *milliseconds);
+/* Device time of each recorded tpsrhs_mult call, first kernel start to last kernel end (the same event sets):
+ * what the median of SURVEY 8(d) is taken over.  Returns the number of calls written (<= capacity, <= 128). */
+int tpsrhs_mult_times(tpsrhs_handle h, int capacity, double *milliseconds);
 
 /* Algorithmic HBM bytes one tpsrhs_mult moves per kernel (DESIGN.md "bytes per unit"), matching
  * the order of tpsrhs_kernel_times. */

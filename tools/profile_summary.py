@@ -78,6 +78,7 @@ for k, v in summary.items():
         # rocprofv3 reports both in kilobytes (1024 B)
         ent["raw"][k] = {"FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"]}
         ent["bytes_per_launch"][k] = 1024.0 * (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"])
+ent["valu_insts_per_launch"] = {k: v["SQ_INSTS_VALU"] for k, v in summary.items() if "SQ_INSTS_VALU" in v}
 traffic[w] = ent
 json.dump(traffic, open(tp, "w"), indent=1)
 for k, v in summary.items():

@@ -443,6 +443,7 @@ def load():
     lib.tpsrhs_num_equation.argtypes = [vp]
     lib.tpsrhs_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.tpsrhs_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
+    lib.tpsrhs_mult_times.argtypes = [vp, C.c_int, _dp]
     lib.tpsrhs_kernel_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_rk4_step.argtypes = [vp, C.c_void_p, _dp, C.c_double, _dp, C.POINTER(C.c_int64)]
     lib.tpsrhs_advance.argtypes = [vp, C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
@@ -463,7 +464,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "tpsrhs_create", "tpsrhs_destroy", "tpsrhs_mult", "tpsrhs_mult_host", "tpsrhs_update_gradients",
     "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
-    "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_kernel_bytes", "tpsrhs_face_tables",
+    "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_mult_times", "tpsrhs_kernel_bytes", "tpsrhs_face_tables",
     "tpsrhs_rk4_step", "tpsrhs_advance", "tpsrhs_set_dt", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_status_string",
     "tpsrhs_last_error", "tpsrhs_version",
 ]

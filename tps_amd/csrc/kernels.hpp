@@ -43,6 +43,54 @@ namespace tpsrhs {
 #endif
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// Diagnostic builds only (-DTPSRHS_STAMP=1, tools/stamp_phases.py): s_memtime at the phase boundaries of
+// k_gradient / k_flux of every block, summed per phase into a __device__ array that no kernel reads.  The
+// production library carries none of this.
+#ifndef TPSRHS_STAMP
+#define TPSRHS_STAMP 0
+#endif
+#if TPSRHS_STAMP
+constexpr int NSTAMP = 16, STAMP_BLOCKS = 1 << 16;
+static __device__ unsigned int g_stamp[STAMP_BLOCKS][NSTAMP];  // cycles per phase of every block (one kernel at a time)
+struct Stamper {
+  unsigned long long t0;
+  unsigned int acc[NSTAMP];
+  __device__ inline unsigned long long now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  }
+  __device__ inline void start() {
+    for (int i = 0; i < NSTAMP; i++) acc[i] = 0;
+    t0 = now();
+  }
+  __device__ inline void mark(int phase) {
+    const unsigned long long t = now();
+    acc[phase] += static_cast<unsigned int>(t - t0);
+    t0 = t;
+  }
+  __device__ inline void flush() {
+    if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS)
+      for (int i = 0; i < NSTAMP; i++) g_stamp[blockIdx.x][i] = acc[i];
+  }
+};
+#define STAMP_DECL Stamper stamper
+#define STAMP_ARG , stamper
+#define STAMP_PARAM , Stamper &stamper
+#define STAMP_START() stamper.start()
+#define STAMP(phase) stamper.mark(phase)
+#define STAMP_FLUSH() stamper.flush()
+#else
+#define STAMP_DECL
+#define STAMP_ARG
+#define STAMP_PARAM
+#define STAMP_START()
+#define STAMP(phase)
+#define STAMP_FLUSH()
+#endif
+
 // 1-D operator tables of every (dim, order), filled by tpsrhs_create.  Identical for all operators of
 // a process (they depend on (dim, p) only).  Indexed with compile-time constants they are scalar loads.
 static __constant__ Tables1D c_tab[2][TPSRHS_MAXORDER + 1];
@@ -791,6 +839,136 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const type
     for (int eq = 1; eq < NEQ; eq++) out[(eq - 1) * C::NQ] = fn[eq];  // fn[0] == 0 (src/fluxes.cpp:284)
   }
 }
+// ---- heavy point physics, 3-D, one round of quadrature points per direction pair: the viscous traces in
+// two steps.  (1) The conserved state at the face quadrature points -> the state-only closure (collision
+// integrals: the transcendental-heavy part) while only NEQ interpolated values are live.  (2) The gradient,
+// one Cartesian direction per chunk: the velocity rows are kept (9 values), of the scalar rows only the
+// normal derivative sum_d n_d d(.)/dx_d is accumulated -- heat and diffusion fluxes are linear in it.  12-15
+// interpolated values per point instead of 24, and none of them live across the closure.
+template <class C, class PH, int D>
+__device__ inline void visc_state_dir(const double *sU, double *Tb, double *Wb, const Tab<C> &tab, const Tables1D &ct,
+                                      double *u, int tid) {
+  constexpr int NEQ = PH::NEQ;
+  trace_lines<C, D, NEQ>(sU, Tb, ct, tid);
+  block_sync<C::BLOCK>();
+  interp1_lines<C, NEQ>(Tb, Wb, ct, tid);
+  block_sync<C::BLOCK>();
+  if (tid < C::TQ) {
+    const int pf = tid / C::NQ, q = tid - pf * C::NQ;
+    double bq[C::N1];
+#pragma unroll
+    for (int a = 0; a < C::N1; a++) bq[a] = tab.B[(q / C::Q1) * C::N1 + a];
+#pragma unroll
+    for (int k = 0; k < NEQ; k++) u[k] = interp2_point<C>(Tb + k * C::TN, Wb + k * C::TW, bq, pf, q);
+  }
+  block_sync<C::BLOCK>();
+}
+// sG: the nodal gradient [d][eq][NODES]; gv[i + j*DIM] = d u_i / d x_j; gn[eq] = normal derivative (scalar rows)
+template <class C, class PH, int D>
+__device__ inline void visc_grad_dir(const double *sG, double *Tb, double *Wb, const Tab<C> &tab, const Tables1D &ct,
+                                     const double *n, double *gv, double *gn, int tid) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM, NVEL = PH::NVEL;
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) gn[eq] = 0.0;
+#pragma unroll
+  for (int c = 0; c < DIM; c++) {
+    trace_lines<C, D, NEQ>(sG + c * NEQ * C::NODES, Tb, ct, tid);
+    block_sync<C::BLOCK>();
+    interp1_lines<C, NEQ>(Tb, Wb, ct, tid);
+    block_sync<C::BLOCK>();
+    if (tid < C::TQ) {
+      const int pf = tid / C::NQ, q = tid - pf * C::NQ;
+      double bq[C::N1];
+#pragma unroll
+      for (int a = 0; a < C::N1; a++) bq[a] = tab.B[(q / C::Q1) * C::N1 + a];
+#pragma unroll
+      for (int k = 0; k < NEQ; k++) {
+        const double val = interp2_point<C>(Tb + k * C::TN, Wb + k * C::TW, bq, pf, q);
+        if (k >= 1 && k <= NVEL)
+          gv[(k - 1) + c * DIM] = val;
+        else
+          gn[k] += n[c] * val;
+      }
+    }
+    block_sync<C::BLOCK>();
+  }
+}
+template <class C, class PH>
+__device__ inline void visc_phase_heavy3d(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
+                                          const double *sU, const double *sG, double *Tb, double *Wb, const double *sV,
+                                          const Tab<C> &tab, const Tables1D &ct, double *__restrict__ TB, int tid0 STAMP_PARAM) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  static_assert(DIM == 3 && C::Q_ROUNDS == 1 && PH::NVEL == 3, "3-D, one round of face points per direction pair");
+#pragma clang loop unroll(disable)
+  for (int d = 0; d < DIM; d++) {
+    const int tid = tid0;
+    const int pf = tid / C::NQ, q = tid - pf * C::NQ;
+    const int le = pf >> 1, s = pf & 1;
+    const bool on = tid < C::TQ && (e0 + le) < m.ne;
+    double u[NEQ];
+#pragma unroll
+    for (int k = 0; k < NEQ; k++) u[k] = 1.0;
+    if (d == 0)
+      visc_state_dir<C, PH, 0>(sU, Tb, Wb, tab, ct, u, tid);
+    else if (d == 1)
+      visc_state_dir<C, PH, 1>(sU, Tb, Wb, tab, ct, u, tid);
+    else
+      visc_state_dir<C, PH, 2>(sU, Tb, Wb, tab, ct, u, tid);
+    STAMP(5);
+    PH::clamp_species(u);
+    int nb = 0;
+    double n[DIM] = {1.0, 0.0, 0.0}, wq, Xq[DIM];
+    if (on) {
+      nb = sFI[le * C::NFACES + 2 * d + s].x;
+      face_geometry_rt<C>(d, &sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
+    }
+    // 0: no viscous term on this face, 1: interior face, 2: wall face (interior state, then wall-side state)
+    const int np_lane = on ? PH::visc_passes(prm, nb) : 0;
+    const int npass = (__ballot(np_lane == 2) != 0) ? 2 : ((__ballot(np_lane >= 1) != 0) ? 1 : 0);
+    double fn[NEQ];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) fn[eq] = 0.0;
+    // the second pass exists in the few waves that touch a wall; it repeats the gradient interpolation
+    // rather than keeping 12 more values alive across the closure of every wave
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < npass; pass++) {
+      double Us[NEQ];
+      typename PH::WallFlux w;
+      typename PH::ViscCoef cf;
+      if (pass < np_lane) {
+        PH::visc_pass_state(prm, nb, pass, u, n, Us, w);
+        PH::visc_point_coeffs(prm, Us, !w.species, cf);
+      }
+      STAMP(6);
+      double gv[DIM * DIM], gn[NEQ];
+      if (d == 0)
+        visc_grad_dir<C, PH, 0>(sG, Tb, Wb, tab, ct, n, gv, gn, tid);
+      else if (d == 1)
+        visc_grad_dir<C, PH, 1>(sG, Tb, Wb, tab, ct, n, gv, gn, tid);
+      else
+        visc_grad_dir<C, PH, 2>(sG, Tb, Wb, tab, ct, n, gv, gn, tid);
+      STAMP(7);
+      if (pass < np_lane) {
+        double f[NEQ];
+        PH::visc_normal_flux_n(prm, Us, cf, gv, gn, n, w, f);
+        if (nb >= 0) {
+#pragma unroll
+          for (int eq = 0; eq < NEQ; eq++) fn[eq] = f[eq];
+        } else {
+#pragma unroll
+          for (int eq = 1; eq < NEQ; eq++) fn[eq] -= 0.5 * f[eq];
+        }
+      }
+    }
+    if (on) {
+      const int slot = (e0 + le) * C::NFACES + 2 * d + s;
+      double *out = TB + static_cast<int64_t>(slot) * ((NEQ - 1) * C::NQ) + q;
+#pragma unroll
+      for (int eq = 1; eq < NEQ; eq++) out[(eq - 1) * C::NQ] = fn[eq];  // fn[0] == 0 (src/fluxes.cpp:284)
+    }
+    STAMP(8);
+  }
+}
 // 2-D viscous phase: both direction pairs at once (see Cfg::TQ2)
 template <class C, class PH>
 __device__ inline void visc_phase_2d(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
@@ -876,10 +1054,13 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
   const int bid = m.blocks ? m.blocks[blockIdx.x] : static_cast<int>(blockIdx.x);
   const int e0 = bid * C::EPB;
   __shared__ int2 sFI[C::EPB * C::NFACES];
+  STAMP_DECL;
+  STAMP_START();
   load_face_info<C>(sFI, m, e0);
   load_tables<C>(tab, ct);
   load_vertices<C>(sV, m, e0);
   block_sync<C::BLOCK>();
+  STAMP(0);
   // neighbour Up traces of all direction pairs: issued first, consumed by the jump passes
   NbTraces<C, NEQ> ta0, ta1, ta2;
   issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta0, tid);
@@ -904,6 +1085,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
     }
   }
   block_sync<C::BLOCK>();
+  STAMP(1);
 
   // ---- volume part: collocation derivative (Ke then M^-1 of the reference collapse to it)
   double g[NEQ * DIM];  // g[eq + d*NEQ]
@@ -950,6 +1132,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
     }
   }
 
+  STAMP(2);
   // ---- face part of the gradient, collocated (grad_jump_nodal), one direction pair at a time
   if (!(TPSRHS_ABLATE & 8)) {
     trace_lines<C, 0, NEQ>(sUp, sJ, ct, tid);
@@ -974,6 +1157,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
     }
   }
 
+  STAMP(3);
   if (node_on) {
     const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
 #pragma unroll
@@ -984,11 +1168,14 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
     }
   }
   if (L::G_IN_LDS) block_sync<C::BLOCK>();
+  STAMP(4);
 
   // ---- viscous normal-flux traces (T chunk in the sUp region: the nodal Up values are dead)
   if (!(TPSRHS_ABLATE & 16)) {
     if constexpr (DIM == 2) {
       visc_phase_2d<C, PH>(m, sFI, prm, e0, sU, g, node_on, sJ, sUp, sV, tab, ct, TB, tid);
+    } else if constexpr (PH::TWO_STEP && C::Q_ROUNDS == 1 && !(TPSRHS_ABLATE & 256)) {
+      visc_phase_heavy3d<C, PH>(m, sFI, prm, e0, sU, sJ, sUp, sW, sV, tab, ct, TB, tid STAMP_ARG);
     } else if constexpr (PH::HEAVY) {
 #pragma clang loop unroll(disable)
       for (int d = 0; d < DIM; d++) {
@@ -1008,6 +1195,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
         visc_traces_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, sFI, prm, e0, sU, g, node_on, sJ, sUp, sW, sV, tab, ct, TB, tid);
     }
   }
+  STAMP_FLUSH();
 }
 
 // =============================================================================================
@@ -1559,6 +1747,8 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
       PH::clamp_species(uc);
       const typename PH::State st = PH::make_state(prm, uc);
       speed = PH::max_char_speed(prm, uc, st);
+      typename PH::FluxCoef fc;
+      if constexpr (PH::TWO_STEP) PH::flux_coeffs(prm, uc, st, fc);
       if (PH::HAS_SOURCE) {
         double up[NEQ];
         PH::prim(prm, u, up);
@@ -1570,10 +1760,10 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
 #pragma unroll
         for (int k = 0; k < NEQ * DIM; k++) F[k] = uc[k % NEQ] + gr[k];
       } else {
-        if constexpr (PH::AXISYM)
+        if constexpr (PH::TWO_STEP)
+          PH::total_flux(prm, uc, st, fc, gr, PH::AXISYM ? radius : -1.0, F);
+        else if constexpr (PH::AXISYM)
           PH::total_flux(prm, uc, st, gr, radius, F);
-        else if constexpr (PH::HEAVY)
-          PH::total_flux(prm, uc, st, gr, -1.0, F);
         else
           PH::total_flux(prm, uc, st, gr, F);
       }

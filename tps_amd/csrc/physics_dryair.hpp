@@ -87,6 +87,8 @@ struct DryAirPhys {
   static constexpr bool AXISYM = false;
   static constexpr bool VISC_USES_GRAD_RHO = false;  // Newtonian stress + Fourier flux: grad u and grad T only
   static constexpr bool HEAVY = false;  // light point physics: inlined at every face pass
+  static constexpr bool TWO_STEP = false;  // no state-only closure worth separating from the gradient terms
+  struct FluxCoef {};
   static constexpr int MINW_GRAD = TPSRHS_MINW_GRAD, MINW_FLUX = TPSRHS_MINW_FLUX;  // launch-bound waves per SIMD
   typedef DryAirParams Params;
 

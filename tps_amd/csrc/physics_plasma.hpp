@@ -61,6 +61,10 @@ struct PlasmaParams {
   // derived on the host (fill_plasma_params): reciprocal molar masses; per-particle masses m = mw / N_A, their
   // roots, k_f / m; sqrt(reduced mass of a pair) / d_fc of the binary diffusivities (src/gas_transport.cpp:291-310)
   double imw[NSP], mwp[NSP], sq_mwp[NSP], kf_imwp[NSP], sq_muw_idfc[NSP * NSP];
+  // every other product of constants the closures use (a uniform FP64 expression left in a kernel is computed by
+  // the vector ALU, hoisted out of the point loops and then kept in -- or spilled from -- a VGPR pair):
+  //   v_f sqrt(m_sp); v_f k_f / sqrt(m_e) and sqrt(2) times that; (q_e / k_B) Z_sp; R / mw_sp; 1 / cv_e
+  double vf_sq_mwp[NSP], ke_fac, ke_fac3, qkb_charge[NSP], rg_imw[NSP], icv_e;
   // constant transport
   double c_visc, c_bulk, c_k, c_ke, c_diff[NSP], c_mtfreq[NSP];
   int c_eidx;
@@ -164,6 +168,9 @@ __device__ inline double eAr1r(int r, double logT) {
 }
 }  // namespace coll
 
+#ifndef TPSRHS_PLASMA_MINW_FLUX
+#define TPSRHS_PLASMA_MINW_FLUX 2
+#endif
 #ifndef TPSRHS_PLASMA_MINW_GRAD3
 #define TPSRHS_PLASMA_MINW_GRAD3 2
 #endif
@@ -182,7 +189,7 @@ struct PlasmaPhys {
   static constexpr bool HAS_NR_BC = false;  // the reference's non-reflecting conditions are perfect-gas algebra
   static constexpr bool VISC_USES_GRAD_RHO = true;  // mole-fraction gradients need grad(rho)
   static constexpr bool AXISYM = NVEL_ > DIM_;  // dim 2 with (r, z, theta) velocity components
-  static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : TPSRHS_PLASMA_MINW_GRAD3, MINW_FLUX = 2;  // waves per SIMD asked of the allocator
+  static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : TPSRHS_PLASMA_MINW_GRAD3, MINW_FLUX = TPSRHS_PLASMA_MINW_FLUX;  // waves per SIMD asked of the allocator
   typedef PlasmaParams<NSP_> Params;
   struct Transport {};
 
@@ -356,35 +363,19 @@ struct PlasmaPhys {
     for (int sp = 0; sp < NSP; sp++) q.X[sp] = q.n[sp] * q.intot;
     return q;
   }
-  __device__ static inline void mole_fraction_grad(const Params &p, const double *n, double in, const double *g,
-                                                   double *gX) {  // :1534-1592; in = 1 / total number density
-#pragma unroll
-    for (int d = 0; d < DIM; d++) {
-      double ne = 0.0, nb = g[0 + d * NEQ], nt = 0.0;
-#pragma unroll
-      for (int sp = 0; sp < NACTIVE; sp++) {
-        const double gs = g[(NVEL + 2 + sp) + d * NEQ];
-        if (AMBI) ne += gs * p.charge[sp];
-        nb -= gs * p.mw[sp];
-        nt += gs;
-      }
-      if (AMBI) nb -= p.mw[IE] * ne;
-      nb *= p.imw[IB];
-      if (AMBI) nt += ne;
-      nt += nb;
-#pragma unroll
-      for (int sp = 0; sp < NACTIVE; sp++)
-        gX[sp + d * NSP] = g[(NVEL + 2 + sp) + d * NEQ] * in - n[sp] * in * in * nt;
-      if (AMBI) gX[IE + d * NSP] = ne * in - n[IE] * in * in * nt;
-      gX[IB + d * NSP] = nb * in - n[IB] * in * in * nt;
-    }
-  }
-
   // ---- transport ----------------------------------------------------------------------------
   struct Trans {
     double visc, bulk, k, ke;
     double V[NSP * DIM];  // diffusion velocities [sp + d*NSP]
     double n[NSP];        // number densities of computeSpeciesPrimitives
+  };
+  // The state-only part of ComputeFluxTransportProperties: everything the diffusion velocities need besides
+  // the gradient.  The diffusion velocity is the same linear map of grad X in every direction, so the face
+  // kernels apply it to the NORMAL derivative alone (diffusion_velocity below).
+  struct TCoef {
+    double visc, bulk, k, ke;
+    double dX[NSP], mob[NSP], imho;        // D_sp / (X_sp + eps), mobilities, 1 / (sum mob n Z + eps)
+    double Y[NSP], n[NSP], intot;          // computeSpeciesPrimitives: mass fractions, number densities, 1 / n
   };
   // species positions of the argon ternary mixture are fixed by the mixture ordering (electron
   // second to last, neutral background last); tpsrhs_create checks the tpsrhs_gas_transport indices
@@ -409,27 +400,35 @@ struct PlasmaPhys {
   // sTe = sqrt(T_e), c_ke = v_f k_f sqrt(2 / m_e)
   __device__ static inline double third_order_ke(const double *X, const Debye &d, double sTe, double lnTe, double att11c,
                                                  double c_ke) {  // :400-489
-    const double Q2[3] = {d.circle * coll::rep22(d.e), d.circle * coll::rep23(d.e), d.circle * coll::rep24(d.e)};
-    const double QI[5] = {att11c, d.circle * coll::att12(d.e), d.circle * coll::att13(d.e), d.circle * coll::att14(d.e),
-                          d.circle * coll::att15(d.e)};
-    double QN[5];
-#pragma unroll
-    for (int r = 1; r <= 5; r++) QN[r - 1] = coll::eAr1r(r, lnTe);
     auto L11ea = [](const double *Q) { return 6.25 * Q[0] - 15. * Q[1] + 12. * Q[2]; };
     auto L12ea = [](const double *Q) { return 10.9375 * Q[0] - 39.375 * Q[1] + 57. * Q[2] - 30. * Q[3]; };
     auto L22ea = [](const double *Q) {
       return 19.140625 * Q[0] - 91.875 * Q[1] + 199.5 * Q[2] - 210. * Q[3] + 90. * Q[4];
     };
     constexpr double s2 = 1.4142135623730951;  // sqrt(2)
-    double L11 = s2 * X[I_E] * Q2[0];
-    L11 += X[I_ION] * L11ea(QI);
-    L11 += X[I_N] * L11ea(QN);
-    double L12 = s2 * X[I_E] * (1.75 * Q2[0] - 2.0 * Q2[1]);
-    L12 += X[I_ION] * L12ea(QI);
-    L12 += X[I_N] * L12ea(QN);
-    double L22 = s2 * X[I_E] * (4.8125 * Q2[0] - 7.0 * Q2[1] + 5. * Q2[2]);
-    L22 += X[I_ION] * L22ea(QI);
-    L22 += X[I_N] * L22ea(QN);
+    // one collision partner at a time (electron, ion, neutral), each group reduced to its three sums
+    double L11, L12, L22;
+    {
+      const double Q2[3] = {d.circle * coll::rep22(d.e), d.circle * coll::rep23(d.e), d.circle * coll::rep24(d.e)};
+      L11 = s2 * X[I_E] * Q2[0];
+      L12 = s2 * X[I_E] * (1.75 * Q2[0] - 2.0 * Q2[1]);
+      L22 = s2 * X[I_E] * (4.8125 * Q2[0] - 7.0 * Q2[1] + 5. * Q2[2]);
+    }
+    {
+      const double QI[5] = {att11c, d.circle * coll::att12(d.e), d.circle * coll::att13(d.e), d.circle * coll::att14(d.e),
+                            d.circle * coll::att15(d.e)};
+      L11 += X[I_ION] * L11ea(QI);
+      L12 += X[I_ION] * L12ea(QI);
+      L22 += X[I_ION] * L22ea(QI);
+    }
+    {
+      double QN[5];
+#pragma unroll
+      for (int r = 1; r <= 5; r++) QN[r - 1] = coll::eAr1r(r, lnTe);
+      L11 += X[I_N] * L11ea(QN);
+      L12 += X[I_N] * L12ea(QN);
+      L22 += X[I_N] * L22ea(QN);
+    }
     return c_ke * sTe * X[I_E] * fast_rcp(L11 - L12 * L12 * fast_rcp(L22));
   }
 
@@ -484,16 +483,19 @@ struct PlasmaPhys {
   //   1 / D_ij = n Q_ij sqrt(mu_ij) / (d_fc sqrt(T)) directly (CurtissHirschfelder only ever divides by D_ij);
   //   one reciprocal each of T_e, T_h, n, X_sp + eps, shared by everything that divides by them.
   // Results differ from the reference's order by rounding (a few ulp).
-  __device__ static inline void transport(const Params &p, const double *U, double Th, double Te, const double *g,
-                                          bool diffusion, Trans &t) {
+  __device__ static inline void transport_coeffs(const Params &p, const double *U, double Th, double Te, bool diffusion,
+                                                 TCoef &t) {
     const Species q = species(p, U);
 #pragma unroll
-    for (int sp = 0; sp < NSP; sp++) t.n[sp] = q.n[sp];
-#pragma unroll
-    for (int k = 0; k < NSP * DIM; k++) t.V[k] = 0.0;
+    for (int sp = 0; sp < NSP; sp++) {
+      t.n[sp] = q.n[sp];
+      t.Y[sp] = q.Y[sp];
+      t.dX[sp] = t.mob[sp] = 0.0;
+    }
+    t.intot = q.intot;
+    t.imho = 0.0;
     double diff[NSP], mob[NSP];
     const double iTe = fast_rcp(Te), iTh = TWOT ? fast_rcp(Th) : iTe;
-    const double vf = 5. / 16. * sqrt(kPi * kBoltz), kf = 15. / 4. * kBoltz;  // folded at compile time
     if (TRANSPORT == TRANSPORT_CONSTANT) {
       t.visc = p.c_visc;
       t.bulk = p.c_bulk;
@@ -503,7 +505,7 @@ struct PlasmaPhys {
       for (int sp = 0; sp < NSP; sp++) {
         diff[sp] = p.c_diff[sp];
         const double itemp = (sp == p.c_eidx) ? iTe : iTh;
-        mob[sp] = (kQe / kBoltz) * p.charge[sp] * itemp * diff[sp];
+        mob[sp] = p.qkb_charge[sp] * itemp * diff[sp];
       }
     } else if (TRANSPORT == TRANSPORT_ARGON_MIXTURE) {  // GasMixtureTransport, src/gas_transport.cpp:1285-1407
       const MixColl c = mix_inputs(p, q.n, Th, Te);
@@ -512,11 +514,11 @@ struct PlasmaPhys {
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) {
         if (sp == IE) continue;
-        const double sv = vf * p.sq_mwp[sp] * sTh * fast_rcp(collision<2, 2>(p, sp, sp, c));
+        const double sv = p.vf_sq_mwp[sp] * sTh * fast_rcp(collision<2, 2>(p, sp, sp, c));
         t.visc += q.X[sp] * sv;
         t.k += q.X[sp] * (sv * p.kf_imwp[sp]);
       }
-      const double ke_fac = vf * kf * sTe * q.X[IE] * fast_rsqrt(p.mwp[IE]);  // v_f k_f sqrt(T_e / m_e) X_e
+      const double ke_fac = p.ke_fac * sTe * q.X[IE];  // v_f k_f sqrt(T_e / m_e) X_e
       if (p.third_order) {  // :1388-1407
         constexpr double s2 = 1.4142135623730951;
         const double Q22 = collision<2, 2>(p, IE, IE, c), Q23 = collision<2, 3>(p, IE, IE, c),
@@ -555,7 +557,7 @@ struct PlasmaPhys {
           for (int j = 0; j < NSP; j++)
             if (i != j) a += (q.X[j] + kXeps) * ibd[i + j * NSP];
           diff[i] = (1.0 - q.Y[i]) * fast_rcp(a);
-          mob[i] = (kQe / kBoltz) * p.charge[i] * ((i == IE) ? iTe : iTh) * diff[i];
+          mob[i] = p.qkb_charge[i] * ((i == IE) ? iTe : iTh) * diff[i];
         }
       }
       if (p.multiply) {
@@ -575,16 +577,15 @@ struct PlasmaPhys {
       const double lnTe = flog(Te), lnTh = TWOT ? flog(Th) : lnTe;
       const double QeAr = coll::eAr1r(1, lnTe), Qatt = coll::att11(d.e) * d.circle;
       const double rep22h = coll::rep22(d.h) * d.circle;
-      const double sv_ion = vf * p.sq_mwp[I_ION] * sTh * fast_rcp(rep22h);
-      const double sv_n = vf * p.sq_mwp[I_N] * sTh * coll::iArAr22(sTh);
+      const double sv_ion = p.vf_sq_mwp[I_ION] * sTh * fast_rcp(rep22h);
+      const double sv_n = p.vf_sq_mwp[I_N] * sTh * coll::iArAr22(sTh);
       t.bulk = 0.0;
       t.visc = q.X[I_ION] * sv_ion + q.X[I_N] * sv_n;
       t.k = q.X[I_ION] * (sv_ion * p.kf_imwp[I_ION]) + q.X[I_N] * (sv_n * p.kf_imwp[I_N]);
-      const double ke_fac = vf * kf * fast_rsqrt(p.mwp[I_E]);  // uniform: v_f k_f / sqrt(m_e)
       if (p.third_order)
-        t.ke = third_order_ke(q.X, d, sTe, lnTe, Qatt, 1.4142135623730951 * ke_fac);
+        t.ke = third_order_ke(q.X, d, sTe, lnTe, Qatt, p.ke_fac3);
       else
-        t.ke = ke_fac * sTe * q.X[I_E] * fast_rcp(TWOT ? coll::rep22(d.e) * d.circle : rep22h);
+        t.ke = p.ke_fac * sTe * q.X[I_E] * fast_rcp(TWOT ? coll::rep22(d.e) * d.circle : rep22h);
       __builtin_amdgcn_sched_barrier(0);  // the collision integrals of k_e are dead here: keep it that way
       if (diffusion) {
         const double nrsTe = q.ntot * (sTe * iTe), nrsTh = TWOT ? q.ntot * (sTh * iTh) : nrsTe;  // n / sqrt(T)
@@ -602,7 +603,7 @@ struct PlasmaPhys {
           for (int j = 0; j < NSP; j++)
             if (i != j) a += (q.X[j] + kXeps) * ibd[i + j * NSP];
           diff[i] = (1.0 - q.Y[i]) * fast_rcp(a);
-          mob[i] = (kQe / kBoltz) * p.charge[i] * ((i == I_E) ? iTe : iTh) * diff[i];
+          mob[i] = p.qkb_charge[i] * ((i == I_E) ? iTe : iTh) * diff[i];
         }
       }
       if (p.multiply) {
@@ -618,34 +619,77 @@ struct PlasmaPhys {
       }
     }
     if (!diffusion) return;
-    // diffusion velocities: -D grad X / X, ambipolar field, mass-flux correction
-    // (src/transport_properties.cpp:59-136)
     double mho = 0.0;
 #pragma unroll
-    for (int sp = 0; sp < NSP; sp++) mho += mob[sp] * q.n[sp] * p.charge[sp];
-    double gX[NSP * DIM];
-    mole_fraction_grad(p, q.n, q.intot, g, gX);
-    double dX[NSP];  // D / (X + eps)
+    for (int sp = 0; sp < NSP; sp++) {
+      mho += mob[sp] * q.n[sp] * p.charge[sp];
+      t.dX[sp] = diff[sp] * fast_rcp(q.X[sp] + kXeps);
+      t.mob[sp] = mob[sp];
+    }
+    t.imho = AMBI ? fast_rcp(mho + kXeps) : 0.0;
+  }
+  // Diffusion velocities of one direction: -D grad X / X, ambipolar field, mass-flux correction
+  // (src/transport_properties.cpp:59-136).  gs[eq] = derivative of the primitives in that direction -- a
+  // Cartesian direction, or the normal derivative sum_d n_d dUp/dx_d (the map is linear and the same for every
+  // direction, so V . n comes out of one application).  Only the density and species rows are read.
+  __device__ static inline void diffusion_velocity(const Params &p, const TCoef &t, const double *gs, double *V) {
+    // ComputeMoleFractionGradient, src/equation_of_state.cpp:1534-1592
+    double ne = 0.0, nb = gs[0], nt = 0.0;
 #pragma unroll
-    for (int sp = 0; sp < NSP; sp++) dX[sp] = diff[sp] * fast_rcp(q.X[sp] + kXeps);
-    const double imho = AMBI ? fast_rcp(mho + kXeps) : 0.0;
+    for (int sp = 0; sp < NACTIVE; sp++) {
+      const double gsp = gs[NVEL + 2 + sp];
+      if (AMBI) ne += gsp * p.charge[sp];
+      nb -= gsp * p.mw[sp];
+      nt += gsp;
+    }
+    if (AMBI) nb -= p.mw[IE] * ne;
+    nb *= p.imw[IB];
+    if (AMBI) nt += ne;
+    nt += nb;
+    const double in = t.intot;
+    double gX[NSP];
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) gX[sp] = gs[NVEL + 2 + sp] * in - t.n[sp] * in * in * nt;
+    if (AMBI) gX[IE] = ne * in - t.n[IE] * in * in * nt;
+    gX[IB] = nb * in - t.n[IB] * in * in * nt;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) V[sp] = -t.dX[sp] * gX[sp];
+    if (AMBI) {
+      double ambE = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) ambE -= V[sp] * t.n[sp] * p.charge[sp];
+      ambE *= t.imho;
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) V[sp] += t.mob[sp] * ambE;
+    }
+    double Vc = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) Vc += t.Y[sp] * V[sp];
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) V[sp] -= Vc;
+  }
+  // ComputeFluxTransportProperties: coefficients + the diffusion velocities of every direction
+  __device__ static inline void transport(const Params &p, const double *U, double Th, double Te, const double *g,
+                                          bool diffusion, Trans &t) {
+    TCoef c;
+    transport_coeffs(p, U, Th, Te, diffusion, c);
+    t.visc = c.visc;
+    t.bulk = c.bulk;
+    t.k = c.k;
+    t.ke = c.ke;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) t.n[sp] = c.n[sp];
+#pragma unroll
+    for (int k = 0; k < NSP * DIM; k++) t.V[k] = 0.0;
+    if (!diffusion) return;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
+      double gs[NEQ], V[NSP];
 #pragma unroll
-      for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] = -dX[sp] * gX[sp + d * NSP];
-      if (AMBI) {
-        double ambE = 0.0;
+      for (int eq = 0; eq < NEQ; eq++) gs[eq] = g[eq + d * NEQ];
+      diffusion_velocity(p, c, gs, V);
 #pragma unroll
-        for (int sp = 0; sp < NSP; sp++) ambE -= t.V[sp + d * NSP] * q.n[sp] * p.charge[sp];
-        ambE *= imho;
-#pragma unroll
-        for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] += mob[sp] * ambE;
-      }
-      double Vc = 0.0;
-#pragma unroll
-      for (int sp = 0; sp < NSP; sp++) Vc += q.Y[sp] * t.V[sp + d * NSP];
-#pragma unroll
-      for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] -= Vc;
+      for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] = V[sp];
     }
   }
   // what SourceTerm uses of ComputeSourceTransportProperties (src/gas_transport.cpp:592-773,
@@ -667,7 +711,7 @@ struct PlasmaPhys {
     } else if (TRANSPORT == TRANSPORT_ARGON_MIXTURE) {  // src/gas_transport.cpp:1445-1459
       const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
       const MixColl c = mix_inputs(p, q.n, Th, Te);
-      const double vth = mff * fast_sqrt(Te) * fast_rsqrt(p.mwp[IE]);  // mff sqrt(T_e / m_e)
+      const double vth = (mff / (15. / 4. * kBoltz * 5. / 16. * sqrt(kPi * kBoltz))) * p.ke_fac * fast_sqrt(Te);  // mff sqrt(T_e / m_e)
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) {
         if (sp == IE) continue;
@@ -678,7 +722,7 @@ struct PlasmaPhys {
       const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
       const Debye d = debye(q.n, Th, Te, fast_rcp(Th), fast_rcp(Te));
       const double QeAr = coll::eAr1r(1, flog(Te)), Qatt = coll::att11(d.e) * d.circle;
-      const double vth = mff * fast_sqrt(Te) * fast_rsqrt(p.mwp[I_E]);  // mff sqrt(T_e / m_e)
+      const double vth = (mff / (15. / 4. * kBoltz * 5. / 16. * sqrt(kPi * kBoltz))) * p.ke_fac * fast_sqrt(Te);  // mff sqrt(T_e / m_e)
       mtfreq[I_ION] = vth * q.n[I_ION] * Qatt;
       mtfreq[I_N] = vth * q.n[I_N] * QeAr;
       if (p.multiply) {
@@ -693,13 +737,28 @@ struct PlasmaPhys {
   }
 
   // ComputeViscousFluxes, src/fluxes.cpp:178-335 (3-D / planar 2-D part); Fv[eq + d*NEQ]
-  __device__ static inline void visc_flux(const Params &p, const double *U, const State &s, const double *g,
-                                          double radius, double *Fv) {
+  // (the state-only closure `c` -- transport_coeffs -- is evaluated by the caller, before it touches the gradient)
+  __device__ static inline void visc_flux(const Params &p, const double *U, const State &s, const TCoef &c,
+                                          const double *g, double radius, double *Fv) {
 #pragma unroll
     for (int i = 0; i < NEQ * DIM; i++) Fv[i] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
-    Trans t;
-    transport(p, U, s.Th, s.Te, g, true, t);
+    struct {
+      double visc, bulk, k, ke, V[NSP * DIM];
+    } t;
+    t.visc = c.visc;
+    t.bulk = c.bulk;
+    t.k = c.k;
+    t.ke = c.ke;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      double gs[NEQ], V[NSP];
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) gs[eq] = g[eq + d * NEQ];
+      diffusion_velocity(p, c, gs, V);
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) t.V[sp + d * NSP] = V[sp];
+    }
     double h[NSP];
     enthalpies(p, s, h);
     const double bulk = t.bulk - 2. / 3. * t.visc;
@@ -747,10 +806,16 @@ struct PlasmaPhys {
       for (int sp = 0; sp < NACTIVE; sp++) Fv[(NVEL + 2 + sp) + i * NEQ] = -U[NVEL + 2 + sp] * t.V[sp + i * NSP];
     }
   }
-  __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const double *g,
-                                           double radius, double *F) {
+  // closure of the nodal flux: everything of ComputeFluxTransportProperties that depends on the state alone
+  typedef TCoef FluxCoef;
+  __device__ static inline void flux_coeffs(const Params &p, const double *U, const State &s, FluxCoef &c) {
+    if (p.eq_system == TPSRHS_EULER) return;
+    transport_coeffs(p, U, s.Th, s.Te, true, c);
+  }
+  __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const FluxCoef &c,
+                                           const double *g, double radius, double *F) {
     double Fv[NEQ * DIM];
-    visc_flux(p, U, s, g, radius, Fv);
+    visc_flux(p, U, s, c, g, radius, Fv);
     const double H = U[ITH] + s.p;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
@@ -876,7 +941,7 @@ struct PlasmaPhys {
       rhoB -= ne * p.mw[IE];
       n[IE] = ne;
     }
-    n[IB] = rhoB / p.mw[IB];
+    n[IB] = rhoB * p.imw[IB];
     double ctot = heavies_cv(p, n);
     if (!TWOT) ctot += n[IE] * p.cv[IE];
     double e = ke + ctot * Up[ITH];
@@ -910,7 +975,7 @@ struct PlasmaPhys {
       if (sp == IE || sp == IB) continue;  // the electron is negative, the background neutral
       const double Z = p.charge[sp];
       if (Z > 0.0) {
-        const double VB = sqrt((s.Th + Z * s.Te) * kRgas / p.mw[sp]);
+        const double VB = fast_sqrt((s.Th + Z * s.Te) * p.rg_imw[sp]);
         w.Vn[sp] = VB;
         w.Vn[IE] += Z * s.n[sp] * VB;
         w.Vn[IB] -= p.mw[sp] * s.n[sp] * VB;
@@ -920,7 +985,7 @@ struct PlasmaPhys {
     w.Vn[IB] -= p.mw[IE] * s.n[IE] * w.Vn[IE];
     w.Vn[IB] /= p.mw[IB] * s.n[IB];
     if (TWOT) {
-      const double vTe = sqrt(8.0 * kRgas * s.Te / kPi / p.mw[IE]);
+      const double vTe = fast_sqrt((8.0 / kPi) * s.Te * p.rg_imw[IE]);
       const double gam = -log(4.0 / vTe * w.Vn[IE]);
       w.ef = w.Vn[IE] * (gam + 2.0) * s.n[IE] * kRgas * s.Te;
     }
@@ -946,7 +1011,7 @@ struct PlasmaPhys {
     double n[NSP];
     number_densities(p, Uin, n);
     double pe = 0.0, nsum = 0.0;
-    if (TWOT && !modE) pe = n[IE] * kRgas * (Uin[ITE] / (n[IE] + kXeps) / p.cv[IE]);
+    if (TWOT && !modE) pe = n[IE] * kRgas * (Uin[ITE] / (n[IE] + kXeps) * p.icv_e);
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++)
       if (!(TWOT && !modE && sp == IE)) nsum += n[sp];
@@ -1016,66 +1081,146 @@ struct PlasmaPhys {
       }
     }
   }
+  // State and wall prescriptions of pass `pass` of the viscous trace of a face point: pass 0 = the interior
+  // state, pass 1 (wall faces) = the wall-side state of the wall type (src/wallBC.cpp:277-543)
+  __device__ static inline void visc_pass_state(const Params &p, int nb, int pass, const double *U, const double *n,
+                                                double *Us, WallFlux &w) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) Us[eq] = U[eq];
+    w = no_prescription();
+    if (pass == 1) {  // the wall-side state
+      const BcDev &wbc = p.bc[-nb - 1];
+      const int type = wbc.type;
+      const double twall = wbc.data[0];
+      double ke = 0.0;
+#pragma unroll
+      for (int d = 0; d < NVEL; d++) ke += 0.5 * U[1 + d] * U[1 + d] / U[0];
+      if (type == TPSRHS_INV) {
+        double nm = 0.0, vn = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
+        nm = fast_sqrt(nm);
+#pragma unroll
+        for (int d = 0; d < DIM; d++) vn += (U[1 + d] / U[0]) * (n[d] / nm);
+#pragma unroll
+        for (int d = 0; d < DIM; d++) Us[1 + d] = U[0] * (U[1 + d] / U[0] - 2.0 * vn * (n[d] / nm));
+      } else if (type == TPSRHS_VISC_ADIAB) {
+#pragma unroll
+        for (int d = 0; d < NVEL; d++) Us[1 + d] = 0.0;
+        Us[ITH] = U[ITH] - ke;
+        w.species = w.heavy_heat = w.electron_heat = true;
+      } else if (type == TPSRHS_VISC_ISOTH) {
+        stagnant_with_temp(p, U, twall, Us);
+        w.species = true;
+      } else {  // VISC_GNRL, src/wallBC.cpp:512-543
+        const BcDev &bc = p.bc[-nb - 1];
+        general_wall_state(p, bc, U, Us);
+        const int hc = static_cast<int>(bc.data[2]), ec = static_cast<int>(bc.data[3]);
+        w.species = true;
+        w.heavy_heat = (hc == TPSRHS_ADIAB);
+        w.electron_heat = TWOT && (ec == TPSRHS_ADIAB || ec == TPSRHS_SHTH);
+        double nm = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
+        w.nm = fast_sqrt(nm);
+        if (ec == TPSRHS_SHTH) sheath(p, Us, w);
+      }
+    }
+  }
+  // passes of the viscous trace of a face point: 0 = no viscous term (Euler; inlets, outlets and slip walls add
+  // the Riemann flux only), 1 = interior face, 2 = wall face (interior state, then wall-side state)
+  __device__ static inline int visc_passes(const Params &p, int nb) {
+    if (p.eq_system == TPSRHS_EULER) return 0;
+    if (nb >= 0) return 1;
+    const BcDev &bc = p.bc[-nb - 1];
+    return (bc.category != TPSRHS_WALL || bc.type == TPSRHS_SLIP) ? 0 : 2;
+  }
+  // ---- the same trace in two steps (3-D face kernel): the state-only closure first -- the transcendental-heavy
+  // part, evaluated while only the NEQ interpolated state values are live --, then the flux from the velocity
+  // gradient and the NORMAL derivatives of the scalar primitives (the heat and diffusion fluxes are linear in
+  // grad(.) . n), which the kernel interpolates afterwards.
+  struct ViscCoef {
+    TCoef t;
+    double vel[NVEL], h[NSP];
+  };
+  __device__ static inline void visc_point_coeffs(const Params &p, const double *U, bool diffusion, ViscCoef &c) {
+    const State s = make_state(p, U);
+    transport_coeffs(p, U, s.Th, s.Te, diffusion, c.t);
+    enthalpies(p, s, c.h);
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) c.vel[d] = s.vel[d];
+  }
+  // gv[i + j*DIM] = d u_i / d x_j; gn[eq] = sum_d n_d dUp_eq/dx_d (read for the scalar rows only).
+  // Same terms as visc_normal_flux (ComputeViscousFluxes . n / ComputeBdrViscousFluxes, src/fluxes.cpp:178-505).
+  __device__ static inline void visc_normal_flux_n(const Params &p, const double *U, const ViscCoef &c, const double *gv,
+                                                   const double *gn, const double *n, const WallFlux &w, double *Fn) {
+    static_assert(!AXISYM, "planar / 3-D form");
+    double Vn[NSP];
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) Vn[sp] = 0.0;
+    if (!w.species) diffusion_velocity(p, c.t, gn, Vn);
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++)
+      if (w.species) Vn[sp] = w.Vn[sp] * w.nm;
+    const double bulk = c.t.bulk - 2. / 3. * c.t.visc;
+    double divV = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) divV += gv[i + i * DIM];
+    double e = 0.0;
+    Fn[0] = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) {
+      double sn = 0.0;
+#pragma unroll
+      for (int j = 0; j < DIM; j++) {
+        double st = c.t.visc * (gv[j + i * DIM] + gv[i + j * DIM]);
+        if (i == j) st += bulk * divV;
+        sn += st * n[j];
+      }
+      Fn[1 + i] = sn;
+      e += sn * c.vel[i];
+    }
+    double HF = 0.0, EF = 0.0;
+    if (w.heavy_heat) {
+      HF = w.hf * w.nm;
+    } else {
+      const double k = TWOT ? c.t.k : c.t.k + c.t.ke;
+      HF -= k * gn[ITH];
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++)
+        if (!(TWOT && sp == IE)) HF += c.h[sp] * Vn[sp];
+    }
+    if (TWOT) {
+      if (w.electron_heat) {
+        EF = w.ef * w.nm;
+      } else {
+        EF -= c.t.ke * gn[ITE];
+        EF += c.h[IE] * Vn[IE];
+      }
+    }
+    Fn[ITH] = e - HF - EF;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) Fn[NVEL + 2 + sp] = -U[NVEL + 2 + sp] * Vn[sp];
+    if (TWOT) Fn[ITE] = -EF;
+  }
   // The viscous trace of one face quadrature point.  Interior face (nb >= 0): Fv(U, g) . n.  Boundary
   // face: the complete additive viscous boundary term -1/2 (Fv_wall + Fv_in) . n of the wall types
   // (src/wallBC.cpp:302-320,448-468,492-510), zero for inlets and outlets.  One transport evaluation
   // site, looped: the kernels carry a single copy of the transport code.
   static constexpr bool HEAVY = true;
+  // the closures split into a state-only part (collision integrals) and terms linear in the gradient: the kernels
+  // evaluate the first before they bring the gradient into registers (flux_coeffs / visc_point_coeffs)
+  static constexpr bool TWO_STEP = true;
   __device__ static inline void visc_trace(const Params &p, int nb, const double *U, const double *g, const double *n,
                                            double radius, double *fn) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) fn[eq] = 0.0;
-    if (p.eq_system == TPSRHS_EULER) return;
-    int type = -1;
-    double twall = 0.0;
-    if (nb < 0) {
-      const BcDev &bc = p.bc[-nb - 1];
-      if (bc.category != TPSRHS_WALL || bc.type == TPSRHS_SLIP) return;  // slip wall: Riemann flux only
-      type = bc.type;
-      twall = bc.data[0];
-    }
-    const int npass = (nb < 0) ? 2 : 1;
+    const int npass = visc_passes(p, nb);
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < npass; pass++) {
       double Us[NEQ];
-#pragma unroll
-      for (int eq = 0; eq < NEQ; eq++) Us[eq] = U[eq];
-      WallFlux w = no_prescription();
-      if (pass == 1) {  // the wall-side state
-        double ke = 0.0;
-#pragma unroll
-        for (int d = 0; d < NVEL; d++) ke += 0.5 * U[1 + d] * U[1 + d] / U[0];
-        if (type == TPSRHS_INV) {
-          double nm = 0.0, vn = 0.0;
-#pragma unroll
-          for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
-          nm = fast_sqrt(nm);
-#pragma unroll
-          for (int d = 0; d < DIM; d++) vn += (U[1 + d] / U[0]) * (n[d] / nm);
-#pragma unroll
-          for (int d = 0; d < DIM; d++) Us[1 + d] = U[0] * (U[1 + d] / U[0] - 2.0 * vn * (n[d] / nm));
-        } else if (type == TPSRHS_VISC_ADIAB) {
-#pragma unroll
-          for (int d = 0; d < NVEL; d++) Us[1 + d] = 0.0;
-          Us[ITH] = U[ITH] - ke;
-          w.species = w.heavy_heat = w.electron_heat = true;
-        } else if (type == TPSRHS_VISC_ISOTH) {
-          stagnant_with_temp(p, U, twall, Us);
-          w.species = true;
-        } else {  // VISC_GNRL, src/wallBC.cpp:512-543
-          const BcDev &bc = p.bc[-nb - 1];
-          general_wall_state(p, bc, U, Us);
-          const int hc = static_cast<int>(bc.data[2]), ec = static_cast<int>(bc.data[3]);
-          w.species = true;
-          w.heavy_heat = (hc == TPSRHS_ADIAB);
-          w.electron_heat = TWOT && (ec == TPSRHS_ADIAB || ec == TPSRHS_SHTH);
-          double nm = 0.0;
-#pragma unroll
-          for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
-          w.nm = fast_sqrt(nm);
-          if (ec == TPSRHS_SHTH) sheath(p, Us, w);
-        }
-      }
+      WallFlux w;
+      visc_pass_state(p, nb, pass, U, n, Us, w);
       double f[NEQ];
       visc_normal_flux(p, Us, g, n, radius, w, f);
       if (nb >= 0) {
@@ -1113,7 +1258,7 @@ struct PlasmaPhys {
       visc = 0.0;
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++)
-        if (sp != IE) visc += q.X[sp] * (vf * p.sq_mwp[sp] * fast_sqrt(Th) * fast_rcp(collision<2, 2>(p, sp, sp, c)));
+        if (sp != IE) visc += q.X[sp] * (p.vf_sq_mwp[sp] * fast_sqrt(Th) * fast_rcp(collision<2, 2>(p, sp, sp, c)));
       bulk = 0.0;
       if (p.multiply) {
         visc *= p.mult_flux[0];
@@ -1123,8 +1268,8 @@ struct PlasmaPhys {
     }
     const Debye d = debye(q.n, Th, Te, fast_rcp(Th), fast_rcp(Te));
     const double sTh = fast_sqrt(Th);
-    const double sv_ion = vf * p.sq_mwp[I_ION] * sTh * fast_rcp(coll::rep22(d.h) * d.circle);
-    const double sv_n = vf * p.sq_mwp[I_N] * sTh * coll::iArAr22(sTh);
+    const double sv_ion = p.vf_sq_mwp[I_ION] * sTh * fast_rcp(coll::rep22(d.h) * d.circle);
+    const double sv_n = p.vf_sq_mwp[I_N] * sTh * coll::iArAr22(sTh);
     visc = q.X[I_ION] * sv_ion + q.X[I_N] * sv_n;
     bulk = 0.0;
     if (p.multiply) {
@@ -1166,7 +1311,7 @@ struct PlasmaPhys {
     } else {
       ne = Up[NVEL + 2 + IE];
     }
-    nh += rhoB / p.mw[IB];
+    nh += rhoB * p.imw[IB];
     const double Th = Up[ITH], Te = TWOT ? Up[ITE] : Up[ITH];
     const double pres = kRgas * (nh * Th + ne * Te);
     double tau_tt = 0.0, tau_tr = 0.0;

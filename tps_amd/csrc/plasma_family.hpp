@@ -44,6 +44,15 @@ static void pick_plasma_family(tpsrhs_operator *op, bool two_temperature, int tr
   }
 }
 
+#if TPSRHS_STAMP
+// diagnostic builds (one translation unit compiled with -DTPSRHS_STAMP=1): the phase cycles of the first
+// `nblocks` blocks of the last stamped kernel, [nblocks][NSTAMP]
+extern "C" int tpsrhs_debug_stamps(unsigned int *out, int nblocks) {
+  const size_t bytes = static_cast<size_t>(nblocks) * tpsrhs::NSTAMP * sizeof(unsigned int);
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(tpsrhs::g_stamp), bytes) == hipSuccess ? 0 : 1;
+}
+#endif
+
 #define TPSRHS_PLASMA_FAMILY(name, DIM, NVEL, NSP, AMBI)                          \
   void name(tpsrhs_operator *op, bool two_temperature, int transport) {           \
     pick_plasma_family<DIM, NVEL, NSP, AMBI>(op, two_temperature, transport);     \

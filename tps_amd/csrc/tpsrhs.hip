@@ -69,7 +69,13 @@ void fill_plasma_params(tpsrhs_operator *op, const tpsrhs_disc *disc, const tpsr
     p.mwp[sp] = p.mw[sp] / kAvogadro;
     p.sq_mwp[sp] = std::sqrt(p.mwp[sp]);
     p.kf_imwp[sp] = (15. / 4. * kBoltz) / p.mwp[sp];
+    p.vf_sq_mwp[sp] = 5. / 16. * std::sqrt(kPi * kBoltz) * p.sq_mwp[sp];
+    p.qkb_charge[sp] = (kQe / kBoltz) * p.charge[sp];
+    p.rg_imw[sp] = kRgas / p.mw[sp];
   }
+  p.ke_fac = 5. / 16. * std::sqrt(kPi * kBoltz) * (15. / 4. * kBoltz) / std::sqrt(p.mwp[NSP - 2]);
+  p.ke_fac3 = std::sqrt(2.0) * p.ke_fac;
+  p.icv_e = 1.0 / p.cv[NSP - 2];
   {  // sqrt(m_i m_j / (m_i + m_j)) / d_fc of the binary diffusivities (src/gas_transport.cpp:291-310,1353-1365)
     const double dfc = 3. / 16. * std::sqrt(2.0 * kPi * kBoltz) / kAvogadro;
     for (int i = 0; i < NSP; i++)
@@ -737,6 +743,19 @@ int tpsrhs_kernel_times(tpsrhs_handle h, int capacity, const char **names, doubl
     }
     if (names) names[n] = kKernelNames[k];
     if (milliseconds) milliseconds[n] = sum / nsets;  // average over the recorded Mults
+  }
+  return n;
+}
+
+int tpsrhs_mult_times(tpsrhs_handle h, int capacity, double *milliseconds) {
+  if (!h || h->sets_recorded == 0 || !milliseconds) return 0;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return 0;
+  const int nsets = static_cast<int>(std::min<int64_t>(h->sets_recorded, tpsrhs_operator::MAXSETS));
+  int n = 0;
+  for (; n < nsets && n < capacity; n++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->evs[n][0], h->evs[n][NKERN]) != hipSuccess) return n;
+    milliseconds[n] = ms;
   }
   return n;
 }

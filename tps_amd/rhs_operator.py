@@ -120,6 +120,12 @@ class RHSoperator:
         n = self._lib.tpsrhs_kernel_times(self._h, 8, names, ms)
         return {names[i].decode(): ms[i] for i in range(n)}
 
+    def mult_times(self):
+        """Device milliseconds of each ``Mult`` since timing was enabled (at most the last 128)."""
+        ms = (C.c_double * 128)()
+        n = self._lib.tpsrhs_mult_times(self._h, 128, ms)
+        return [ms[i] for i in range(n)]
+
     def rk4_step(self, x: torch.Tensor, time: float, dt: float, want_max_char_speed=False, want_nan_count=False):
         """One explicit RK4 step, ``x`` updated in place; returns the new time (the role of
         ``timeIntegrator->Step(*U, time, dt); Check_NAN(); Check_Undershoot();`` in
