@@ -74,22 +74,24 @@ def workload(name):
                 f"SUB_DENS_VEL / outlet SUB_P / isothermal wall ({what})",
                 lambda order: cases.argon_cyl3d(7, 28, 4, order))
     if name == "cfg5":
-        ph = capi.argon_ternary_physics(capi.NS, True, capi.CONSTANT, "arrhenius", radiation=True)
+        ph = capi.argon_ternary_physics(capi.NS, True, capi.CONSTANT, "tabulated", radiation=True)
         return (3, ph, lambda p: cases.argon_axisym(2, 2, 3).bcs,
                 lambda X, p: cases.plasma_state(X, p, nvel=3, seed=12345, amp=0.05, vel0=(1.0, 20.0, 3.0)),
                 "AXISYMMETRIC (r, z) 400x500 quads, two-temperature argon ternary plasma, constant transport, "
-                "2 Arrhenius reactions, NEC radiation table, inlet / outlet / isothermal wall / axis "
+                "ionisation / three-body recombination on the reference's rate tables (test/inputs/rate-coefficients), "
+                "its net-emission table (rad-data/nec_sample.0.h5), inlet / outlet / isothermal wall / axis "
                 "(BASELINE.json configs[4] on one GPU)",
                 lambda order: cases.argon_axisym(40, 50, order))
     if name == "torch6":
-        ph = capi.argon_six_species_physics(capi.NS, capi.CONSTANT, True, True, radiation=True)
+        ph = capi.argon_six_species_physics(capi.NS, capi.CONSTANT, True, "tabulated", radiation=True)
         return (3, ph, lambda p: cases.argon_axisym(2, 2, 3, physics=p).bcs,
                 lambda X, p: cases.plasma_state(X, p, nvel=3, seed=12345, amp=0.05, vel0=(1.0, 20.0, 3.0)),
                 "AXISYMMETRIC (r, z) 400x500 quads, the six-species two-temperature argon mixture of the reference's "
                 "torch input (test/inputs/plasma.ini: Ar.+1, Ar_m, Ar_r, Ar_p, E, Ar; not ambipolar; 11 equations), "
-                "constant transport, 4 reactions, NEC radiation table",
+                "constant transport, the 14 tabulated electron-impact reactions of test/inputs/input.radDecay.ini on the "
+                "reference's rate tables, its net-emission table",
                 lambda order: cases.argon_axisym(40, 50, order, physics=capi.argon_six_species_physics(
-                    capi.NS, capi.CONSTANT, True, True, radiation=True)))
+                    capi.NS, capi.CONSTANT, True, "tabulated", radiation=True)))
     raise SystemExit(f"unknown workload {name}")
 
 

@@ -301,6 +301,23 @@ int tpsrhs_get_primitives(tpsrhs_handle h, double *up_out);
 int tpsrhs_get_gradients(tpsrhs_handle h, double *gradup_out);
 
 /* A->Height() (src/rhs_operator.cpp:49), vfes->GetNDofs(), num_equation. */
+/* Point-wise closures of the gas model on the device, for n conserved states U[eq * n + i] (device pointers,
+ * synchronous): the public GasMixture methods the reference's unit tests call directly --
+ * GetPrimitivesFromConservatives (src/equation_of_state.cpp:321-335,679-700), ComputePressure (:605-628 of the
+ * header, :1044-1062), ComputeSpeedOfSound (:337-348,1405-1432; test/test_speed_of_sound.cpp:84-93),
+ * ComputeMaxCharSpeed (:278-292,1359-1373).  out: [neq][n] for the primitives, [n] otherwise. */
+enum tpsrhs_point_quantity {
+  TPSRHS_POINT_PRIMITIVES = 0,
+  TPSRHS_POINT_PRESSURE = 1,
+  TPSRHS_POINT_SOUND_SPEED = 2,
+  TPSRHS_POINT_MAX_CHAR_SPEED = 3
+};
+int tpsrhs_eval_pointwise(tpsrhs_handle h, int quantity, int64_t n, const double *U, double *out);
+
+/* TableInterpolator::eval of a LinearTable (src/table.cpp:52-110; test/test_table.cpp:104-121) on the device
+ * for n abscissae (x, f: device pointers; the table itself is host data as in tpsrhs_chemistry).  Synchronous. */
+int tpsrhs_table_eval(const tpsrhs_table *table, int64_t n, const double *x, double *f);
+
 int64_t tpsrhs_height(tpsrhs_handle h);
 int64_t tpsrhs_num_dofs(tpsrhs_handle h);
 int tpsrhs_num_equation(tpsrhs_handle h);

@@ -1005,6 +1005,22 @@ int tpsoracle_rk4_step(void *h, double *x, double *time, double dt, double *max_
 }
 // collision-integral fits by name id: 0 att11, 1 att12, 2 att13, 3 att14, 4 att15, 5 rep22, 6 rep23,
 // 7 rep24 (argument: nondimensional temperature); 8 ArAr22, 9 ArAr1P11, 10..14 eAr1r r=1..5 (argument: T in K)
+// LinearTable::eval / findInterval on host arrays (test/test_table.cpp:26-121)
+int tpsoracle_table_eval(const tpsrhs_table *t, int64_t n, const double *x, double *f, int *interval) {
+  try {
+    tpsoracle::LinearTable tab;
+    tab.init(*t);
+    for (int64_t i = 0; i < n; i++) {
+      if (f) f[i] = tab.eval(x[i]);
+      if (interval) interval[i] = tab.findInterval(x[i]);
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
 double tpsoracle_collision_integral(int id, double x) {
   using namespace tpsoracle::collision;
   switch (id) {

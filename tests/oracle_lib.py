@@ -293,3 +293,15 @@ def collision_integral(name, x):
            "ArAr22": 8, "ArAr1P11": 9, "eAr11": 10, "eAr12": 11, "eAr13": 12, "eAr14": 13, "eAr15": 14}
     return lib().tpsoracle_collision_integral(ids[name], float(x))
 
+
+
+def table_eval(table, x):
+    """LinearTable of the oracle on host arrays -> (values, interval indices)"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    f = np.empty_like(x)
+    idx = np.empty(x.shape, dtype=np.int32)
+    L = lib()
+    L.tpsoracle_table_eval.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    st = L.tpsoracle_table_eval(C.byref(table), x.size, x.ctypes.data, f.ctypes.data, idx.ctypes.data)
+    assert st == 0, L.tpsoracle_last_error().decode()
+    return f, idx

@@ -97,13 +97,15 @@ def _boost_transport(ph, factor=300.0):
     (2, False, capi.ARGON_MINIMAL, "arrhenius", capi.VISC_ISOTH, capi.NS),   # the physics of cfg3
     (2, True, capi.ARGON_MINIMAL, "arrhenius", capi.VISC_ADIAB, capi.NS),
     (1, True, capi.CONSTANT, "balance", capi.INV, capi.NS),
-    (3, False, capi.CONSTANT, "tabulated", capi.VISC_ISOTH, capi.NS),
+    (3, False, capi.CONSTANT, "tabulated", capi.VISC_ISOTH, capi.NS),   # the reference's Ionization / 3BdyRecomb tables + NEC table
+    (2, True, capi.ARGON_MINIMAL, "tabulated", capi.VISC_ISOTH, capi.NS),
+    (2, False, capi.CONSTANT, "tabulated_loglog", capi.VISC_ADIAB, capi.NS),  # LinearTable's logarithmic axes
     (1, False, capi.ARGON_MINIMAL, "hoffertlien", capi.INV, capi.EULER),
     (2, True, capi.ARGON_MIXTURE, "arrhenius", capi.VISC_ISOTH, capi.NS),    # GasMixtureTransport, pair table
     (3, False, capi.ARGON_MIXTURE, "arrhenius", capi.VISC_ADIAB, capi.NS),
 ])
 def test_plasma_cylinder(order, two_t, transport, reactions, wall, eq):
-    c = cases.argon_cyl3d(4, 12, 3, order, two_t, transport, reactions, wall, eq, radiation=(reactions == "tabulated"))
+    c = cases.argon_cyl3d(4, 12, 3, order, two_t, transport, reactions, wall, eq, radiation=reactions.startswith("tabulated"))
     _boost_transport(c.physics)
     # amplitudes keep the interpolated species densities positive on these coarse meshes (the reference
     # exits on a negative background density and divides by n_e)
@@ -202,6 +204,66 @@ def test_plasma_six_species(geo, order, transport):
         c = cases.argon_cyl3d(4, 12, 3, order, physics=ph)
     amp = 0.005 if order == 1 else 0.01
     _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=9, amp=amp), tol=_tol(amp))
+
+
+@pytest.mark.parametrize("geo,order", [("3d", 2), ("axisym", 3), ("3d", 3)])
+def test_plasma_six_species_reference_tables(geo, order):
+    """The chemistry of test/inputs/input.radDecay.ini:172-345 as far as it is in scope: the six-species argon
+    mixture with all 14 TABULATED electron-impact reactions on the reference's own rate-coefficient tables
+    (test/inputs/rate-coefficients/*.h5, linear axes) and its net-emission table (rad-data/nec_sample.0.h5)."""
+    ph = capi.argon_six_species_physics(capi.NS, capi.CONSTANT, True, "tabulated", radiation=True)
+    assert ph.chemistry.num_reactions == 14
+    _boost_transport(ph, 30.0)
+    if geo == "axisym":
+        c = cases.argon_axisym(6, 8, order, physics=ph, r_in=0.0)
+    else:
+        c = cases.argon_cyl3d(4, 12, 3, order, physics=ph)
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=13, amp=0.01), tol=_tol(0.01))
+
+
+def _face_point_minimum(field, order, dim=3):
+    """minimum over the face quadrature points of every element of the interpolated nodal field [ne][npe]
+    (tensor Lagrange basis on the Gauss-Legendre nodes, MFEM node order, (p+2)-point face rule)"""
+    n1 = order + 1
+    xn = 0.5 * (np.polynomial.legendre.leggauss(n1)[0] + 1.0)
+    xq = 0.5 * (np.polynomial.legendre.leggauss(((dim - 1) + 2 * order) // 2 + 1)[0] + 1.0)
+
+    def lagrange(x):
+        out = np.ones((len(x), n1))
+        for j in range(n1):
+            for m in range(n1):
+                if m != j:
+                    out[:, j] *= (x - xn[m]) / (xn[j] - xn[m])
+        return out
+
+    Bq, Be = lagrange(xq), lagrange(np.array([0.0, 1.0]))
+    f = field.reshape(-1, n1, n1, n1)  # [e][k][j][i]
+    lo = np.inf
+    for axis in range(3):
+        mats = [Bq, Bq, Bq]
+        mats[axis] = Be
+        v = np.einsum("ekji,ai,bj,ck->ecba", f, mats[0], mats[1], mats[2])
+        lo = min(lo, v.min())
+    return lo
+
+
+def test_species_clamp_active():
+    """src/face_integrator.cpp:297-302 clamps interpolated species densities to >= 0 before the Riemann solver and
+    the viscous fluxes (and the kernels do, kernels.hpp clamp_species).  Here the clamp WORKS on both sides: the
+    metastable density of a four-species ambipolar argon mixture is positive at every node but varies over four
+    decades from node to node, so that its extrapolation to the faces is negative at many quadrature points."""
+    order = 2
+    mesh = meshgen.scramble_orientations(meshgen.box_hex(3, 4, 3, lengths=(1.0, 0.8, 1.2), warp=0.1), 5)
+    ph = capi.argon_levels_physics(1, True, capi.NS, capi.CONSTANT, False, True)
+    _boost_transport(ph, 30.0)
+    U = cases.plasma_state(node_coordinates(mesh, order), ph, nvel=3, seed=21, amp=0.01)
+    rng = np.random.default_rng(8)
+    im = 3 + 2 + 1  # rho Y of Ar_m (mixture order Ar.+1, Ar_m, E, Ar; ambipolar: the first two are active)
+    U[im] = U[im].mean() * 10.0 ** rng.uniform(-4.0, 0.0, size=U.shape[1])
+    assert U[im].min() > 0.0
+    assert _face_point_minimum(U[im], order) < -0.1 * U[im].mean()  # the clamp has work to do
+    # the same density taken smooth gives a different residual: the comparison below does see the clamped points
+    _compare(mesh, capi.Disc(order, 0, 0, 0, 0), ph, [], U, tol=_tol(0.01))
 
 
 # ---- flow/useRoe: RiemannSolverTPS::Eval_Roe on interior faces and inviscid walls (2-D dry air) ----

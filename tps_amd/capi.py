@@ -195,6 +195,48 @@ def make_table(x, f, x_log=False, f_log=False, keep=None) -> Table:
     return Table(len(x), x.ctypes.data_as(_dp), f.ctypes.data_as(_dp), int(x_log), int(f_log))
 
 
+_REF_TABLES = None
+
+
+def reference_table(name) -> np.ndarray:
+    """A table the reference's own tests hold, (N, 2) = (abscissa, value), bit for bit: the 14 argon
+    electron-impact rate coefficients of test/inputs/rate-coefficients/*.h5 ("Ionization", "3BdyRecomb_Ground",
+    "StepIonization_Metastable", ...) and "nec_sample_0" = test/inputs/rad-data/nec_sample.0.h5.  Read from the
+    fixture tests/golden/tables/reference_tables.npz (generator next to it)."""
+    global _REF_TABLES
+    if _REF_TABLES is None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        _REF_TABLES = dict(np.load(os.path.join(root, "tests", "golden", "tables", "reference_tables.npz")))
+    return _REF_TABLES[name]
+
+
+def reference_nec_table(keep) -> "Table":
+    """[plasma_models/radiation_model/net_emission] of test/inputs/input.radDecay.ini:81-87: nec_sample.0.h5,
+    x_log = f_log = False, order 1"""
+    t = reference_table("nec_sample_0")
+    return make_table(t[:, 0], t[:, 1], False, False, keep)
+
+
+# the tabulated electron-impact reactions of test/inputs/input.radDecay.ini:176-345 (x_log = f_log = False, order 1):
+# reactants, products (by species name), table, reaction energy [J/mol]
+RADDECAY_REACTIONS = [
+    ({"ar": 1, "e": 1}, {"ion": 1, "e": 2}, "Ionization", 1520571.3883),
+    ({"ion": 1, "e": 2}, {"ar": 1, "e": 1}, "3BdyRecomb_Ground", -1520571.3883),
+    ({"m": 1, "e": 1}, {"ion": 1, "e": 2}, "StepIonization_Metastable", 403710.426440),
+    ({"ion": 1, "e": 2}, {"m": 1, "e": 1}, "3BdyRecomb_Metastable", -403710.426440),
+    ({"ar": 1, "e": 1}, {"m": 1, "e": 1}, "Excitation_Metastable", 1116860.96186),
+    ({"m": 1, "e": 1}, {"ar": 1, "e": 1}, "DeExcitation_Metastable", -1116860.96186),
+    ({"r": 1, "e": 1}, {"ion": 1, "e": 2}, "StepIonization_Resonant", 389703.996814),
+    ({"ion": 1, "e": 2}, {"r": 1, "e": 1}, "3BdyRecomb_Resonant", -389703.996814),
+    ({"ar": 1, "e": 1}, {"r": 1, "e": 1}, "Excitation_Resonant", 1130867.391486),
+    ({"r": 1, "e": 1}, {"ar": 1, "e": 1}, "DeExcitation_Resonant", -1130867.391486),
+    ({"p": 1, "e": 1}, {"ion": 1, "e": 2}, "StepIonization_4p", 250621.50241031335),
+    ({"ion": 1, "e": 2}, {"p": 1, "e": 1}, "3BdyRecomb_4p", -250621.50241031335),
+    ({"ar": 1, "e": 1}, {"p": 1, "e": 1}, "Excitation_4p", 1269949.8858896866),
+    ({"p": 1, "e": 1}, {"ar": 1, "e": 1}, "DeExcitation_4p", -1269949.8858896866),
+]
+
+
 def argon_ternary_physics(eq_system=NS, two_temperature=False, transport=ARGON_MINIMAL, reactions="arrhenius",
                           third_order_ke=True, radiation=False, ambipolar=True) -> Physics:
     """[plasma_models] of the reference's argon inputs: species (Ar.+1, E, Ar) in mixture order -- active
@@ -255,7 +297,12 @@ def argon_ternary_physics(eq_system=NS, two_temperature=False, transport=ARGON_M
                 ch.product_stoich[sp + r * nsp] = pr[sp]
             for k in range(3):
                 ch.rate_params[k + r * MAXCHEMPARAMS] = abe[k]
-        if reactions == "tabulated":  # ionisation rate as a log-log table of the same Arrhenius law
+        if reactions == "tabulated":  # reactions 1 and 2 of test/inputs/input.radDecay.ini:176-198, the reference's tables
+            for r, name in enumerate(("Ionization", "3BdyRecomb_Ground")):
+                t = reference_table(name)
+                ch.reaction_models[r] = TABULATED_RXN
+                ch.rate_tables[r] = make_table(t[:, 0], t[:, 1], False, False, keep)
+        if reactions == "tabulated_loglog":  # LinearTable's logarithmic axes: the ionisation law sampled log-log
             T = np.geomspace(300.0, 5.0e4, 257)
             A, b, E = rxn[0][2]
             ch.reaction_models[0] = TABULATED_RXN
@@ -269,10 +316,9 @@ def argon_ternary_physics(eq_system=NS, two_temperature=False, transport=ARGON_M
             ch.reaction_models[0] = HOFFERTLIEN
             for k, v in enumerate((1.0e-2, 0.5, 1.85e-18)):
                 ch.rate_params[k] = v
-    if radiation:  # smooth stand-in for the NEC table (the reference's nec_sample.0.h5 is an LFS pointer)
-        T = np.linspace(300.0, 3.0e4, 512)
+    if radiation:  # the reference's net-emission table
         ph.radiation.model = NET_EMISSION
-        ph.radiation.nec_table = make_table(T, 1.0e9 * np.exp(-8.0e4 / T), False, False, keep)
+        ph.radiation.nec_table = reference_nec_table(keep)
     ph._keep = keep
     return ph
 
@@ -328,9 +374,22 @@ def argon_levels_physics(levels=3, ambipolar=False, eq_system=NS, transport=CONS
     ch = ph.chemistry
     ch.electron_index = ie
     ch.minimum_temperature = 2000.0
-    if reactions:
+    keep = []
+    names = ["ion"] + ["m", "r", "p"][:levels] + ["e", "ar"]
+    if reactions == "tabulated":  # the tabulated reactions of test/inputs/input.radDecay.ini among the present species
+        rxn = [r for r in RADDECAY_REACTIONS if all(k in names for k in list(r[0]) + list(r[1]))]
+        ch.num_reactions = len(rxn)
+        for r, (re_, pr, table, en) in enumerate(rxn):
+            ch.reaction_energies[r] = en
+            ch.detailed_balance[r] = 0
+            ch.reaction_models[r] = TABULATED_RXN
+            t = reference_table(table)
+            ch.rate_tables[r] = make_table(t[:, 0], t[:, 1], False, False, keep)
+            for sp in range(nsp):
+                ch.reactant_stoich[sp + r * nsp] = re_.get(names[sp], 0)
+                ch.product_stoich[sp + r * nsp] = pr.get(names[sp], 0)
+    elif reactions:
         # species by name -> stoichiometry in mixture order; Arrhenius A, b, E; energy; detailed balance
-        names = ["ion"] + ["m", "r", "p"][:levels] + ["e", "ar"]
         rxn = [({"e": 1, "ar": 1}, {"ion": 1, "e": 2}, (74072.331348, 1.511, 1176329.772504), 1520571.3883, 0),
                ({"e": 1, "ar": 1}, {"m": 1, "e": 1}, (2.1e4, 1.2, 9.1e5), 1116860.96186, 1),
                ({"m": 1, "e": 1}, {"ion": 1, "e": 2}, (5.6e5, 0.9, 3.3e5), 403710.42644, 0),
@@ -349,11 +408,9 @@ def argon_levels_physics(levels=3, ambipolar=False, eq_system=NS, transport=CONS
             if db:
                 for k, v in enumerate((6.0, 0.0, 134330.0)):
                     ch.equilibrium_constant_params[k + r * MAXCHEMPARAMS] = v
-    keep = []
-    if radiation:
-        T = np.linspace(300.0, 3.0e4, 512)
+    if radiation:  # the reference's net-emission table
         ph.radiation.model = NET_EMISSION
-        ph.radiation.nec_table = make_table(T, 1.0e9 * np.exp(-8.0e4 / T), False, False, keep)
+        ph.radiation.nec_table = reference_nec_table(keep)
     ph._keep = keep
     return ph
 
@@ -363,6 +420,33 @@ def argon_six_species_physics(eq_system=NS, transport=CONSTANT, two_temperature=
     """The mixture of the reference's torch input test/inputs/plasma.ini:200-275: Ar (background), E, Ar.+1 and
     the excited levels Ar_m, Ar_r, Ar_p; NOT ambipolar (the electron density has its own equation)."""
     return argon_levels_physics(3, False, eq_system, transport, two_temperature, reactions, radiation, third_order_ke)
+
+
+def air_five_species_physics(eq_system=EULER) -> Physics:
+    """[atoms], [species] of test/inputs/perfectGas.air.ini:96-134 as test/test_speed_of_sound.cpp:37-41 sets them
+    up: CO2, Ar, O2, E, N2 in mixture order (N2 = background last, electron second to last), NOT ambipolar,
+    single temperature, no transport / chemistry model (constant transport with zero coefficients)."""
+    ph = Physics()
+    ph.eq_system = eq_system
+    ph.working_fluid = USER_DEFINED
+    mC, mO, mAr, mN, mE = 12.011e-3, 15.999e-3, 39.948e-3, 14.0067e-3, 5.4858e-07
+    mw = [mC + 2 * mO, mAr, 2 * mO, mE, 2 * mN]
+    cv = [3.4230, 1.5, 2.5257, 1.5, 2.5017]
+    nsp = 5
+    mx = ph.mixture
+    mx.num_species, mx.is_electron_included, mx.ambipolar, mx.two_temperature = nsp, 1, 0, 0
+    for sp in range(nsp):
+        mx.gas_params[sp + SPECIES_MW * nsp] = mw[sp]
+        mx.gas_params[sp + SPECIES_CHARGES * nsp] = -1.0 if sp == 3 else 0.0
+        mx.gas_params[sp + FORMATION_ENERGY * nsp] = 0.0
+        mx.gas_params[sp + SPECIES_DEGENERACY * nsp] = 1.0
+        mx.molar_cv[sp] = cv[sp]
+    ph.transport_model = CONSTANT
+    ph.constant_transport.electron_index = 3
+    ph.chemistry.electron_index = 3
+    ph.chemistry.num_reactions = 0
+    ph._keep = []
+    return ph
 
 
 def make_bc(attribute, category, bc_type, data=()) -> BC:
@@ -444,6 +528,8 @@ def load():
     lib.tpsrhs_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.tpsrhs_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_mult_times.argtypes = [vp, C.c_int, _dp]
+    lib.tpsrhs_eval_pointwise.argtypes = [vp, C.c_int, C.c_int64, vp, vp]
+    lib.tpsrhs_table_eval.argtypes = [C.POINTER(Table), C.c_int64, vp, vp]
     lib.tpsrhs_kernel_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_rk4_step.argtypes = [vp, C.c_void_p, _dp, C.c_double, _dp, C.POINTER(C.c_int64)]
     lib.tpsrhs_advance.argtypes = [vp, C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
@@ -464,7 +550,8 @@ def load():
 EXPORTED_SYMBOLS = [
     "tpsrhs_create", "tpsrhs_destroy", "tpsrhs_mult", "tpsrhs_mult_host", "tpsrhs_update_gradients",
     "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
-    "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_mult_times", "tpsrhs_kernel_bytes", "tpsrhs_face_tables",
+    "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_mult_times", "tpsrhs_kernel_bytes",
+    "tpsrhs_eval_pointwise", "tpsrhs_table_eval", "tpsrhs_face_tables",
     "tpsrhs_rk4_step", "tpsrhs_advance", "tpsrhs_set_dt", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_status_string",
     "tpsrhs_last_error", "tpsrhs_version",
 ]

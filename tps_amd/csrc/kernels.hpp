@@ -1877,6 +1877,31 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
   }
 }
 
+// Point-wise closures of the gas model for n states U[eq + ...]: U is [NEQ][n] (byNODES), one lane per state
+// (tpsrhs_eval_pointwise).  quantity: 0 primitives -> out[NEQ][n], 1 pressure, 2 speed of sound, 3 |u| + c -> out[n]
+template <class PH>
+__global__ __launch_bounds__(256) void k_point_eval(typename PH::Params prm, int quantity, int64_t n,
+                                                    const double *__restrict__ U, double *__restrict__ out) {
+  constexpr int NEQ = PH::NEQ;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  double u[NEQ];
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) u[eq] = U[eq * n + i];
+  if (quantity == 0) {
+    double up[NEQ];
+    PH::prim(prm, u, up);
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) out[eq * n + i] = up[eq];
+  } else if (quantity == 1) {
+    out[i] = PH::pressure(prm, u);
+  } else if (quantity == 2) {
+    out[i] = PH::sound_speed(prm, u);
+  } else {
+    out[i] = PH::max_char_speed(prm, u);
+  }
+}
+
 // max over the per-block maxima written by k_flux (one block)
 template <int BLOCK>
 __global__ void k_reduce_max(int n, const double *__restrict__ v, double *__restrict__ out) {

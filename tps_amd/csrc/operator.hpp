@@ -123,6 +123,7 @@ struct tpsrhs_operator {
   hipEvent_t *ev = evs[0];
 
   void (*launch)(tpsrhs_operator *, const double *, double *, bool) = nullptr;
+  void (*point_eval)(tpsrhs_operator *, int, int64_t, const double *, double *) = nullptr;
 
   MeshDev mesh_dev() const {
     MeshDev m;
@@ -312,6 +313,15 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
   }
 }
 
+template <class PH>
+void launch_point_eval(tpsrhs_operator *op, int quantity, int64_t n, const double *U, double *out) {
+  const typename PH::Params &prm = *reinterpret_cast<const typename PH::Params *>(op->params);
+  const int grid = static_cast<int>((n + 255) / 256);
+  if (grid == 0) return;
+  hipLaunchKernelGGL((k_point_eval<PH>), dim3(grid), dim3(256), 0, op->stream, prm, quantity, n, U, out);
+  HIP_CHECK(hipGetLastError());
+}
+
 // 1-D operator tables -> this translation unit's __constant__ copy; a function of (dim, order) only
 inline void upload_tables(int dim, int order) {
   const Tables1D tabs = make_tables(order, dim);
@@ -322,6 +332,7 @@ inline void upload_tables(int dim, int order) {
 template <int DIM, class PH>
 void pick_order(tpsrhs_operator *op) {
   upload_tables(DIM, op->order);
+  op->point_eval = &launch_point_eval<PH>;
   switch (op->order) {
     case 1: op->launch = &launch_all<DIM, 1, PH>; break;
     case 2: op->launch = &launch_all<DIM, 2, PH>; break;

@@ -51,6 +51,10 @@ struct DryAirAxiPhys {
   __device__ static inline double max_char_speed(const Params &p, const double *, const State &s) {
     return fast_sqrt(s.k * s.ir) + fast_sqrt(p.gamma * s.p * s.ir);
   }
+  __device__ static inline double max_char_speed(const Params &p, const double *U) {
+    return max_char_speed(p, U, make_state(p, U));
+  }
+  __device__ static inline double pressure(const Params &p, const double *U) { return make_state(p, U).p; }
   __device__ static inline double sound_speed(const Params &p, const double *U) {  // src/equation_of_state.cpp:337-348
     const State s = make_state(p, U);
     return sqrt(p.gamma * s.p * s.ir);

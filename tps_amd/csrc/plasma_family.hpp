@@ -11,6 +11,7 @@ template <int DIM, int NVEL, int NSP, bool AMBI, bool TWOT, int TR>
 static void pick_plasma_orders(tpsrhs_operator *op) {
   typedef PlasmaPhys<DIM, NVEL, NSP, AMBI, TWOT, TR> PH;
   upload_tables(DIM, op->order);
+  op->point_eval = &launch_point_eval<PH>;
   switch (op->order) {
     case 1: op->launch = &launch_all<DIM, 1, PH>; break;
     case 2: op->launch = &launch_all<DIM, 2, PH>; break;

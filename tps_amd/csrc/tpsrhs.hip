@@ -747,6 +747,38 @@ int tpsrhs_kernel_times(tpsrhs_handle h, int capacity, const char **names, doubl
   return n;
 }
 
+int tpsrhs_eval_pointwise(tpsrhs_handle h, int quantity, int64_t n, const double *U, double *out) {
+  if (!h || n < 0 || !U || !out || quantity < 0 || quantity > 3) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "eval_pointwise");
+  return guarded([&] {
+    HIP_CHECK(hipSetDevice(h->device));
+    h->point_eval(h, quantity, n, U, out);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+namespace {
+__global__ void k_table_eval(TableDev t, int64_t n, const double *__restrict__ x, double *__restrict__ f) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) f[i] = table_eval(t, x[i]);
+}
+}  // namespace
+
+int tpsrhs_table_eval(const tpsrhs_table *table, int64_t n, const double *x, double *f) {
+  if (!table || n < 0 || !x || !f) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "table_eval");
+  return guarded([&] {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device visible");
+    tpsrhs_operator tmp;  // owns the device copy of the table for the duration of the call
+    (void)hipGetDevice(&tmp.device);
+    const TableDev td = upload_table(&tmp, *table);
+    if (n > 0) {
+      hipLaunchKernelGGL(k_table_eval, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, td, n, x, f);
+      HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+  });
+}
+
 int tpsrhs_mult_times(tpsrhs_handle h, int capacity, double *milliseconds) {
   if (!h || h->sets_recorded == 0 || !milliseconds) return 0;
   if (hipStreamSynchronize(h->stream) != hipSuccess) return 0;
