@@ -67,9 +67,13 @@ def test_unsupported_configurations_are_refused():
     ma = capi.MeshArgs(c.mesh)
     bcs = (capi.BC * len(c.bcs))(*c.bcs)
     h = C.c_void_p()
-    disc = capi.Disc(2, 1, 1, 0, 0)  # GLL/GLL is not collocated
+    for basis, rule in ((0, 1), (1, 0)):  # built pairs: Gauss-Legendre (0, 0) and Gauss-Lobatto (1, 1)
+        disc = capi.Disc(2, basis, rule, 0, 0)
+        st = lib.tpsrhs_create(C.byref(ma.c), C.byref(disc), C.byref(c.physics), len(c.bcs), bcs, None, C.byref(h))
+        assert st == 2
+    disc = capi.Disc(2, 1, 1, 1, 0)  # the Gauss-Lobatto pair is planar / 3-D
     st = lib.tpsrhs_create(C.byref(ma.c), C.byref(disc), C.byref(c.physics), len(c.bcs), bcs, None, C.byref(h))
-    assert st == 2
+    assert st in (1, 2)
     bad = capi.make_bc(3, capi.WALL, capi.VISC_GNRL)
     bcs2 = (capi.BC * 3)(c.bcs[0], c.bcs[1], bad)
     st = lib.tpsrhs_create(C.byref(ma.c), C.byref(c.disc), C.byref(c.physics), 3, bcs2, None, C.byref(h))

@@ -93,7 +93,8 @@ struct Stamper {
 
 // 1-D operator tables of every (dim, order), filled by tpsrhs_create.  Identical for all operators of
 // a process (they depend on (dim, p) only).  Indexed with compile-time constants they are scalar loads.
-static __constant__ Tables1D c_tab[2][TPSRHS_MAXORDER + 1];
+// (first index: 0 the collocated Gauss-Legendre pair, 1 the non-collocated Gauss-Lobatto pair)
+static __constant__ Tables1D c_tab[2][2][TPSRHS_MAXORDER + 1];
 
 // LDS read of one double (a hook: a volatile-typed variant that stops hipcc from fusing neighbouring
 // 8-byte reads into ds_read2_b64 was measured and dropped -- volatile LDS accesses are followed by a
@@ -122,12 +123,18 @@ __device__ inline void block_sync() {
   }
 }
 
-template <int DIM_, int P_>
+// NC_ = 0: Gauss-Legendre basis + Gauss-Legendre rules (basisType 0, integrationRule 0): nodes and volume
+//          quadrature points coincide, diagonal mass matrix -- the pair of the reference's cylinder / wedge / torch inputs;
+// NC_ = 1: Gauss-Lobatto basis + Gauss-Lobatto rules (1, 1; the reference's defaults, src/M2ulPhyS.cpp:2671-2672):
+//          p+2 volume points per direction, dense element mass matrix, every integral through quadrature points.
+template <int DIM_, int P_, int NC_ = 0>
 struct Cfg {
-  static constexpr int DIM = DIM_, P = P_, N1 = P_ + 1;
+  static constexpr int DIM = DIM_, P = P_, N1 = P_ + 1, NC = NC_;
   static constexpr int NPE = (DIM_ == 3) ? N1 * N1 * N1 : N1 * N1;
   static constexpr int NF = (DIM_ == 3) ? N1 * N1 : N1;  // nodes of a face = lines through the element
-  static constexpr int Q1 = ((DIM_ - 1) + 2 * P_) / 2 + 1;
+  static constexpr int Q1 = ((DIM_ - 1) + 2 * P_) / 2 + 1 + NC_;  // face rule, order OrderW + 2p
+  static constexpr int QV = P_ + 1 + NC_;                          // volume rule, order 2p
+  static constexpr int NQV = (DIM_ == 3) ? QV * QV * QV : QV * QV;
   static constexpr int NQ = (DIM_ == 3) ? Q1 * Q1 : Q1;
   static constexpr int NW = (DIM_ == 3) ? Q1 * N1 : 1;  // half-interpolated face values (3-D only)
   static constexpr int NFACES = 2 * DIM_;
@@ -153,6 +160,7 @@ template <class C>
 struct Tab {
   double x[C::N1], w[C::N1], iw[C::N1], D[C::N1 * C::N1], b0[C::N1], b1[C::N1];
   double xq[C::Q1], wq[C::Q1], B[C::Q1 * C::N1];
+  double xv[C::QV], wv[C::QV];  // volume rule (read by the non-collocated variant)
 };
 
 // ConstantPressureGradient / HeatSource / SpongeZone / JouleHeating of RHSoperator's forcing array
@@ -181,6 +189,7 @@ struct MeshDev {
   int64_t ndofs;
   const double *verts;         // [ne][NV][DIM] lexicographic corners
   const int2 *face_info;       // [ne*NFACES] {neighbour slot | -(bc+1), orientation code}
+  const double *minv;          // non-collocated variant: [ne][NPE][NPE] inverse element mass matrices (symmetric)
 };
 
 // Face records of the block's elements -> LDS, once, so that no later stage has a global load on the
@@ -504,6 +513,10 @@ __device__ inline void load_tables(Tab<C> &t, const Tables1D &src) {
     t.xq[tid] = src.xq[tid];
     t.wq[tid] = src.wq[tid];
   }
+  if (tid < C::QV) {
+    t.xv[tid] = src.xv[tid];
+    t.wv[tid] = src.wv[tid];
+  }
   for (int i = tid; i < C::N1 * C::N1; i += C::BLOCK) t.D[i] = src.D[i];
   for (int i = tid; i < C::Q1 * C::N1; i += C::BLOCK) t.B[i] = src.B[i];
 }
@@ -622,7 +635,7 @@ template <class C, class PH>
 __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
                                                      double *__restrict__ TA) {
   constexpr int NEQ = PH::NEQ;
-  const Tables1D &ct = c_tab[C::DIM - 2][C::P];
+  const Tables1D &ct = c_tab[C::NC][C::DIM - 2][C::P];
   __shared__ double sF[2 * NEQ * C::NODES];
   __shared__ double sT[2 * NEQ * C::TN];
   const int tid = threadIdx.x;
@@ -656,6 +669,358 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Par
 //   interior / shared face: F_v(U_q, gradUp_q) . n_out   (the consumer forms -1/2 (own - neighbour))
 //   boundary face:          the complete additive viscous term of the boundary flux
 // =============================================================================================
+
+// =============================================================================================
+// Non-collocated variant (Cfg::NC: Gauss-Lobatto basis + Gauss-Lobatto rules, the reference's default pair).
+// Nodes and quadrature points differ, so the three element operators of the reference -- Ke (src/gradients.cpp:
+// 84-133), the (v, grad w) blocks of Aflux (src/domain_integrator.cpp:45-99) and Me_inv (src/rhs_operator.cpp:
+// 173-224) -- no longer collapse to point-wise products.  Ke and Aflux are applied by sum factorisation through
+// the QV^dim volume quadrature points (never formed: at p = 3 they are 98 KB per element each); the inverse
+// mass matrix of a non-affine element has no tensor structure and is applied as the dense NPE x NPE block the
+// reference stores too (32 KB per hex at p = 3, streamed once per sweep).
+// =============================================================================================
+constexpr int NC_NFC = 2;  // fields per chunk of the volume operators (LDS scratch per chunk ~ 9 KB per field at p = 3)
+
+// One axis of a tensor-product operator on `nbatch` arrays [d2][d1][d0] in LDS:
+//   out[b][..r..] = sum_a c(r, a) in[b][..a..] along axis AX (0 = fastest), a < NIN = d_AX, r < NOUT;
+//   c(r, a) = M[r * NIN + a], or M[a * NOUT + r] with TR (the transposed operator: quadrature -> nodes).
+// M is a __constant__ table indexed at compile time (scalar operands); one lane per line.
+template <int BLOCK, int AX, int NIN, int NOUT, bool TR>
+__device__ inline void tensor_axis(const double *in, double *out, const double *M, int nbatch, int d0, int d1, int d2,
+                                   int tid) {
+  const int size_in = d0 * d1 * d2, lines = size_in / NIN, size_out = lines * NOUT;
+  for (int item = tid; item < nbatch * lines; item += BLOCK) {
+    const int b = item / lines, l = item - b * lines;
+    int off_in, off_out, s_in, s_out;
+    if (AX == 0) {  // l = j + d1 k
+      off_in = l * d0;
+      off_out = l * NOUT;
+      s_in = s_out = 1;
+    } else if (AX == 1) {  // l = i + d0 k
+      const int k = l / d0, i = l - k * d0;
+      off_in = k * d1 * d0 + i;
+      off_out = k * NOUT * d0 + i;
+      s_in = s_out = d0;
+    } else {  // l = i + d0 j
+      off_in = off_out = l;
+      s_in = s_out = d0 * d1;
+    }
+    const double *src = in + b * size_in + off_in;
+    double v[NIN];
+#pragma unroll
+    for (int a = 0; a < NIN; a++) v[a] = ldsr(&src[a * s_in]);
+    double *dst = out + b * size_out + off_out;
+#pragma unroll
+    for (int r = 0; r < NOUT; r++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < NIN; a++) acc += (TR ? M[a * NOUT + r] : M[r * NIN + a]) * v[a];
+      dst[r * s_out] = acc;
+    }
+  }
+}
+
+// LDS scratch of the volume operators for one chunk of NC_NFC fields of a block:
+//   A: 3 arrays [nb][N1]^(dim-1)[QV]   B (3-D): 3 arrays [nb][N1][QV][QV]   Cq: dim arrays [nb][QV^dim]   OUT: dim arrays [nb][NPE]
+template <class C>
+struct NcScratch {
+  static constexpr int NB = NC_NFC * C::EPB;
+  static constexpr int SA = (C::DIM == 3) ? C::N1 * C::N1 * C::QV : C::N1 * C::QV;
+  static constexpr int SB = (C::DIM == 3) ? C::N1 * C::QV * C::QV : 0;
+  static constexpr int O_A = 0, O_B = O_A + 3 * NB * SA, O_C = O_B + 3 * NB * SB, O_OUT = O_C + C::DIM * NB * C::NQV;
+  static constexpr int TOTAL = O_OUT + C::DIM * NB * C::NPE;
+};
+
+// adjugate (det J  dxi_m/dx_d) and rule weight at volume quadrature point q of local element le
+template <class C>
+__device__ inline double nc_point_geometry(const double *sV, const Tab<C> &tab, int le, int q, double *A) {
+  constexpr int DIM = C::DIM;
+  double xi[DIM], J[DIM * DIM], w = 1.0;
+  int r = q;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    const int qd = r % C::QV;
+    r /= C::QV;
+    xi[d] = tab.xv[qd];
+    w *= tab.wv[qd];
+  }
+  jacobian<DIM>(&sV[le * C::NV * DIM], xi, J);
+  adjugate<DIM>(J, A);
+  return w;
+}
+
+// Volume part of the gradient: g[eq + d*NEQ] += sum_q phi_j(q) w_q (adj(J)^T grad_xi Up_eq)_d (q)   (Ke Up, not yet
+// divided by the mass matrix).  sF: nodal fields [NEQ][NODES].
+template <class C, int NEQ>
+__device__ inline void nc_volume_gradient(const double *sF, double *scr, const double *sV, const Tab<C> &tab,
+                                          const Tables1D &ct, bool node_on, int le_n, int nd, int tid, double *g) {
+  constexpr int DIM = C::DIM, N1 = C::N1, QV = C::QV, B = C::BLOCK;
+  typedef NcScratch<C> S;
+  double *A1 = scr + S::O_A, *A2 = A1 + S::NB * S::SA, *A3 = A2 + S::NB * S::SA;
+  double *B1 = scr + S::O_B, *B2 = B1 + S::NB * S::SB, *B3 = B2 + S::NB * S::SB;
+  double *Cq = scr + S::O_C, *OUT = scr + S::O_OUT;
+#pragma clang loop unroll(disable)
+  for (int f0 = 0; f0 < NEQ; f0 += NC_NFC) {
+    const int nf = (NEQ - f0 < NC_NFC) ? NEQ - f0 : NC_NFC, nb = nf * C::EPB;
+    const double *in = sF + f0 * C::NODES;
+    // nodes -> quadrature points: the three reference derivatives
+    tensor_axis<B, 0, N1, QV, false>(in, A1, ct.Bv, nb, N1, N1, (DIM == 3) ? N1 : 1, tid);  // B(x)
+    tensor_axis<B, 0, N1, QV, false>(in, A2, ct.Dv, nb, N1, N1, (DIM == 3) ? N1 : 1, tid);  // D(x)
+    block_sync<B>();
+    if constexpr (DIM == 3) {
+      tensor_axis<B, 1, N1, QV, false>(A2, B1, ct.Bv, nb, QV, N1, N1, tid);  // D B .
+      tensor_axis<B, 1, N1, QV, false>(A1, B2, ct.Dv, nb, QV, N1, N1, tid);  // B D .
+      tensor_axis<B, 1, N1, QV, false>(A1, B3, ct.Bv, nb, QV, N1, N1, tid);  // B B .
+      block_sync<B>();
+      tensor_axis<B, 2, N1, QV, false>(B1, Cq, ct.Bv, nb, QV, QV, N1, tid);                       // d/dxi0
+      tensor_axis<B, 2, N1, QV, false>(B2, Cq + S::NB * C::NQV, ct.Bv, nb, QV, QV, N1, tid);      // d/dxi1
+      tensor_axis<B, 2, N1, QV, false>(B3, Cq + 2 * S::NB * C::NQV, ct.Dv, nb, QV, QV, N1, tid);  // d/dxi2
+    } else {
+      tensor_axis<B, 1, N1, QV, false>(A2, Cq, ct.Bv, nb, QV, N1, 1, tid);                    // d/dxi0
+      tensor_axis<B, 1, N1, QV, false>(A1, Cq + S::NB * C::NQV, ct.Dv, nb, QV, N1, 1, tid);   // d/dxi1
+    }
+    block_sync<B>();
+    // physical gradient times det J and the weight, at the quadrature points (in place)
+    for (int item = tid; item < nb * C::NQV; item += B) {
+      const int b = item / C::NQV, q = item - b * C::NQV;
+      double A[DIM * DIM];
+      const double w = nc_point_geometry<C>(sV, tab, b % C::EPB, q, A);
+      double dr[DIM], G[DIM];
+#pragma unroll
+      for (int mm = 0; mm < DIM; mm++) dr[mm] = ldsr(&Cq[mm * S::NB * C::NQV + item]);
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        double sgm = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < DIM; mm++) sgm += A[mm + d * DIM] * dr[mm];
+        G[d] = w * sgm;
+      }
+#pragma unroll
+      for (int d = 0; d < DIM; d++) Cq[d * S::NB * C::NQV + item] = G[d];
+    }
+    block_sync<B>();
+    // test with the basis: quadrature points -> nodes, per direction d (batched as [d][b])
+    // NOTE the [d][NB] layout of Cq keeps the nb <= NB used arrays of each d apart: one call per d
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      if constexpr (DIM == 3)
+        tensor_axis<B, 2, QV, N1, true>(Cq + d * S::NB * C::NQV, B1 + d * S::NB * S::SB, ct.Bv, nb, QV, QV, QV, tid);
+      else
+        tensor_axis<B, 1, QV, N1, true>(Cq + d * S::NB * C::NQV, A1 + d * S::NB * S::SA, ct.Bv, nb, QV, QV, 1, tid);
+    }
+    block_sync<B>();
+    if constexpr (DIM == 3) {
+#pragma unroll
+      for (int d = 0; d < DIM; d++)
+        tensor_axis<B, 1, QV, N1, true>(B1 + d * S::NB * S::SB, A1 + d * S::NB * S::SA, ct.Bv, nb, QV, QV, N1, tid);
+      block_sync<B>();
+    }
+#pragma unroll
+    for (int d = 0; d < DIM; d++)
+      tensor_axis<B, 0, QV, N1, true>(A1 + d * S::NB * S::SA, OUT + d * S::NB * C::NPE, ct.Bv, nb, QV, N1,
+                                      (DIM == 3) ? N1 : 1, tid);
+    block_sync<B>();
+    if (node_on) {
+      for (int f = 0; f < nf; f++)
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+          const double val = ldsr(&OUT[d * S::NB * C::NPE + (f * C::EPB + le_n) * C::NPE + nd]);
+          // (f0 + f) is a run-time index: select, do not index the register array dynamically
+#pragma unroll
+          for (int eq = 0; eq < NEQ; eq++)
+            if (eq == f0 + f) g[eq + d * NEQ] += val;
+        }
+    }
+    block_sync<B>();
+  }
+}
+
+// Volume term of the residual: z[eq] += sum_q w_q sum_m dphi_j/dxi_m(q) sum_d adj(m,d)(q) F_{eq,d}(q), with the nodal
+// flux interpolated to the quadrature points -- Aflux F of the reference (src/domain_integrator.cpp:45-99,
+// src/rhs_operator.cpp:379-391).  sF: nodal physical flux [(eq + d*NEQ)][NODES].
+template <class C, int NEQ>
+__device__ inline void nc_volume_divergence(const double *sF, double *scr, const double *sV, const Tab<C> &tab,
+                                            const Tables1D &ct, bool node_on, int le_n, int nd, int tid, double *z) {
+  constexpr int DIM = C::DIM, N1 = C::N1, QV = C::QV, B = C::BLOCK;
+  typedef NcScratch<C> S;
+  double *A1 = scr + S::O_A, *B1 = scr + S::O_B, *Cq = scr + S::O_C, *OUT = scr + S::O_OUT;
+#pragma clang loop unroll(disable)
+  for (int f0 = 0; f0 < NEQ; f0 += NC_NFC) {
+    const int nf = (NEQ - f0 < NC_NFC) ? NEQ - f0 : NC_NFC, nb = nf * C::EPB;
+    // nodes -> quadrature points of the DIM flux components (B in every direction)
+#pragma unroll
+    for (int d = 0; d < DIM; d++)
+      tensor_axis<B, 0, N1, QV, false>(sF + (f0 + d * NEQ) * C::NODES, A1 + d * S::NB * S::SA, ct.Bv, nb, N1, N1,
+                                       (DIM == 3) ? N1 : 1, tid);
+    block_sync<B>();
+    if constexpr (DIM == 3) {
+#pragma unroll
+      for (int d = 0; d < DIM; d++)
+        tensor_axis<B, 1, N1, QV, false>(A1 + d * S::NB * S::SA, B1 + d * S::NB * S::SB, ct.Bv, nb, QV, N1, N1, tid);
+      block_sync<B>();
+#pragma unroll
+      for (int d = 0; d < DIM; d++)
+        tensor_axis<B, 2, N1, QV, false>(B1 + d * S::NB * S::SB, Cq + d * S::NB * C::NQV, ct.Bv, nb, QV, QV, N1, tid);
+    } else {
+#pragma unroll
+      for (int d = 0; d < DIM; d++)
+        tensor_axis<B, 1, N1, QV, false>(A1 + d * S::NB * S::SA, Cq + d * S::NB * C::NQV, ct.Bv, nb, QV, N1, 1, tid);
+    }
+    block_sync<B>();
+    // contravariant components times the weight (in place)
+    for (int item = tid; item < nb * C::NQV; item += B) {
+      const int b = item / C::NQV, q = item - b * C::NQV;
+      double A[DIM * DIM];
+      const double w = nc_point_geometry<C>(sV, tab, b % C::EPB, q, A);
+      double F[DIM], G[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) F[d] = ldsr(&Cq[d * S::NB * C::NQV + item]);
+#pragma unroll
+      for (int mm = 0; mm < DIM; mm++) {
+        double sgm = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) sgm += A[mm + d * DIM] * F[d];
+        G[mm] = w * sgm;
+      }
+#pragma unroll
+      for (int mm = 0; mm < DIM; mm++) Cq[mm * S::NB * C::NQV + item] = G[mm];
+    }
+    block_sync<B>();
+    // quadrature points -> nodes: component m with the transposed derivative in direction m
+    if constexpr (DIM == 3) {
+      tensor_axis<B, 2, QV, N1, true>(Cq, B1, ct.Bv, nb, QV, QV, QV, tid);
+      tensor_axis<B, 2, QV, N1, true>(Cq + S::NB * C::NQV, B1 + S::NB * S::SB, ct.Bv, nb, QV, QV, QV, tid);
+      tensor_axis<B, 2, QV, N1, true>(Cq + 2 * S::NB * C::NQV, B1 + 2 * S::NB * S::SB, ct.Dv, nb, QV, QV, QV, tid);
+      block_sync<B>();
+      tensor_axis<B, 1, QV, N1, true>(B1, A1, ct.Bv, nb, QV, QV, N1, tid);
+      tensor_axis<B, 1, QV, N1, true>(B1 + S::NB * S::SB, A1 + S::NB * S::SA, ct.Dv, nb, QV, QV, N1, tid);
+      tensor_axis<B, 1, QV, N1, true>(B1 + 2 * S::NB * S::SB, A1 + 2 * S::NB * S::SA, ct.Bv, nb, QV, QV, N1, tid);
+      block_sync<B>();
+      tensor_axis<B, 0, QV, N1, true>(A1, OUT, ct.Dv, nb, QV, N1, N1, tid);
+      tensor_axis<B, 0, QV, N1, true>(A1 + S::NB * S::SA, OUT + S::NB * C::NPE, ct.Bv, nb, QV, N1, N1, tid);
+      tensor_axis<B, 0, QV, N1, true>(A1 + 2 * S::NB * S::SA, OUT + 2 * S::NB * C::NPE, ct.Bv, nb, QV, N1, N1, tid);
+    } else {
+      tensor_axis<B, 1, QV, N1, true>(Cq, A1, ct.Bv, nb, QV, QV, 1, tid);
+      tensor_axis<B, 1, QV, N1, true>(Cq + S::NB * C::NQV, A1 + S::NB * S::SA, ct.Dv, nb, QV, QV, 1, tid);
+      block_sync<B>();
+      tensor_axis<B, 0, QV, N1, true>(A1, OUT, ct.Dv, nb, QV, N1, 1, tid);
+      tensor_axis<B, 0, QV, N1, true>(A1 + S::NB * S::SA, OUT + S::NB * C::NPE, ct.Bv, nb, QV, N1, 1, tid);
+    }
+    block_sync<B>();
+    if (node_on) {
+      for (int f = 0; f < nf; f++) {
+        double val = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < DIM; mm++) val += ldsr(&OUT[mm * S::NB * C::NPE + (f * C::EPB + le_n) * C::NPE + nd]);
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++)
+          if (eq == f0 + f) z[eq] += val;
+      }
+    }
+    block_sync<B>();
+  }
+}
+
+// v <- Me^-1 v for NV nodal vectors held one entry per node lane (src/gradients.cpp:198-229, src/rhs_operator.cpp:
+// 432-448).  The inverse is symmetric: lane j walks column j, i.e. every step of the loop reads one contiguous row.
+template <class C, int NV>
+__device__ inline void nc_apply_minv(const double *__restrict__ minv, double *sR, bool node_on, int e, int le_n, int nd,
+                                     int tid, double *v) {
+  if (node_on) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) sR[k * C::NODES + tid] = v[k];
+  }
+  block_sync<C::BLOCK>();
+  if (node_on) {
+    const double *Mi = minv + static_cast<int64_t>(e) * (C::NPE * C::NPE) + nd;
+    const double *r = sR + le_n * C::NPE;
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = 0.0;
+    for (int a = 0; a < C::NPE; a++) {
+      const double mm = Mi[a * C::NPE];
+#pragma unroll
+      for (int k = 0; k < NV; k++) acc[k] += mm * ldsr(&r[k * C::NODES + a]);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = acc[k];
+  }
+  block_sync<C::BLOCK>();
+}
+
+// Face term of the gradient through the face quadrature points (GradFaceIntegrator::AssembleFaceVector,
+// src/faceGradientIntegration.cpp:40-140): g[eq + d*NEQ] += sum_q w_q phi_j(q) 1/2 (Up2 - Up1)(q) n_d(q) over the two
+// faces of direction D.  sT: own | neighbour traces of Up at the face nodes, [2*NEQ][TN]; scr: >= 2*NEQ*TW + NEQ*TQ.
+template <class C, class PH, int D>
+__device__ inline void nc_grad_jump(const int2 *sFI, const typename PH::Params &prm, double *sT, double *scr, const double *sV,
+                                    const Tab<C> &tab, const Tables1D &ct, bool node_on, int le_n, const int *idx, int tid,
+                                    double *g) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  double *Wb = scr, *R = scr + 2 * NEQ * C::TW;
+  interp1_lines<C, 2 * NEQ>(sT, Wb, ct, tid);
+  block_sync<C::BLOCK>();
+  double jump[C::Q_ROUNDS][NEQ], nw[C::Q_ROUNDS][DIM];
+#pragma unroll
+  for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
+    const int item = tid + rd * C::BLOCK;
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) jump[rd][eq] = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) nw[rd][d] = 0.0;
+    if (item < C::TQ) {
+      const int pf = item / C::NQ, q = item - pf * C::NQ;
+      const int le = pf >> 1, s = pf & 1;
+      const int nb = sFI[le * C::NFACES + 2 * D + s].x;
+      if (nb != INT32_MIN) {
+        double bq[C::N1];
+        const int qrow = (DIM == 2) ? q : q / C::Q1;
+#pragma unroll
+        for (int a = 0; a < C::N1; a++) bq[a] = tab.B[qrow * C::N1 + a];
+        double u1[NEQ], u2[NEQ];
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) {
+          u1[eq] = interp2_point<C>(sT + eq * C::TN, Wb + eq * C::TW, bq, pf, q);
+          u2[eq] = interp2_point<C>(sT + (NEQ + eq) * C::TN, Wb + (NEQ + eq) * C::TW, bq, pf, q);
+        }
+        if (nb < 0) {  // boundary: u2 = u1, or the wall ghost of useBCinGrad (:96-113)
+#pragma unroll
+          for (int eq = 0; eq < NEQ; eq++) u2[eq] = u1[eq];
+          if (prm.use_bc_in_grad) PH::bc_grad_prim(prm, prm.bc[-nb - 1], u1, u2);
+        }
+        double n[DIM], wq, Xq[DIM];
+        face_geometry<C, D>(&sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) jump[rd][eq] = 0.5 * (u2[eq] - u1[eq]);
+#pragma unroll
+        for (int d = 0; d < DIM; d++) nw[rd][d] = wq * n[d];
+      }
+    }
+  }
+  block_sync<C::BLOCK>();  // Wb is dead
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+#pragma unroll
+    for (int rd = 0; rd < C::Q_ROUNDS; rd++) {
+      const int item = tid + rd * C::BLOCK;
+      if (item < C::TQ) {
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) R[eq * C::TQ + item] = nw[rd][d] * jump[rd][eq];
+      }
+    }
+    block_sync<C::BLOCK>();
+    double *W2 = (DIM == 3) ? Wb : R;  // 2-D: project2_lines reads R directly
+    project1_lines<C, NEQ>(R, Wb, ct, tid);
+    if (DIM == 3) block_sync<C::BLOCK>();
+    project2_lines<C, NEQ>(W2, sT, ct, tid);  // L over the traces (consumed)
+    block_sync<C::BLOCK>();
+    if (node_on) {
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) g[eq + d * NEQ] += lift_pair<C, D>(sT + eq * C::TN, tab, le_n, idx);
+    }
+    block_sync<C::BLOCK>();
+  }
+}
+
 template <class C, class PH>
 struct GradLds {
   static constexpr int NEQ = PH::NEQ, DIM = C::DIM;
@@ -671,8 +1036,11 @@ struct GradLds {
   static constexpr bool G_IN_LDS = PH::HEAVY;
   static constexpr int J = cmax(2 * NEQ * C::TN, (G_IN_LDS ? DIM : 1) * NEQ * C::NODES);
   static constexpr int W = CH * C::TW;
-  static constexpr int O_U = 0, O_UP = NEQ * C::NODES, O_J = O_UP + SUP, O_W = O_J + J;
-  static constexpr int TOTAL = O_W + W;
+  // non-collocated variant: scratch of the volume operator / the quadrature-point gradient jump / the vectors of
+  // the dense inverse mass (one after the other)
+  static constexpr int V = C::NC ? cmax(cmax(NcScratch<C>::TOTAL, 2 * NEQ * C::TW + NEQ * C::TQ), NEQ * DIM * C::NODES) : 0;
+  static constexpr int O_U = 0, O_UP = NEQ * C::NODES, O_J = O_UP + SUP, O_W = O_J + J, O_V = O_W + W;
+  static constexpr int TOTAL = O_V + V;
 };
 
 // Gradient jump of one direction pair, collocated: g += M^-1 sum_faces <phi, (u^ - u) n>.
@@ -1041,7 +1409,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
                                                        double *__restrict__ TB) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   typedef GradLds<C, PH> L;
-  const Tables1D &ct = c_tab[DIM - 2][C::P];
+  const Tables1D &ct = c_tab[C::NC][DIM - 2][C::P];
   __shared__ Tab<C> tab;
   __shared__ double sV[C::EPB * C::NV * DIM];
   __shared__ double pool[L::TOTAL];
@@ -1092,7 +1460,9 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
 #pragma unroll
   for (int k = 0; k < NEQ * DIM; k++) g[k] = 0.0;
   double inv_mass = 0.0;
-  if (node_on) {
+  if constexpr (C::NC) {
+    nc_volume_gradient<C, NEQ>(sUp, pool + L::O_V, sV, tab, ct, node_on, le_n, nd, tid, g);
+  } else if (node_on) {
     double xi[DIM], J[DIM * DIM], A[DIM * DIM];
     double iwn = 1.0;
 #pragma unroll
@@ -1135,27 +1505,37 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
   STAMP(2);
   // ---- face part of the gradient, collocated (grad_jump_nodal), one direction pair at a time
   if (!(TPSRHS_ABLATE & 8)) {
+    // the jump of one direction pair: collocated (a product at the face nodes), or through the face quadrature
+    // points when nodes and points differ
+    auto jump = [&](auto dtag) {
+      constexpr int D = decltype(dtag)::value;
+      if constexpr (C::NC) {
+        nc_grad_jump<C, PH, D>(sFI, prm, sJ, pool + L::O_V, sV, tab, ct, node_on, le_n, idx, tid, g);
+      } else {
+        if (node_on) grad_jump_nodal<C, PH>(D, sFI, prm, sJ, sJ + NEQ * C::TN, sV, tab, le_n, idx, inv_mass, g);
+        block_sync<C::BLOCK>();
+      }
+    };
     trace_lines<C, 0, NEQ>(sUp, sJ, ct, tid);
     block_sync<C::BLOCK>();  // own traces complete (boundary faces copy them)
     store_neighbour_traces<C, NEQ>(ta0, sJ, sJ + NEQ * C::TN, tid);
     block_sync<C::BLOCK>();
-    if (node_on) grad_jump_nodal<C, PH>(0, sFI, prm, sJ, sJ + NEQ * C::TN, sV, tab, le_n, idx, inv_mass, g);
-    block_sync<C::BLOCK>();
+    jump(std::integral_constant<int, 0>());
     trace_lines<C, 1, NEQ>(sUp, sJ, ct, tid);
     block_sync<C::BLOCK>();
     store_neighbour_traces<C, NEQ>(ta1, sJ, sJ + NEQ * C::TN, tid);
     block_sync<C::BLOCK>();
-    if (node_on) grad_jump_nodal<C, PH>(1, sFI, prm, sJ, sJ + NEQ * C::TN, sV, tab, le_n, idx, inv_mass, g);
-    block_sync<C::BLOCK>();
+    jump(std::integral_constant<int, 1>());
     if (DIM == 3) {
       trace_lines<C, (DIM == 3 ? 2 : 0), NEQ>(sUp, sJ, ct, tid);
       block_sync<C::BLOCK>();
       store_neighbour_traces<C, NEQ>(ta2, sJ, sJ + NEQ * C::TN, tid);
       block_sync<C::BLOCK>();
-      if (node_on) grad_jump_nodal<C, PH>(2, sFI, prm, sJ, sJ + NEQ * C::TN, sV, tab, le_n, idx, inv_mass, g);
-      block_sync<C::BLOCK>();
+      jump(std::integral_constant<int, (DIM == 3 ? 2 : 0)>());
     }
   }
+  // non-collocated: gradUp = Me^-1 (Ke Up + face terms), dense (src/gradients.cpp:198-229)
+  if constexpr (C::NC) nc_apply_minv<C, NEQ * DIM>(m.minv, pool + L::O_V, node_on, e0 + le_n, le_n, nd, tid, g);
 
   STAMP(3);
   if (node_on) {
@@ -1334,7 +1714,7 @@ template <class C, class PH>
 __global__ __launch_bounds__(256) void k_bc_mean(int nfaces, const int2 *__restrict__ faces,
                                                  const double *__restrict__ TA, double *__restrict__ sums) {
   constexpr int NEQ = PH::NEQ;
-  const Tables1D &ct = c_tab[C::DIM - 2][C::P];
+  const Tables1D &ct = c_tab[C::NC][C::DIM - 2][C::P];
   __shared__ double red[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   double cw[C::N1];
@@ -1385,7 +1765,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_bc_nr(MeshDev m, typename PH::Para
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   if (dt_dev) prm.nr_dt = *dt_dev;  // tpsrhs_advance keeps dt in device memory
   static_assert(C::NQ <= C::BLOCK, "one lane per face quadrature point");
-  const Tables1D &ct = c_tab[DIM - 2][C::P];
+  const Tables1D &ct = c_tab[C::NC][DIM - 2][C::P];
   __shared__ Tab<C> tab;
   load_tables<C>(tab, ct);
   __syncthreads();
@@ -1448,7 +1828,7 @@ __global__ __launch_bounds__(256) void k_forcing(MeshDev m, typename PH::Params 
                                                  const double *__restrict__ U, const double *__restrict__ gradUp,
                                                  double *__restrict__ Y) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-  const Tables1D &ct = c_tab[DIM - 2][C::P];
+  const Tables1D &ct = c_tab[C::NC][DIM - 2][C::P];
   const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (n >= m.ndofs) return;
   const int e = static_cast<int>(n / C::NPE), nd = static_cast<int>(n - static_cast<int64_t>(e) * C::NPE);
@@ -1485,8 +1865,12 @@ struct FluxLds {
   static constexpr int X = BOTH_2D ? 4 * NEQ * C::TN : cmax(cmax(2 * NEQ * C::TN, NEQ * C::TQ), NEQ * C::TN);
   static constexpr int Y = BOTH_2D ? 2 * NEQ * C::TQ
                                    : cmax(cmax(2 * NEQ * C::TW, NEQ * C::TW), (DIM == 2) ? NEQ * C::TQ : 0);
-  static constexpr int GF = cmax(NEQ * DIM * C::NODES, X + Y);  // sGf, then X and Y
+  // non-collocated variant: the nodal flux and the scratch of the volume operator live together; the vectors of
+  // the dense inverse mass are staged in X at the end
+  static constexpr int NCV = C::NC ? NcScratch<C>::TOTAL : 0;
+  static constexpr int GF = cmax(NEQ * DIM * C::NODES + NCV, X + Y);  // sGf (+ scratch), then X and Y
   static constexpr int TOTAL = NEQ * C::NODES + GF;
+  static_assert(!C::NC || X >= NEQ * C::NODES, "staging of the inverse-mass vectors");
 };
 
 template <class C, class PH, int D>
@@ -1687,7 +2071,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
                                                    double *__restrict__ block_speed) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   typedef FluxLds<C, PH> L;
-  const Tables1D &ct = c_tab[DIM - 2][C::P];
+  const Tables1D &ct = c_tab[C::NC][DIM - 2][C::P];
   __shared__ Tab<C> tab;
   __shared__ double sV[C::EPB * C::NV * DIM];
   __shared__ double pool[L::TOTAL];
@@ -1785,15 +2169,20 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
       wn *= radius;
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (C::NC) {  // the physical nodal flux: the metric is applied at the volume quadrature points
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++)
+      for (int k = 0; k < NEQ * DIM; k++) sGf[k * C::NODES + tid] = F[k];
+    } else {
 #pragma unroll
-      for (int mm = 0; mm < DIM; mm++) {
-        double s = 0.0;
+      for (int eq = 0; eq < NEQ; eq++)
 #pragma unroll
-        for (int d = 0; d < DIM; d++) s += A[mm + d * DIM] * F[eq + d * NEQ];
-        sGf[(eq + mm * NEQ) * C::NODES + tid] = wn * s;
-      }
+        for (int mm = 0; mm < DIM; mm++) {
+          double s = 0.0;
+#pragma unroll
+          for (int d = 0; d < DIM; d++) s += A[mm + d * DIM] * F[eq + d * NEQ];
+          sGf[(eq + mm * NEQ) * C::NODES + tid] = wn * s;
+        }
+    }
   }
   // max |u|+c of the block -> one slot per block.  (A single global atomicMax per wave serialises
   // at the L2: ~12 ns each, 0.6 ms for 50k waves -- measured; per-block stores cost nothing and a
@@ -1822,7 +2211,10 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
   double z[NEQ];
 #pragma unroll
   for (int eq = 0; eq < NEQ; eq++) z[eq] = 0.0;
-  if (node_on) {
+  if constexpr (C::NC) {
+    static_assert(!PH::AXISYM, "the non-collocated variant is planar / 3-D");
+    nc_volume_divergence<C, NEQ>(sGf, sGf + NEQ * DIM * C::NODES, sV, tab, ct, node_on, le_n, nd, tid, z);
+  } else if (node_on) {
     double Dc[DIM][C::N1];
 #pragma unroll
     for (int mm = 0; mm < DIM; mm++)
@@ -1870,6 +2262,10 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
                                                 tid);
   }
 
+  if constexpr (C::NC) {  // y = Me^-1 z (src/rhs_operator.cpp:432-448), then the point sources
+    nc_apply_minv<C, NEQ>(m.minv, sX, node_on, e0 + le_n, le_n, nd, tid, z);
+    inv_mass = 1.0;
+  }
   if (node_on) {
     const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
 #pragma unroll

@@ -56,6 +56,8 @@ const char *kKernelNames[NKERN] = {"k_traces", "k_gradient", "k_flux"};
 
 struct tpsrhs_operator {
   int dim = 0, order = 0, neq = 0, nvel = 0;
+  int nc = 0;  // 1: the non-collocated Gauss-Lobatto pair (basisType 1, integrationRule 1), 0: the collocated Gauss-Legendre pair
+  double *d_minv = nullptr;  // nc: [ne][npe][npe] inverse element mass matrices
   int ne = 0, nfaces = 0, nf = 0, nq = 0;
   int64_t ndofs = 0;
   int device = 0;
@@ -132,6 +134,7 @@ struct tpsrhs_operator {
     m.ndofs = ndofs;
     m.verts = d_verts;
     m.face_info = d_face_info;
+    m.minv = d_minv;
     return m;
   }
   ~tpsrhs_operator() {
@@ -143,6 +146,7 @@ struct tpsrhs_operator {
                     static_cast<void *>(d_shared_orient), static_cast<void *>(d_send)})
       if (p) (void)hipFree(p);
     if (d_chem) (void)hipFree(d_chem);
+    if (d_minv) (void)hipFree(d_minv);
     if (d_rk) (void)hipFree(d_rk);
     if (d_nan) (void)hipFree(d_nan);
     if (d_forcing) (void)hipFree(d_forcing);
@@ -167,7 +171,7 @@ namespace {
 inline void exchange(tpsrhs_operator *op, int phase, double *T, int nfld, int per, hipStream_t stream) {
   const Topology &tp = op->topo;
   if (tp.num_shared == 0) return;
-  const int n1 = (phase == 0) ? op->order + 1 : ((op->dim - 1) + 2 * op->order) / 2 + 1;
+  const int n1 = (phase == 0) ? op->order + 1 : rule_points(op->nc, (op->dim - 1) + 2 * op->order);
   const int64_t total = static_cast<int64_t>(tp.num_shared) * nfld * per;
   const int grid = static_cast<int>(std::min<int64_t>((total + 255) / 256, 2048));
   if (op->dim == 3)
@@ -183,9 +187,9 @@ inline void exchange(tpsrhs_operator *op, int phase, double *T, int nfld, int pe
   if (st != 0) throw std::runtime_error("halo callback failed in phase " + std::to_string(phase));
 }
 
-template <int DIM, int P, class PH>
+template <int DIM, int P, class PH, int NC = 0>
 void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_only) {
-  typedef Cfg<DIM, P> C;
+  typedef Cfg<DIM, P, NC> C;
   static_assert(sizeof(typename PH::Params) <= sizeof(op->params), "parameter block too large");
   const typename PH::Params &prm = *reinterpret_cast<const typename PH::Params *>(op->params);
   const int nblocks = (op->ne + C::EPB - 1) / C::EPB;
@@ -323,14 +327,35 @@ void launch_point_eval(tpsrhs_operator *op, int quantity, int64_t n, const doubl
 }
 
 // 1-D operator tables -> this translation unit's __constant__ copy; a function of (dim, order) only
-inline void upload_tables(int dim, int order) {
-  const Tables1D tabs = make_tables(order, dim);
-  const size_t off = (static_cast<size_t>(dim - 2) * (TPSRHS_MAXORDER + 1) + order) * sizeof(Tables1D);
+inline void upload_tables(int dim, int order, int nc = 0) {
+  const Tables1D tabs = make_tables(order, dim, nc, nc);
+  const size_t off = ((static_cast<size_t>(nc) * 2 + (dim - 2)) * (TPSRHS_MAXORDER + 1) + order) * sizeof(Tables1D);
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &tabs, sizeof(Tables1D), off, hipMemcpyHostToDevice));
+}
+
+// non-collocated (Gauss-Lobatto / Gauss-Lobatto) kernels: orders 1..3
+template <int DIM, class PH>
+void pick_order_nc(tpsrhs_operator *op) {
+  upload_tables(DIM, op->order, 1);
+  op->point_eval = &launch_point_eval<PH>;
+  if constexpr (PH::AXISYM) {
+    throw Unsupported("the Gauss-Lobatto pair is built for the planar 2-D and the 3-D formulation");
+  } else {
+    switch (op->order) {
+      case 1: op->launch = &launch_all<DIM, 1, PH, 1>; break;
+      case 2: op->launch = &launch_all<DIM, 2, PH, 1>; break;
+      case 3: op->launch = &launch_all<DIM, 3, PH, 1>; break;
+      default: throw Unsupported("Gauss-Lobatto basis + rule: polynomial orders 1..3 are built");
+    }
+  }
 }
 
 template <int DIM, class PH>
 void pick_order(tpsrhs_operator *op) {
+  if (op->nc) {
+    pick_order_nc<DIM, PH>(op);
+    return;
+  }
   upload_tables(DIM, op->order);
   op->point_eval = &launch_point_eval<PH>;
   switch (op->order) {

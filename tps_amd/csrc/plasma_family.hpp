@@ -10,6 +10,16 @@
 template <int DIM, int NVEL, int NSP, bool AMBI, bool TWOT, int TR>
 static void pick_plasma_orders(tpsrhs_operator *op) {
   typedef PlasmaPhys<DIM, NVEL, NSP, AMBI, TWOT, TR> PH;
+  if (op->nc) {
+    // the Gauss-Lobatto pair: the ternary mixtures (the species count of test/inputs/argonMinimal.ini, which runs
+    // on that pair), planar / 3-D
+    if constexpr (NSP == 3 && NVEL == DIM) {
+      pick_order_nc<DIM, PH>(op);
+      return;
+    } else {
+      throw Unsupported("Gauss-Lobatto basis + rule: built for dry air and the ternary plasma (planar 2-D, 3-D)");
+    }
+  }
   upload_tables(DIM, op->order);
   op->point_eval = &launch_point_eval<PH>;
   switch (op->order) {

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <new>
+#include <thread>
 
 // kernel families instantiated in their own translation units (plasma_family.hpp)
 #define DECL(name) void name(tpsrhs_operator *op, bool two_temperature, int transport)
@@ -174,11 +175,128 @@ void fill_plasma_params(tpsrhs_operator *op, const tpsrhs_disc *disc, const tpsr
   p.chem = dc;
 }
 
+// Inverse element mass matrices of the non-collocated pair: M_jk = sum_q w_q det J(q) phi_j(q) phi_k(q) with the
+// order-2p rule of the same family (MassIntegrator, src/rhs_operator.cpp:179-187), inverted per element
+// (Cholesky; the reference calls DenseMatrix::Invert, :205-212) -- the role of Me_inv, built once, on the host,
+// on all cores.  verts: [ne][2^dim][dim] lexicographic corners.
+std::vector<double> inverse_mass_matrices(const std::vector<double> &verts, int dim, int order, int ne) {
+  const Tables1D t = make_tables(order, dim, 1, 1);
+  const int n1 = order + 1, qv = rule_points(1, 2 * order);
+  const int npe = (dim == 3) ? n1 * n1 * n1 : n1 * n1, nq = (dim == 3) ? qv * qv * qv : qv * qv, nv = 1 << dim;
+  // Phi[q][j]: tensor basis at the tensor rule
+  std::vector<double> Phi(static_cast<size_t>(nq) * npe), wq(nq), xq(static_cast<size_t>(nq) * dim);
+  for (int q = 0; q < nq; q++) {
+    int qi[3] = {q % qv, (q / qv) % qv, q / (qv * qv)};
+    wq[q] = 1.0;
+    for (int d = 0; d < dim; d++) {
+      wq[q] *= t.wv[qi[d]];
+      xq[static_cast<size_t>(q) * dim + d] = t.xv[qi[d]];
+    }
+    for (int j = 0; j < npe; j++) {
+      int ji[3] = {j % n1, (j / n1) % n1, j / (n1 * n1)};
+      double v = 1.0;
+      for (int d = 0; d < dim; d++) v *= t.Bv[qi[d] * n1 + ji[d]];
+      Phi[static_cast<size_t>(q) * npe + j] = v;
+    }
+  }
+  std::vector<double> out(static_cast<size_t>(ne) * npe * npe);
+  auto work = [&](int e_begin, int e_end) {
+    std::vector<double> M(static_cast<size_t>(npe) * npe), Wp(static_cast<size_t>(nq) * npe), L(static_cast<size_t>(npe) * npe);
+    for (int e = e_begin; e < e_end; e++) {
+      const double *V = &verts[static_cast<size_t>(e) * nv * dim];
+      for (int q = 0; q < nq; q++) {  // det J at the point (multilinear map of the 2^dim corners)
+        const double *xi = &xq[static_cast<size_t>(q) * dim];
+        double J[9] = {0};
+        for (int c = 0; c < nv; c++) {
+          for (int m2 = 0; m2 < dim; m2++) {
+            double g = 1.0;  // d/dxi_m2 of the corner's shape function
+            for (int d = 0; d < dim; d++) {
+              const int bit = (c >> d) & 1;
+              if (d == m2)
+                g *= bit ? 1.0 : -1.0;
+              else
+                g *= bit ? xi[d] : 1.0 - xi[d];
+            }
+            for (int i = 0; i < dim; i++) J[i + m2 * dim] += g * V[c * dim + i];
+          }
+        }
+        const double det = (dim == 2) ? J[0] * J[3] - J[2] * J[1]
+                                      : J[0] * (J[4] * J[8] - J[7] * J[5]) - J[3] * (J[1] * J[8] - J[7] * J[2]) +
+                                            J[6] * (J[1] * J[5] - J[4] * J[2]);
+        const double wd = wq[q] * det;
+        for (int j = 0; j < npe; j++) Wp[static_cast<size_t>(q) * npe + j] = wd * Phi[static_cast<size_t>(q) * npe + j];
+      }
+      std::fill(M.begin(), M.end(), 0.0);
+      for (int q = 0; q < nq; q++)
+        for (int j = 0; j < npe; j++) {
+          const double pj = Phi[static_cast<size_t>(q) * npe + j];
+          const double *wrow = &Wp[static_cast<size_t>(q) * npe];
+          double *mrow = &M[static_cast<size_t>(j) * npe];
+          for (int k = 0; k < npe; k++) mrow[k] += pj * wrow[k];
+        }
+      // Cholesky M = L L^T, then M^-1 = L^-T L^-1
+      std::fill(L.begin(), L.end(), 0.0);
+      for (int j = 0; j < npe; j++) {
+        double d = M[static_cast<size_t>(j) * npe + j];
+        for (int k = 0; k < j; k++) d -= L[static_cast<size_t>(j) * npe + k] * L[static_cast<size_t>(j) * npe + k];
+        if (!(d > 0.0)) throw std::runtime_error("element mass matrix is not positive definite (inverted element?)");
+        const double ljj = std::sqrt(d);
+        L[static_cast<size_t>(j) * npe + j] = ljj;
+        for (int i = j + 1; i < npe; i++) {
+          double v = M[static_cast<size_t>(i) * npe + j];
+          for (int k = 0; k < j; k++) v -= L[static_cast<size_t>(i) * npe + k] * L[static_cast<size_t>(j) * npe + k];
+          L[static_cast<size_t>(i) * npe + j] = v / ljj;
+        }
+      }
+      // Linv (lower) in M's storage
+      std::fill(M.begin(), M.end(), 0.0);
+      for (int j = 0; j < npe; j++) {
+        M[static_cast<size_t>(j) * npe + j] = 1.0 / L[static_cast<size_t>(j) * npe + j];
+        for (int i = j + 1; i < npe; i++) {
+          double v = 0.0;
+          for (int k = j; k < i; k++) v -= L[static_cast<size_t>(i) * npe + k] * M[static_cast<size_t>(k) * npe + j];
+          M[static_cast<size_t>(i) * npe + j] = v / L[static_cast<size_t>(i) * npe + i];
+        }
+      }
+      double *o = &out[static_cast<size_t>(e) * npe * npe];
+      for (int i = 0; i < npe; i++)
+        for (int j = 0; j <= i; j++) {
+          double v = 0.0;
+          for (int k = i; k < npe; k++) v += M[static_cast<size_t>(k) * npe + i] * M[static_cast<size_t>(k) * npe + j];
+          o[static_cast<size_t>(i) * npe + j] = o[static_cast<size_t>(j) * npe + i] = v;
+        }
+    }
+  };
+  const int nthreads = std::max(1, std::min<int>(static_cast<int>(std::thread::hardware_concurrency()), std::min(32, ne / 64 + 1)));
+  std::vector<std::thread> pool;
+  std::vector<std::exception_ptr> errs(nthreads);
+  for (int t2 = 0; t2 < nthreads; t2++) {
+    const int b = static_cast<int>(static_cast<int64_t>(ne) * t2 / nthreads), en = static_cast<int>(static_cast<int64_t>(ne) * (t2 + 1) / nthreads);
+    pool.emplace_back([&, b, en, t2] {
+      try {
+        work(b, en);
+      } catch (...) {
+        errs[t2] = std::current_exception();
+      }
+    });
+  }
+  for (auto &th : pool) th.join();
+  for (auto &e : errs)
+    if (e) std::rethrow_exception(e);
+  return out;
+}
+
 void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc, const tpsrhs_physics *phys,
            int num_bcs, const tpsrhs_bc *bcs, const tpsrhs_runtime *rt) {
-  if (disc->basis_type != TPSRHS_BASIS_GAUSS_LEGENDRE || disc->int_rule_type != 0)
-    throw Unsupported(
-        "only the collocated Gauss-Legendre basis + Gauss-Legendre rule (basisType 0, integrationRule 0) is built");
+  // basisType / integrationRule (src/M2ulPhyS.cpp:557-572): the collocated Gauss-Legendre pair (0, 0) of the
+  // cylinder / wedge / torch inputs, or the Gauss-Lobatto pair (1, 1), the reference's defaults (:2671-2672)
+  if (disc->basis_type == TPSRHS_BASIS_GAUSS_LEGENDRE && disc->int_rule_type == 0)
+    op->nc = 0;
+  else if (disc->basis_type == TPSRHS_BASIS_GAUSS_LOBATTO && disc->int_rule_type == 1)
+    op->nc = 1;
+  else
+    throw Unsupported("basisType / integrationRule: built pairs are (0, 0) Gauss-Legendre and (1, 1) Gauss-Lobatto");
+  if (op->nc && disc->axisymmetric) throw Unsupported("the Gauss-Lobatto pair is built for the planar 2-D and the 3-D formulation");
   const bool plasma = phys->working_fluid == TPSRHS_USER_DEFINED;
   if (disc->axisymmetric && mesh->dim != 2) throw std::invalid_argument("the axisymmetric formulation needs a 2-D mesh");
   if (phys->working_fluid != TPSRHS_DRY_AIR && !plasma) throw Unsupported("WorkingFluid::LTE_FLUID is out of scope");
@@ -256,7 +374,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   if (tp.num_shared > 0 && !op->halo) throw std::invalid_argument("mesh has shared faces but runtime.halo is NULL");
   op->ne = tp.ne;
   op->nfaces = tp.nfaces;
-  const int n1 = op->order + 1, q1 = ((op->dim - 1) + 2 * op->order) / 2 + 1;
+  const int n1 = op->order + 1, q1 = rule_points(op->nc, (op->dim - 1) + 2 * op->order);
   op->nf = (op->dim == 3) ? n1 * n1 : n1;
   op->nq = (op->dim == 3) ? q1 * q1 : q1;
   const int npe = (op->dim == 3) ? n1 * n1 * n1 : n1 * n1;
@@ -317,6 +435,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   }
 
   op->d_verts = dev_upload(tp.verts);
+  if (op->nc) op->d_minv = dev_upload(inverse_mass_matrices(tp.verts, op->dim, op->order, op->ne));
   {
     std::vector<int2> fi(tp.face_nbr.size());
     for (size_t i = 0; i < fi.size(); i++) fi[i] = make_int2(tp.face_nbr[i], tp.face_orient[i]);

@@ -205,13 +205,17 @@ class RHSoperator:
             pass
 
 
-def node_coordinates(host_mesh, order: int) -> np.ndarray:
+def node_coordinates(host_mesh, order: int, basis_type: int = 0) -> np.ndarray:
     """Physical coordinates of the DG nodes, ``(dim, NDofs)``: the role of
-    ``mesh->GetNodes(*coordsDof)`` (``src/rhs_operator.cpp:139-142``) for a GL nodal basis on
-    order-1 geometry.  Host-side input generation only."""
+    ``mesh->GetNodes(*coordsDof)`` (``src/rhs_operator.cpp:139-142``) for a Gauss-Legendre (``basis_type`` 0) or
+    Gauss-Lobatto (1) nodal basis on order-1 geometry.  Host-side input generation only."""
     dim = host_mesh.dim
     n1 = order + 1
-    x, _ = np.polynomial.legendre.leggauss(n1)
+    if basis_type == 0:
+        x, _ = np.polynomial.legendre.leggauss(n1)
+    else:  # end points and the roots of P'_{n1-1}
+        inner = np.polynomial.legendre.Legendre.basis(n1 - 1).deriv().roots() if n1 > 2 else np.array([])
+        x = np.concatenate([[-1.0], np.sort(inner.real), [1.0]])
     x = 0.5 * (x + 1.0)
     ex = host_mesh.elem_coords  # (ne, 2^dim, dim), MFEM order
     if dim == 3:
