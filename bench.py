@@ -17,9 +17,14 @@ configs[1]/[2] per GPU.  Workloads:
   torch6          the mixture of the reference's torch input (plasma.ini): six species, two temperatures, not
                   ambipolar, 11 equations, on the axisymmetric 400x500 mesh of cfg5
 At N = 1 the JSON line also carries the workloads that were not selected, under `other_workloads`.
-N > 1 (launched by ``torch.distributed.run``, one rank per GPU): every rank owns one such block --
-spanwise slabs of an N-times longer cylinder -- and exchanges the traces of its two shared planes
-with RCCL send/recv (weak scaling, no collective on the data path).
+  cfg4            configs[3]: perfect-gas Navier-Stokes, p=3, on the 56x224x32 = 401 408-hex cylinder, cut into
+                  N spanwise slabs (STRONG scaling: the total work is fixed)
+N > 1 (launched by ``torch.distributed.run``, one rank per GPU): every rank owns one block -- spanwise slabs of an
+N-times longer cylinder (weak scaling; cfg4: slabs of the same cylinder, strong scaling) -- and exchanges the
+traces of its two shared planes with its neighbours through the native RCCL library (libtpsrhs_rccl.so:
+ncclSend/ncclRecv groups on the operator's communication stream, no collective on the data path, no Python in the
+exchange).  ``--backend gloo --share-gpu`` rehearses the same launches on a one-GPU box through the Python hook
+(traces staged via host); the line then says so.  A failing exchange ends the run with a non-zero exit code.
 
 Prints ONE JSON line (rank 0).  ``value`` = DOFs of x processed per second by the whole job / 1e6.
 """
@@ -56,11 +61,12 @@ def workload(name):
     """-> order, physics, bcs(physics), state(X, physics), description, sample-case builder"""
     from tps_amd import capi, cases
 
-    if name == "cfg2":
+    if name in ("cfg2", "cfg4"):
         return (3, capi.dry_air_physics(capi.NS), lambda ph: cases.cylinder_bcs(capi.VISC_ISOTH, 300.0),
                 lambda X, ph: cases.dry_air_state(X, seed=12345),
                 "perfect-gas Navier-Stokes (dry air, Sutherland), inlet SUB_DENS_VEL / outlet SUB_P / isothermal "
-                "wall (BASELINE.json configs[1])",
+                "wall (BASELINE.json " + ("configs[1])" if name == "cfg2" else
+                                          "configs[3]: 56x224x32 = 401 408 hexes in all, spanwise slabs)"),
                 lambda order: cases.cyl3d(7, 28, 4, order, capi.NS, capi.VISC_ISOTH))
     if name in ("argon_p3", "cfg3"):
         order = 3 if name == "argon_p3" else 2
@@ -139,7 +145,7 @@ def main():
     ap.add_argument("--ntheta", type=int, default=112)
     ap.add_argument("--nz", type=int, default=16)
     ap.add_argument("--order", type=int, default=0, help="override the workload's polynomial order")
-    ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3", "cfg5", "torch6"])
+    ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3", "cfg4", "cfg5", "torch6"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the multi-rank path on a one-GPU box (traces staged via host)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses device 0")
@@ -169,13 +175,14 @@ def main():
     halo = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        fallback = None
         if args.backend == "nccl":
+            from tps_amd.halo_rccl import RcclHalo
+
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            fallback = dist.new_group(backend="gloo")  # only used if the first RCCL exchange raises
+            halo = RcclHalo(local_rank)  # C function pointers into libtpsrhs_rccl.so; no fallback
         else:
             dist.init_process_group("gloo")
-        halo = HaloExchange(device=torch.device("cuda", local_rank), fallback_group=fallback)
+            halo = HaloExchange(device=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
@@ -186,8 +193,13 @@ def main():
         order, physics, make_bcs, make_state, description, sample_case = workload(wname)
         order = args.order or order
         axisym = wname in ("cfg5", "torch6")
+        strong = wname == "cfg4"
         if axisym:  # (r, z) tube 0.05 x 0.25 per rank, 400 x 500 quads; axial slabs at N > 1 (weak scaling)
             mesh = meshgen.annulus_quad_slab(400, 500, rank, world, r_in=0.0, r_out=0.05, length_local=0.25)
+        elif strong:  # the 56x224x32 cylinder of configs[3] in `world` spanwise slabs
+            if 32 % world:
+                raise SystemExit("cfg4: the 32 spanwise layers must divide by the number of ranks")
+            mesh = meshgen.ogrid_cylinder_slab(56, 224, 32 // world, rank, world, span_local=4.0 / world)
         else:
             mesh = meshgen.ogrid_cylinder_slab(args.nr, args.ntheta, args.nz, rank, world)
         disc = capi.Disc(order, 0, 0, 1 if axisym else 0, 0)
@@ -252,6 +264,16 @@ def main():
             t_loop = time.perf_counter() - t1
             rk4 = {"rk4_steps_per_s": nst / t_loop, "ms_per_rk4_step": 1e3 * t_loop / nst, "steps": nst,
                    "nan_entries": int(bad), "mult_per_step": 4}
+        comm = None
+        if world > 1:
+            if hasattr(halo, "stats"):
+                st = halo.stats()
+                calls, sent, peers = st["halo_calls"], st["bytes_sent"], st["peers_seen"]
+            else:
+                calls, sent, peers = halo.calls, halo.bytes_sent, len({(rank - 1) % world, (rank + 1) % world})
+            comm = {"backend_used": halo.backend if hasattr(halo, "stats") else f"{halo.backend} (Python hook, staged through host)",
+                    "ranks_seen": peers, "halo_calls": calls,
+                    "halo_bytes_per_mult": 2.0 * sent / max(calls, 1)}  # two exchanges (TA, TB) per Mult
         op.close()
         del x, y
         if rank != 0:
@@ -281,11 +303,14 @@ def main():
                     "valu_insts_per_launch": valu_insts}
         res = {
             "value": value, "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
-            "config": {"workload": (f"{wname}: " + ("" if axisym else f"cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} "
-                                                            "hexes per GPU, ") +
+            "config": {"workload": (f"{wname}: " + ("" if axisym else
+                                                    (f"cyl3d O-grid 56x224x{32 // world} hexes per GPU, " if strong else
+                                                     f"cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} hexes per GPU, ")) +
                                     f"p={order}, GL basis + GL rule, {description}"),
                        "elements_per_gpu": mesh.num_elements, "nodes_per_gpu": ndofs, "num_equation": neq,
-                       "partition": "spanwise slabs, RCCL send/recv of face traces" if world > 1 else "single GPU"},
+                       "partition": (f"{world} spanwise slabs; face traces of the shared planes exchanged by "
+                                     f"{comm['backend_used']}") if world > 1 else "single GPU"},
+            "scaling": "strong" if strong else "weak", "comm": comm,
             "rhs_evals_per_s": evals_per_s, "mnodes_per_s": world * ndofs * evals_per_s / 1e6, "kernel_ms": ktimes,
             "ms_per_mult_median_events": mult_ms[len(mult_ms) // 2] if mult_ms else None,
             "finite": finite, "time_loop": rk4, "comm_exposed_ms": comm_exposed_ms, "roofline_valu": valu,
@@ -312,7 +337,7 @@ def main():
         out = {
             "metric": "DG RHS evals/sec (MDOF/s) for 3D p=3 reacting cyl at 1/2/4/8 MI355X",
             "value": res["value"], "unit": "MDOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": res["scaling"], "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "config": res["config"],
             "rhs_evals_per_s": res["rhs_evals_per_s"], "mnodes_per_s": res["mnodes_per_s"], "kernel_ms": res["kernel_ms"],
             "finite": res["finite"],
@@ -323,6 +348,8 @@ def main():
             out["roofline_valu"] = res["roofline_valu"]
         if res.get("time_loop"):
             out["time_loop"] = res["time_loop"]
+        if res.get("comm"):
+            out.update(res["comm"])  # backend_used, ranks_seen, halo_calls, halo_bytes_per_mult
         if res.get("comm_exposed_ms") is not None:
             out["comm_exposed_ms"] = res["comm_exposed_ms"]  # ms_per_step minus the same launches without the exchange
         if others:

@@ -24,6 +24,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.tpsrhs_status_string(2) == b"TPSRHS_ERR_UNSUPPORTED"
 
 
+def test_rccl_library_exports_every_declared_symbol():
+    """libtpsrhs_rccl.so (the native RCCL implementation of the halo / reduce hooks) loads and exports what
+    include/tpsrhs_rccl.h declares; no communicator is created without GPUs"""
+    from tps_amd import halo_rccl
+
+    lib = halo_rccl.load()
+    hdr = open(os.path.join(ROOT, "include", "tpsrhs_rccl.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*(tpsrhs_rccl_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert declared == set(halo_rccl.EXPORTED_SYMBOLS), declared ^ set(halo_rccl.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    # the function pointers the operator receives have the C types of tpsrhs_halo_fn / tpsrhs_reduce_fn
+    assert C.cast(lib.tpsrhs_rccl_halo, C.c_void_p).value and C.cast(lib.tpsrhs_rccl_reduce, C.c_void_p).value
+
+
 def test_struct_sizes_match_header():
     """ctypes mirror vs sizeof() of the C structs (compiled on the fly with gcc)."""
     import subprocess

@@ -88,7 +88,12 @@ def _worker(rank, world, port, q, kind, backend="gloo"):
         npe = (order + 1) ** full.dim
         idx = (gel[:, None] * npe + np.arange(npe)[None, :]).ravel()
         U = Ug[:, idx]  # the rank's rows of ONE global field
-        halo = HaloExchange(device=torch.device("cuda", dev))
+        if backend == "nccl":  # the native library: C function pointers, ncclSend / ncclRecv groups
+            from tps_amd.halo_rccl import RcclHalo
+
+            halo = RcclHalo(dev)
+        else:
+            halo = HaloExchange(device=torch.device("cuda", dev))
         op = RHSoperator(part, disc, ph, bcs, device=dev, halo=halo)
         x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
         y = torch.empty_like(x)
@@ -126,9 +131,9 @@ def test_ranks_match_serial_oracle(world, kind):
 
 @pytest.mark.parametrize("world,kind", [(2, "slab"), (2, "dry_air_nr")])
 def test_ranks_match_serial_oracle_over_rccl(world, kind):
-    """The same on one GPU per rank with the nccl backend (RCCL send/recv of the traces straight from device
-    memory, all_reduce of the boundary means and of dt): needs as many GPUs as ranks, so it is skipped on the
-    one-GPU test boxes and runs wherever a multi-GPU node executes the suite."""
+    """The same on one GPU per rank through libtpsrhs_rccl.so (ncclSend / ncclRecv groups of the traces straight
+    from device memory, ncclAllReduce of the boundary means and of dt): needs as many GPUs as ranks, so it is
+    skipped on the one-GPU test boxes and runs wherever a multi-GPU node executes the suite."""
     import torch
 
     if torch.cuda.device_count() < world:
@@ -154,9 +159,23 @@ def _run_ranks(world, kind, backend):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, backend)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    res = []
+    try:  # a rank that fails leaves its peers blocked in the exchange: collect what arrives, then end them all
+        for _ in procs:
+            res.append(q.get(timeout=300))
+            if res[-1][1] != "ok":
+                break
+    finally:
+        for p in procs:
+            p.join(timeout=60 if len(res) == len(procs) and all(r[1] == "ok" for r in res) else 5)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+                p.join()
+    assert len(res) == len(procs), "a rank ended without reporting"
     y = np.zeros_like(Ug)
     g = np.zeros_like(ref["gradUp"])
     mcs = 0.0

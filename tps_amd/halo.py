@@ -28,10 +28,8 @@ class _DevPtr:
 
 
 class HaloExchange:
-    def __init__(self, group=None, device=None, host_buffers=False, fallback_group=None):
+    def __init__(self, group=None, device=None, host_buffers=False):
         self.group = group
-        self.fallback_group = fallback_group  # a gloo group: used (staged through host) if the first exchange on
-        #                                       the primary backend raises, so a run degrades instead of dying
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         self.device = device
         self.host_buffers = host_buffers  # True: pointers handed to callback are HOST memory (CPU rehearsal)
@@ -53,23 +51,11 @@ class HaloExchange:
         if self.skip:
             return 0
         try:
+            # a failing exchange is an error (TPSRHS_ERR_HALO), never a silent change of transport: the ranks of a
+            # job cannot switch backends one by one, and a degraded run must not be reported as an RCCL number
             if not self.host_buffers and torch.cuda.is_available():
                 with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0), device=self.device)):
-                    try:
-                        return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
-                    except Exception:
-                        if self.fallback_group is None or self.calls > 0:
-                            raise
-                        import sys
-                        import traceback
-
-                        traceback.print_exc()
-                        print("tps_amd.halo: primary backend failed on its first exchange; staging through the "
-                              "fallback (gloo) group from now on", file=sys.stderr)
-                        self.group, self.fallback_group = self.fallback_group, None
-                        self.backend = dist.get_backend(self.group)
-                        self._plans.clear()
-                        return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
+                    return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
             return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
         except Exception as exc:  # never let an exception cross the C boundary
             import traceback

@@ -48,7 +48,10 @@ class RHSoperator:
         self._stream = st
         rt.stream = C.c_void_p(st.cuda_stream)
         self._halo = halo
-        if halo is not None:
+        if halo is not None and hasattr(halo, "c_halo"):  # native exchange (tps_amd.halo_rccl): C function pointers
+            rt.halo, rt.halo_ctx = halo.c_halo, halo.ctx
+            rt.reduce, rt.reduce_ctx = halo.c_reduce, halo.ctx
+        elif halo is not None:  # Python hook (tps_amd.halo): gloo rehearsals and tests
             self._halo_cb = capi.HALO_FN(halo.callback)
             rt.halo = self._halo_cb
             if hasattr(halo, "reduce_callback"):
