@@ -1,0 +1,81 @@
+"""The C++ side of the boundary: include/tpsrhs_mfem_adapter.hpp (class RHSoperatorHIP : mfem::TimeDependentOperator,
+the adapter a TPS maintainer adds next to src/rhs_operator.hpp:59) is COMPILED here -- against tests/mock_mfem/mfem.hpp,
+a labelled stand-in for the MFEM classes it touches (no MFEM in this image) -- linked with libtpsrhs.so and run the
+way utils/compute_rhs.cpp:60-102 runs the reference's operator: construct, one ``Mult(const Vector&, Vector&)``.
+
+Without a GPU the library must fail loudly through the C++ layer (TPSRHS_ERR_NO_DEVICE as an exception); on the GPU
+box the residual the C++ caller gets is compared with the oracle."""
+import os
+import shutil
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tps_amd import capi, cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "tps_amd", "csrc")
+
+
+def build_driver(tmp_path):
+    exe = str(tmp_path / "adapter_driver")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "tests", "mock_mfem"), os.path.join(ROOT, "tests", "adapter_driver.cpp"), "-o", exe,
+           "-L" + CSRC, "-ltpsrhs", "-Wl,-rpath," + CSRC]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def write_case(path, c, U, order):
+    m = c.mesh
+    ev = np.ascontiguousarray(m.elem_vertices, dtype=np.int32)
+    ex = np.ascontiguousarray(m.elem_coords, dtype=np.float64)
+    bv = np.ascontiguousarray(m.bdr_vertices, dtype=np.int32)
+    ba = np.ascontiguousarray(m.bdr_attributes, dtype=np.int32)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<6i", m.dim, m.num_vertices, m.num_elements, len(ba), U.shape[0], order))
+        for a in (ev, ex, bv, ba, np.ascontiguousarray(U, dtype=np.float64)):
+            f.write(a.tobytes())
+
+
+def make_case():
+    order = 2
+    c = cases.cyl3d(4, 12, 3, order, capi.NS, capi.VISC_ISOTH)
+    c.physics.dry_air.visc_mult = 2000.0  # the driver's dry-air block
+    return c, c.state(seed=31), order
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_adapter_compiles_links_and_fails_loudly_without_a_device(tmp_path):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    exe = build_driver(tmp_path)
+    c, U, order = make_case()
+    write_case(tmp_path / "case.bin", c, U, order)
+    r = subprocess.run([exe, str(tmp_path / "case.bin"), str(tmp_path / "y.bin")], capture_output=True, text=True)
+    assert r.returncode == 3, (r.returncode, r.stderr)  # TPSRHS_ERR_NO_DEVICE came up through the C++ exception
+    assert "no HIP device" in r.stderr and not os.path.exists(tmp_path / "y.bin")
+
+
+@pytest.mark.gpu
+def test_adapter_mult_from_cpp_matches_oracle(tmp_path):
+    from parity_util import RHS_RTOL, oracle_mult, rel_maxnorm
+
+    exe = build_driver(tmp_path)
+    c, U, order = make_case()
+    write_case(tmp_path / "case.bin", c, U, order)
+    r = subprocess.run([exe, str(tmp_path / "case.bin"), str(tmp_path / "y.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(tmp_path / "y.bin", dtype=np.float64)
+    mcs, y = raw[0], raw[1:].reshape(U.shape)
+    ref = oracle_mult(c.mesh, c.disc, c.physics, c.bcs, U)
+    err = rel_maxnorm(y, ref["y"])
+    print("C++ caller vs oracle:", err, file=sys.stderr)
+    assert err.max() < RHS_RTOL
+    assert abs(mcs - ref["max_char_speed"]) < 1e-12 * mcs
