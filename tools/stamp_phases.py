@@ -37,6 +37,9 @@ torch.cuda.synchronize()
 assert lib.tpsrhs_debug_stamps(buf.ctypes.data_as(C.c_void_p), nblocks) == 0
 names = ["tables+vertices", "loads+prim", "volume gradient", "jump phase", "gradUp store", "visc: state interp",
          "visc: closure (coeffs)", "visc: gradient interp", "visc: flux + TB store"]
+if os.environ.get("STAMP_KERNEL") == "flux":  # built with -DTPSRHS_STAMP=2
+    names = ["tables+vertices", "loads of U, gradUp -> LDS", "nodal physics (closure, flux, source)", "volume term",
+             "face term, direction 0", "face term, direction 1", "face term, direction 2", "store y"]
 mean = buf.astype(np.float64).mean(axis=0)
 tot = mean.sum()
 for i, nm in enumerate(names):

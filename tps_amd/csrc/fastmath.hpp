@@ -57,6 +57,9 @@ constexpr double kLn2Lo = 1.9082149292705877e-10;
 
 // exp(x).  x = k ln2 + r, |r| <= ln2/2; degree-11 polynomial; 2^k by v_ldexp_f64 (which rounds into the
 // denormal range and saturates to 0 / inf by itself).
+// CHECKED = false: for arguments known to be finite and of moderate size (|x| < 1000, e.g. a small multiple of the
+// logarithm of a finite positive number); 0 / inf saturation is left to v_ldexp_f64, a NaN still comes out as a NaN.
+template <bool CHECKED = true>
 __device__ inline double fexp(double x) {
   const double k = __builtin_rint(x * fm::kLog2e);
   double r = fma(k, -fm::kLn2Hi, x);
@@ -74,6 +77,7 @@ __device__ inline double fexp(double x) {
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
   double e = __builtin_amdgcn_ldexp(p, static_cast<int>(k));
+  if (!CHECKED) return e;
   // beyond +-1000 (the reduction above is exact far past that) the result is 0 or inf anyway; a NaN
   // fails the comparison and falls through as the NaN the polynomial made of it
   if (!(fabs(x) < 1000.0)) e = (x < 0.0) ? 0.0 : x * __builtin_inf();

@@ -76,6 +76,8 @@ struct Stamper {
       for (int i = 0; i < NSTAMP; i++) g_stamp[blockIdx.x][i] = acc[i];
   }
 };
+#endif
+#if TPSRHS_STAMP == 1  // k_gradient
 #define STAMP_DECL Stamper stamper
 #define STAMP_ARG , stamper
 #define STAMP_PARAM , Stamper &stamper
@@ -89,6 +91,17 @@ struct Stamper {
 #define STAMP_START()
 #define STAMP(phase)
 #define STAMP_FLUSH()
+#endif
+#if TPSRHS_STAMP == 2  // k_flux
+#define FSTAMP_DECL \
+  Stamper stamper;  \
+  stamper.start()
+#define FSTAMP(phase) stamper.mark(phase)
+#define FSTAMP_FLUSH() stamper.flush()
+#else
+#define FSTAMP_DECL
+#define FSTAMP(phase)
+#define FSTAMP_FLUSH()
 #endif
 
 // 1-D operator tables of every (dim, order), filled by tpsrhs_create.  Identical for all operators of
@@ -1424,6 +1437,16 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
   __shared__ int2 sFI[C::EPB * C::NFACES];
   STAMP_DECL;
   STAMP_START();
+  const bool node_on = tid < C::NODES && (e0 + tid / C::NPE) < m.ne;
+  const int le_n = tid / C::NPE, nd = tid - le_n * C::NPE;
+  int idx[3] = {nd % C::N1, (nd / C::N1) % C::N1, nd / (C::N1 * C::N1)};
+  // the state goes out first: its latency overlaps that of the tables, vertices and face records
+  double u[NEQ];
+  if (node_on) {
+    const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) u[eq] = field_ptr(U, eq, m.ndofs)[n];
+  }
   load_face_info<C>(sFI, m, e0);
   load_tables<C>(tab, ct);
   load_vertices<C>(sV, m, e0);
@@ -1434,14 +1457,9 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m,
   issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta0, tid);
   issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta1, tid);
   if (DIM == 3) issue_neighbour_traces<C, (DIM == 3 ? 2 : 0), NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta2, tid);
-  const bool node_on = tid < C::NODES && (e0 + tid / C::NPE) < m.ne;
-  const int le_n = tid / C::NPE, nd = tid - le_n * C::NPE;
-  int idx[3] = {nd % C::N1, (nd / C::N1) % C::N1, nd / (C::N1 * C::N1)};
   if (node_on) {
     const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
-    double u[NEQ], up[NEQ];
-#pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) u[eq] = field_ptr(U, eq, m.ndofs)[n];
+    double up[NEQ];
     PH::prim(prm, u, up);
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) {
@@ -2083,29 +2101,35 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
   const int bid = m.blocks ? m.blocks[blockIdx.x] : static_cast<int>(blockIdx.x);
   const int e0 = bid * C::EPB;
   __shared__ int2 sFI[C::EPB * C::NFACES];
-  load_face_info<C>(sFI, m, e0);
-  load_tables<C>(tab, ct);
-  load_vertices<C>(sV, m, e0);
-  block_sync<C::BLOCK>();
-  NbTraces<C, NEQ> ta0;
-  NbFlux<C, NEQ> tb0;
-  issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta0, tid);
-  if (!L::BOTH_2D) issue_visc_traces<C, 0, NEQ>(sFI, e0, TB, tb0, tid);
+  FSTAMP_DECL;
   const bool node_on = tid < C::NODES && (e0 + tid / C::NPE) < m.ne;
   const int le_n = tid / C::NPE, nd = tid - le_n * C::NPE;
   int idx[3] = {nd % C::N1, (nd / C::N1) % C::N1, nd / (C::N1 * C::N1)};
+  // the nodal loads go out first: their latency (a full trip to HBM under load) then overlaps that of the
+  // tables, vertices and face records instead of following it
   double u[NEQ], gr[NEQ * DIM];
   if (node_on) {
     const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) {
-      u[eq] = field_ptr(U, eq, m.ndofs)[n];
-      sU[eq * C::NODES + tid] = u[eq];
-    }
+    for (int eq = 0; eq < NEQ; eq++) u[eq] = field_ptr(U, eq, m.ndofs)[n];
 #pragma unroll
     for (int k = 0; k < NEQ * DIM; k++) gr[k] = field_ptr(gradUp, k, m.ndofs)[n];
   }
+  load_face_info<C>(sFI, m, e0);
+  load_tables<C>(tab, ct);
+  load_vertices<C>(sV, m, e0);
+  block_sync<C::BLOCK>();
+  FSTAMP(0);
+  NbTraces<C, NEQ> ta0;
+  NbFlux<C, NEQ> tb0;
+  issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta0, tid);
+  if (!L::BOTH_2D) issue_visc_traces<C, 0, NEQ>(sFI, e0, TB, tb0, tid);
+  if (node_on) {
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) sU[eq * C::NODES + tid] = u[eq];
+  }
   block_sync<C::BLOCK>();  // tables + vertices + sU
+  FSTAMP(1);
 
   // ---- nodal flux F_c - F_v (src/rhs_operator.cpp:493-559), contravariant components.
   // Ordered to keep the register peak low: physics first (U, gradUp -> 15 flux entries), then the
@@ -2206,6 +2230,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
     }
   }
   block_sync<C::BLOCK>();  // sGf complete
+  FSTAMP(2);
 
   // ---- volume term: z_j = sum_m sum_a D[a][j_m] Ghat_m(a)   (src/domain_integrator.cpp:45-99)
   double z[NEQ];
@@ -2235,6 +2260,7 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
     }
   }
   block_sync<C::BLOCK>();  // sGf dead: its region becomes X | Y
+  FSTAMP(3);
 
   // ---- face term
   if constexpr (L::BOTH_2D) {
@@ -2252,14 +2278,17 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
     issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta1, tid);
     issue_visc_traces<C, 1, NEQ>(sFI, e0, TB, tb1, tid);
     face_flux_dir<C, PH, 0>(m, prm, e0, sU, sX, sY, sV, tab, ct, ta0, tb0, node_on, le_n, idx, z, tid);
+    FSTAMP(4);
     if (DIM == 3) {
       issue_neighbour_traces<C, (DIM == 3 ? 2 : 0), NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta2, tid);
       issue_visc_traces<C, (DIM == 3 ? 2 : 0), NEQ>(sFI, e0, TB, tb2, tid);
     }
     face_flux_dir<C, PH, 1>(m, prm, e0, sU, sX, sY, sV, tab, ct, ta1, tb1, node_on, le_n, idx, z, tid);
+    FSTAMP(5);
     if (DIM == 3)
       face_flux_dir<C, PH, (DIM == 3 ? 2 : 0)>(m, prm, e0, sU, sX, sY, sV, tab, ct, ta2, tb2, node_on, le_n, idx, z,
                                                 tid);
+    FSTAMP(6);
   }
 
   if constexpr (C::NC) {  // y = Me^-1 z (src/rhs_operator.cpp:432-448), then the point sources
@@ -2271,6 +2300,8 @@ __global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typ
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) field_ptr(Y, eq, m.ndofs)[n] = inv_mass * z[eq] + src[eq];
   }
+  FSTAMP(7);
+  FSTAMP_FLUSH();
 }
 
 // Point-wise closures of the gas model for n states U[eq + ...]: U is [NEQ][n] (byNODES), one lane per state

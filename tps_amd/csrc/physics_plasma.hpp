@@ -119,8 +119,12 @@ __device__ inline Arg arg(double Tp) {
   return a;
 }
 __device__ inline double cfit(double c0, double c1, double c2, double c3, const Arg &a) {
-  // 1 + c1 Tp^c2 >= 1: the inner logarithm needs no special cases (a NaN passes through)
-  return c0 * fexp(c3 * flog(flog_pos(1.0 + c1 * fexp(c2 * a.ln)))) * a.inv2;
+  // 1 + c1 Tp^c2 >= 1: the inner logarithm needs no special cases (a NaN passes through); its value L is > 0
+  // unless Tp^c2 underflowed, where the fit is 0 (c3 > 0) -- so the outer logarithm needs none either.  The two
+  // exponents are small multiples of logarithms of finite positive numbers: the unchecked exponential.
+  const double L = flog_pos(1.0 + c1 * fexp<false>(c2 * a.ln));
+  const double v = c0 * fexp<false>(c3 * flog_pos(L)) * a.inv2;
+  return (L > 0.0) ? v : ((L == 0.0) ? 0.0 : v);
 }
 __device__ inline double att11(const Arg &a) { return cfit(0.2150, 5.2194, 1.0472, 1.2435, a); }
 __device__ inline double att12(const Arg &a) { return cfit(0.0991, 7.4684, 1.0155, 1.1536, a); }
