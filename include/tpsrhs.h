@@ -318,6 +318,13 @@ int tpsrhs_eval_pointwise(tpsrhs_handle h, int quantity, int64_t n, const double
  * for n abscissae (x, f: device pointers; the table itself is host data as in tpsrhs_chemistry).  Synchronous. */
 int tpsrhs_table_eval(const tpsrhs_table *table, int64_t n, const double *x, double *f);
 
+/* Diagnostic: the elementary functions the device closures are built on (tps_amd/csrc/fastmath.hpp; they replace
+ * the libm calls of the reference's point physics -- pow / exp / log of src/collision_integrals.cpp:53-201,
+ * src/reaction.cpp:41-83 -- and its divisions / sqrt), evaluated on the device for n arguments (device pointers,
+ * synchronous), so that their accuracy is a tested number: 0 exp, 1 exp without the range check, 2 log,
+ * 3 log of a positive finite argument, 4 reciprocal, 5 sqrt, 6 reciprocal sqrt. */
+int tpsrhs_math_eval(int function, int64_t n, const double *x, double *y);
+
 int64_t tpsrhs_height(tpsrhs_handle h);
 int64_t tpsrhs_num_dofs(tpsrhs_handle h);
 int tpsrhs_num_equation(tpsrhs_handle h);

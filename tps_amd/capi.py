@@ -530,6 +530,7 @@ def load():
     lib.tpsrhs_mult_times.argtypes = [vp, C.c_int, _dp]
     lib.tpsrhs_eval_pointwise.argtypes = [vp, C.c_int, C.c_int64, vp, vp]
     lib.tpsrhs_table_eval.argtypes = [C.POINTER(Table), C.c_int64, vp, vp]
+    lib.tpsrhs_math_eval.argtypes = [C.c_int, C.c_int64, vp, vp]
     lib.tpsrhs_kernel_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _dp]
     lib.tpsrhs_rk4_step.argtypes = [vp, C.c_void_p, _dp, C.c_double, _dp, C.POINTER(C.c_int64)]
     lib.tpsrhs_advance.argtypes = [vp, C.c_void_p, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double,
@@ -551,7 +552,7 @@ EXPORTED_SYMBOLS = [
     "tpsrhs_create", "tpsrhs_destroy", "tpsrhs_mult", "tpsrhs_mult_host", "tpsrhs_update_gradients",
     "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
     "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_mult_times", "tpsrhs_kernel_bytes",
-    "tpsrhs_eval_pointwise", "tpsrhs_table_eval", "tpsrhs_face_tables",
+    "tpsrhs_eval_pointwise", "tpsrhs_table_eval", "tpsrhs_math_eval", "tpsrhs_face_tables",
     "tpsrhs_rk4_step", "tpsrhs_advance", "tpsrhs_set_dt", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_status_string",
     "tpsrhs_last_error", "tpsrhs_version",
 ]

@@ -4,7 +4,7 @@
 // src/gas_transport.cpp:206-489) cost 16 pow() = 16 exp + 16 log per point in the reference.  The
 // device library's exp / log are 37 / 93 FP64 instructions (correctly rounded, every special case
 // through extended-precision paths); at 214 transport evaluations per p = 3 hex that is where the
-// reacting Mult spends its time.  The versions here are 23 / 30-36 instructions, accurate to < 2 ulp
+// reacting Mult spends its time.  The versions here are 23 / 30-36 instructions, accurate to < 2 ulp (exp) and < 4 ulp (log)
 // (tests/test_gpu_fastmath.py), keep IEEE semantics for the special values the physics can produce
 // (NaN propagates -- Check_NAN of the time loop depends on it --, log(0) = -inf, log(x < 0) = NaN,
 // exp(+-inf)), and have no branches, so that independent evaluations interleave.

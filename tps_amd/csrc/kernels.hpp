@@ -153,7 +153,10 @@ struct Cfg {
   static constexpr int NFACES = 2 * DIM_;
   static constexpr int NV = 1 << DIM_;
   static constexpr int BLOCK = (NPE <= 64) ? 64 : ((NPE <= 128) ? 128 : 256);
-  static constexpr int EPB = (DIM_ == 3 && P_ == 1) ? 4 : BLOCK / NPE;  // elements per block
+  // elements per block.  3-D p = 1: 3 elements = 54 face quadrature points per direction pair, one round of the
+  // 64 lanes (4 elements needed a second round for 8 points, and with 11 equations that instantiation kept
+  // 2 x 3 sets of prefetched traces live: 259 spilled VGPRs); the non-collocated pair has 16 points per face
+  static constexpr int EPB = (DIM_ == 3 && P_ == 1) ? (NC_ ? 4 : 3) : BLOCK / NPE;
   static constexpr int NODES = EPB * NPE;
   // one direction pair (faces 2d, 2d+1) of a block
   static constexpr int PF = 2 * EPB;
@@ -1416,7 +1419,7 @@ __device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const 
 }
 
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK, PH::MINW_GRAD) void k_gradient(MeshDev m, typename PH::Params prm,
+__global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::MINW_GRAD) void k_gradient(MeshDev m, typename PH::Params prm,
                                                        const double *__restrict__ U, const double *__restrict__ TA,
                                                        double *__restrict__ Upout, double *__restrict__ gradUp,
                                                        double *__restrict__ TB) {
@@ -2083,7 +2086,7 @@ __device__ inline void face_flux_2d(const MeshDev &m, const typename PH::Params 
 }
 
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK, PH::MINW_FLUX) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
+__global__ __launch_bounds__(C::BLOCK, (C::NC && PH::MINW_FLUX > 2) ? 2 : PH::MINW_FLUX) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
                                                    const double *__restrict__ gradUp, const double *__restrict__ TA,
                                                    const double *__restrict__ TB, double *__restrict__ Y,
                                                    double *__restrict__ block_speed) {

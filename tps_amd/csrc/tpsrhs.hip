@@ -50,6 +50,15 @@ TableDev upload_table(tpsrhs_operator *op, const tpsrhs_table &t) {
   td.x = d;
   td.a = d + N;
   td.b = d + 2 * N;
+  // uniformly spaced abscissae?  (the device then starts its interval search from the spacing)
+  td.x0 = x[0];
+  td.inv_dx = 0.0;
+  const double dx = (x[N - 1] - x[0]) / (N - 1);
+  if (dx > 0.0) {
+    bool uniform = true;
+    for (int k = 0; k < N && uniform; k++) uniform = std::fabs(x[k] - (x[0] + k * dx)) <= 0.25 * dx;
+    if (uniform) td.inv_dx = 1.0 / dx;
+  }
   return td;
 }
 
@@ -881,6 +890,38 @@ __global__ void k_table_eval(TableDev t, int64_t n, const double *__restrict__ x
   if (i < n) f[i] = table_eval(t, x[i]);
 }
 }  // namespace
+
+namespace {
+__global__ void k_math_eval(int fn, int64_t n, const double *__restrict__ x, double *__restrict__ y) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double v = x[i];
+  double r;
+  switch (fn) {
+    case 0: r = fexp(v); break;
+    case 1: r = fexp<false>(v); break;
+    case 2: r = flog(v); break;
+    case 3: r = flog_pos(v); break;
+    case 4: r = fast_rcp(v); break;
+    case 5: r = fast_sqrt(v); break;
+    default: r = fast_rsqrt(v); break;
+  }
+  y[i] = r;
+}
+}  // namespace
+
+int tpsrhs_math_eval(int function, int64_t n, const double *x, double *y) {
+  if (function < 0 || function > 6 || n < 0 || !x || !y) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "math_eval");
+  return guarded([&] {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device visible");
+    if (n > 0) {
+      hipLaunchKernelGGL(k_math_eval, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, function, n, x, y);
+      HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+  });
+}
 
 int tpsrhs_table_eval(const tpsrhs_table *table, int64_t n, const double *x, double *f) {
   if (!table || n < 0 || !x || !f) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "table_eval");
