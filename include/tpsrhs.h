@@ -120,6 +120,10 @@ typedef struct tpsrhs_mesh {
                                        ascending GLOBAL vertex id (identical physical order on both
                                        sides) */
   const int *shared_neighbor_rank;  /* [num_shared_faces] */
+  /* Optional: [num_elements] mfem::Mesh::GetElementSize(e, 1) (the smallest singular value of the Jacobian at the
+   * element centre), the grid scale of the sub-grid scale models (src/rhs_operator.cpp:154,
+   * src/face_integrator.cpp:253).  NULL: the library computes it from elem_coords. */
+  const double *elem_size;
 } tpsrhs_mesh;
 
 /* ---- discretisation: [flow] order/basisType/integrationRule (src/M2ulPhyS.cpp:557-579,2670) -- */
@@ -206,6 +210,22 @@ typedef struct tpsrhs_radiation { /* RadiationInput */
   tpsrhs_table nec_table;
 } tpsrhs_radiation;
 
+/* Fluxes: sub-grid scale model ([flow] sgsModel / sgsModelConstant / sgsFloor, src/M2ulPhyS.cpp:2689-2699,
+ * src/fluxes.cpp:513-665) and the planar viscous sponge ([viscosityMultiplierFunction], src/M2ulPhyS.cpp:2788-2808,
+ * src/fluxes.cpp:669-688).  Built for dry air, planar 2-D (sponge only: the reference's strain tensor indexes three
+ * directions) and 3-D, Gauss-Legendre pair; anything else: TPSRHS_ERR_UNSUPPORTED. */
+enum tpsrhs_sgs_model { TPSRHS_SGS_NONE = 0, TPSRHS_SGS_SMAGORINSKY = 1, TPSRHS_SGS_SIGMA = 2 };
+typedef struct tpsrhs_sgs {
+  int model_type;      /* tpsrhs_sgs_model */
+  double model_const;  /* 0: the reference's default, 0.12 (Smagorinsky) / 0.135 (sigma) */
+  double model_floor;  /* sgsFloor */
+} tpsrhs_sgs;
+typedef struct tpsrhs_visc_sponge { /* viscositySpongeData (src/M2ulPhyS.cpp:583-600) */
+  int enabled;
+  double normal[3], point[3]; /* used as given (not normalised), as the reference does */
+  double width, ratio;
+} tpsrhs_visc_sponge;
+
 typedef struct tpsrhs_physics {
   int eq_system;        /* tpsrhs_equations */
   int working_fluid;    /* tpsrhs_working_fluid */
@@ -216,6 +236,8 @@ typedef struct tpsrhs_physics {
   tpsrhs_gas_transport gas_transport;
   tpsrhs_chemistry chemistry;
   tpsrhs_radiation radiation;
+  tpsrhs_sgs sgs;
+  tpsrhs_visc_sponge visc_sponge;
 } tpsrhs_physics;
 
 /* ---- boundary conditions: [boundaryConditions/...] (src/M2ulPhyS.cpp:3480-3700) --------------- */
@@ -383,9 +405,16 @@ typedef struct tpsrhs_heat_source { /* heatSourceData, type "cylinder" (src/data
 } tpsrhs_heat_source;
 
 enum tpsrhs_sponge_type { TPSRHS_SPONGE_PLANAR = 0, TPSRHS_SPONGE_ANNULUS = 1 };  /* SpongeZoneType */
+enum tpsrhs_sponge_solution { TPSRHS_SPONGE_USERDEF = 0, TPSRHS_SPONGE_MIXEDOUT = 1 }; /* SpongeZoneSolution */
 
-typedef struct tpsrhs_sponge_zone { /* SpongeZoneData with szSolType USERDEF (src/dataStructures.hpp:260-287) */
+typedef struct tpsrhs_sponge_zone { /* SpongeZoneData (src/dataStructures.hpp:260-287) */
   int type;                          /* tpsrhs_sponge_type */
+  int solution_type;                 /* tpsrhs_sponge_solution.  MIXEDOUT (src/forcing_terms.cpp:713-743): at every
+                                      * Mult the target is the mixed-out state of the mean convective normal flux over
+                                      * the nodes within `tol` of the plane through point_init (planar zone) / of the
+                                      * cylinder of radius r1 (annulus), summed over the ranks with runtime.reduce;
+                                      * target_U is ignored.  Dry air, planar 2-D / 3-D; else TPSRHS_ERR_UNSUPPORTED */
+  double tol;                        /* MIXEDOUT: node search tolerance (spongezone/tolerance) */
   double normal[3], point0[3], point_init[3]; /* normal is normalised by the library (forcing_terms.cpp:528-532) */
   double r1, r2;                     /* annulus radii */
   double mult_factor;
@@ -400,7 +429,7 @@ typedef struct tpsrhs_forcing {
   double pressure_gradient[3];
   int num_heat_sources;              /* enabled HeatSource entries only */
   tpsrhs_heat_source heat_sources[TPSRHS_MAXHEATSOURCES];
-  int num_sponge_zones;              /* SpongeZone, USERDEF target (MIXEDOUT: TPSRHS_ERR_UNSUPPORTED) */
+  int num_sponge_zones;              /* SpongeZone */
   tpsrhs_sponge_zone sponge_zones[TPSRHS_MAXSPONGEZONES];
 } tpsrhs_forcing;
 

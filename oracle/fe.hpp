@@ -402,6 +402,44 @@ struct Mesh {
   }
 };
 
+// Smallest singular value of the dim x dim matrix J[i + m*dim] (the role of DenseMatrix::CalcSingularvalue(dim-1)
+// behind Mesh::GetElementSize(e, 1) [MFEM]): one-sided Jacobi (Hestenes) -- rotate column pairs until they are
+// orthogonal, the singular values are the column norms.
+inline double min_singular_value(int dim, const double *Jin) {
+  double A[9];
+  for (int k = 0; k < dim * dim; k++) A[k] = Jin[k];
+  for (int sweep = 0; sweep < 60; sweep++) {
+    bool rotated = false;
+    for (int p = 0; p < dim; p++)
+      for (int q = p + 1; q < dim; q++) {
+        double app = 0.0, aqq = 0.0, apq = 0.0;
+        for (int i = 0; i < dim; i++) {
+          app += A[i + p * dim] * A[i + p * dim];
+          aqq += A[i + q * dim] * A[i + q * dim];
+          apq += A[i + p * dim] * A[i + q * dim];
+        }
+        if (std::fabs(apq) <= 1e-17 * std::sqrt(app * aqq)) continue;
+        rotated = true;
+        const double zeta = (aqq - app) / (2.0 * apq);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+        for (int i = 0; i < dim; i++) {
+          const double vp = A[i + p * dim], vq = A[i + q * dim];
+          A[i + p * dim] = c * vp - sn * vq;
+          A[i + q * dim] = sn * vp + c * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  double smin = 1e300;
+  for (int p = 0; p < dim; p++) {
+    double n2 = 0.0;
+    for (int i = 0; i < dim; i++) n2 += A[i + p * dim] * A[i + p * dim];
+    smin = std::min(smin, std::sqrt(n2));
+  }
+  return smin;
+}
+
 inline double det_and_inverse(int dim, const double *J, double *Ji) {
   if (dim == 2) {
     const double det = J[0] * J[3] - J[2] * J[1];

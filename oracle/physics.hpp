@@ -313,10 +313,117 @@ class Fluxes {
   TransportProperties *transport;
   int eqSystem, dim, nvel, num_equation, numActiveSpecies;
   bool axisymmetric;
+  // sub-grid scale model and viscous sponge (src/fluxes.hpp:77-84); set by the operator from tpsrhs_physics
+  int sgs_model_type_ = 0;
+  double sgs_model_const_ = 0.0, sgs_model_floor_ = 0.0;
+  tpsrhs_visc_sponge vsd_{};
   Fluxes(GasMixture *m, int eqSys, TransportProperties *t, int neq, int dim_, bool axisym)
       : mixture(m), transport(t), eqSystem(eqSys), dim(dim_), num_equation(neq), axisymmetric(axisym) {
     nvel = m->nvel;
     numActiveSpecies = m->numActiveSpecies;
+  }
+
+  // src/fluxes.cpp:513-537
+  void sgsSmag(const double *state, const double *gradUp, double delta, double &mu) const {
+    double Sij[6];
+    double Smag = 0.;
+    const double Cd = sgs_model_const_;
+    Sij[0] = gradUp[1 + 0 * num_equation];
+    Sij[1] = gradUp[2 + 1 * num_equation];
+    Sij[2] = gradUp[3 + 2 * num_equation];
+    Sij[3] = 0.5 * (gradUp[1 + 1 * num_equation] + gradUp[2 + 0 * num_equation]);
+    Sij[4] = 0.5 * (gradUp[1 + 2 * num_equation] + gradUp[3 + 0 * num_equation]);
+    Sij[5] = 0.5 * (gradUp[2 + 2 * num_equation] + gradUp[3 + 1 * num_equation]);
+    for (int i = 0; i < 3; i++) Smag += Sij[i] * Sij[i];
+    for (int i = 3; i < 6; i++) Smag += 2.0 * Sij[i] * Sij[i];
+    Smag = std::sqrt(2.0 * Smag);
+    const double l_floor = sgs_model_floor_;
+    const double d_model = Cd * std::max(delta - l_floor, 0.0);
+    mu = state[0] * d_model * d_model * Smag;
+  }
+  // src/fluxes.cpp:543-665, the branch without LAPACK (the one the reference's device build runs)
+  void sgsSigma(const double *state, const double *gradUp, double delta, double &mu) const {
+    const double Cd = sgs_model_const_;
+    const double sml = 1.0e-12;
+    const double l_floor = sgs_model_floor_;
+    const double d_model = std::max((delta - l_floor), sml);
+    double Qij[3][3], B[3][3], ev[3], sigma[3];
+    const double pi = 3.14159265359;
+    const double onethird = 1. / 3.;
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) {
+        Qij[i][j] = 0;
+        for (int k = 0; k < dim; k++) Qij[i][j] += gradUp[k + 1 + i * num_equation] * gradUp[k + 1 + j * num_equation];
+      }
+    const double d4 = std::pow(d_model, 4);
+    for (int j = 0; j < dim; j++)
+      for (int i = 0; i < dim; i++) Qij[i][j] *= d4;
+    const double p1 = Qij[0][1] * Qij[0][1] + Qij[0][2] * Qij[0][2] + Qij[1][2] * Qij[1][2];
+    const double q = onethird * (Qij[0][0] + Qij[1][1] + Qij[2][2]);
+    const double p2 = (Qij[0][0] - q) * (Qij[0][0] - q) + (Qij[1][1] - q) * (Qij[1][1] - q) +
+                      (Qij[2][2] - q) * (Qij[2][2] - q) + 2.0 * p1;
+    const double p = std::sqrt(std::max(p2, 0.0) / 6.0);
+    for (int j = 0; j < dim; j++)
+      for (int i = 0; i < dim; i++) B[i][j] = Qij[i][j];
+    for (int i = 0; i < dim; i++) B[i][i] -= q;
+    for (int j = 0; j < dim; j++)
+      for (int i = 0; i < dim; i++) B[i][j] *= (1.0 / std::max(p, sml));
+    const double detB = B[0][0] * (B[1][1] * B[2][2] - B[2][1] * B[1][2]) -
+                        B[0][1] * (B[1][0] * B[2][2] - B[2][0] * B[1][2]) +
+                        B[0][2] * (B[1][0] * B[2][1] - B[2][0] * B[1][1]);
+    const double r = 0.5 * detB;
+    double phi;
+    if (r <= -1.0) {
+      phi = onethird * pi;
+    } else if (r >= 1.0) {
+      phi = 0.0;
+    } else {
+      phi = onethird * std::acos(r);
+    }
+    ev[0] = q + 2.0 * p * std::cos(phi);
+    ev[2] = q + 2.0 * p * std::cos(phi + (2.0 * onethird * pi));
+    ev[1] = 3.0 * q - ev[0] - ev[2];
+    sigma[0] = std::sqrt(std::max(ev[0], sml));
+    sigma[1] = std::sqrt(std::max(ev[1], sml));
+    sigma[2] = std::sqrt(std::max(ev[2], sml));
+    mu = sigma[2] * (sigma[0] - sigma[1]) * (sigma[1] - sigma[2]);
+    mu = std::max(mu, 0.0);
+    mu /= (sigma[0] * sigma[0]);
+    mu *= (Cd * Cd);
+    mu *= state[0];
+    if (mu != mu) mu = 0.0;
+  }
+  // src/fluxes.cpp:669-688
+  void viscSpongePlanar(const double *x, double &wgt) const {
+    const double factor = std::max(vsd_.ratio, 1.0);
+    const double width = vsd_.width;
+    double dist = 0.;
+    for (int d = 0; d < dim; d++) dist += (x[d] - vsd_.point[d]) * vsd_.normal[d];
+    wgt = 0.5 * (std::tanh(dist / width - 2.0) + 1.0);
+    wgt *= (factor - 1.0);
+    wgt += 1.0;
+  }
+  // src/fluxes.cpp:221-246 (shared by the interior and the boundary routine)
+  void sgsAndSponge(const double *state, const double *gradUp, const double *transip, double delta, double &visc,
+                    double &bulkViscosity, double &k, double *diffusionVelocity) const {
+    const double Pr_Cp = visc / k;
+    if (sgs_model_type_ > 0) {
+      double mu_sgs = 0.;
+      if (sgs_model_type_ == 1) sgsSmag(state, gradUp, delta, mu_sgs);
+      if (sgs_model_type_ == 2) sgsSigma(state, gradUp, delta, mu_sgs);
+      bulkViscosity *= (1.0 + mu_sgs / visc);
+      visc += mu_sgs;
+      k += (mu_sgs / Pr_Cp);
+    }
+    if (vsd_.enabled) {
+      double wgt = 0.;
+      viscSpongePlanar(transip, wgt);
+      visc *= wgt;
+      bulkViscosity *= wgt;
+      k *= wgt;
+      for (int sp = 0; sp < numActiveSpecies; sp++)
+        for (int d = 0; d < dim; d++) diffusionVelocity[sp + d * mixture->numSpecies] *= wgt;
+    }
   }
 
   // src/fluxes.cpp:135-170
@@ -339,8 +446,8 @@ class Fluxes {
     }
   }
 
-  // src/fluxes.cpp:178-335 (SGS models and the viscous sponge are outside the hot-path scope)
-  void ComputeViscousFluxes(const double *state, const double *gradUp, const double *transip, double /*delta*/,
+  // src/fluxes.cpp:178-335
+  void ComputeViscousFluxes(const double *state, const double *gradUp, const double *transip, double delta,
                             double distance, double *flux) const {
     for (int d = 0; d < dim; d++)
       for (int eq = 0; eq < num_equation; eq++) flux[eq + d * num_equation] = 0.;
@@ -368,6 +475,7 @@ class Fluxes {
     bulkViscosity -= 2. / 3. * visc;
     double k = transportBuffer[HEAVY_THERMAL_CONDUCTIVITY];
     double ke = transportBuffer[ELECTRON_THERMAL_CONDUCTIVITY];
+    sgsAndSponge(state, gradUp, transip, delta, visc, bulkViscosity, k, diffusionVelocity);
 
     if (twoT) {
       for (int d = 0; d < dim; d++) {
@@ -432,7 +540,7 @@ class Fluxes {
   }
 
   // src/fluxes.cpp:344-505
-  void ComputeBdrViscousFluxes(const double *state, const double *gradUp, const double *transip, double /*delta*/,
+  void ComputeBdrViscousFluxes(const double *state, const double *gradUp, const double *transip, double delta,
                                double distance, const BoundaryViscousFluxData &bcFlux, double *normalFlux) const {
     for (int eq = 0; eq < num_equation; eq++) normalFlux[eq] = 0.;
     if (eqSystem == TPSRHS_EULER) return;
@@ -459,6 +567,7 @@ class Fluxes {
     bulkViscosity -= 2. / 3. * visc;
     double k = transportBuffer[HEAVY_THERMAL_CONDUCTIVITY];
     double ke = transportBuffer[ELECTRON_THERMAL_CONDUCTIVITY];
+    sgsAndSponge(state, gradUp, transip, delta, visc, bulkViscosity, k, diffusionVelocity);
 
     const int primFluxSize = twoT ? numSpecies + nvel + 2 : numSpecies + nvel + 1;
     double normalPrimFlux[MAXEQ + 2];

@@ -496,7 +496,8 @@ class GasMinimalTransport : public TransportProperties {
     diffusivityFactor_ = 3. / 16. * std::sqrt(2.0 * PI_ * kB_) / AVOGADRONUMBER;
     mfFreqFactor_ = 4. / 3. * AVOGADRONUMBER * std::sqrt(8. * kB_ / PI_);
     if (ternary && numSpecies != 3) throw std::runtime_error("argon ternary transport supports Ar, Ar.+1, E only");
-    if (numSpecies > 7) throw std::runtime_error("argon mixture transport supports at most 7 species");
+    if (numSpecies > 7)  // the reference's assert for Gas:Ar, src/gas_transport.cpp:905-911
+      throw std::runtime_error("argon mixture transport supports at most 7 species");
     neutralIndex_ = in.neutral_index;
     ionIndex_ = in.ion_index;
     electronIndex_ = in.electron_index;

@@ -44,6 +44,7 @@ struct Operator {
   tpsrhs_forcing forcing_in;
   std::vector<std::vector<double>> spongeSigma;        // sigma grid function of each zone (:553-606)
   std::vector<std::vector<double>> spongeRadial;       // unit radial vector per node (annulus)
+  std::vector<std::vector<int64_t>> spongePlaneNodes;  // nodesInMixedOutPlane (:545-606)
   std::vector<std::vector<int64_t>> heatNodes;         // nodeList_ of each HeatSource (:890-917)
   std::vector<double> joule;                           // joule_heating_ grid function (empty: none)
 
@@ -51,6 +52,7 @@ struct Operator {
   RuleND faceRule;  // order OrderW + 2p on the reference segment/square
   std::vector<Dense> Ke, MeInv, Aflux;
   std::vector<double> coords;  // byNODES [n + d*ndofs]
+  std::vector<double> elSize;  // per element: GetElementSize(e, 1) / order
   std::vector<double> Up, gradUp;
   double max_char_speed = 0.0;
   // scratch
@@ -82,6 +84,27 @@ struct Operator {
     }
     neq = mixture->num_equation;
     fluxes.reset(new Fluxes(mixture.get(), p->eq_system, transport.get(), neq, dim, axisym));
+    fluxes->sgs_model_type_ = p->sgs.model_type;  // config.GetSgsModelType() etc., src/fluxes.cpp:66-69
+    fluxes->sgs_model_const_ = p->sgs.model_const > 0.0 ? p->sgs.model_const  // defaults: src/M2ulPhyS.cpp:2693-2698
+                               : (p->sgs.model_type == 1 ? 0.12 : (p->sgs.model_type == 2 ? 0.135 : 0.0));
+    fluxes->sgs_model_floor_ = p->sgs.model_floor;
+    fluxes->vsd_ = p->visc_sponge;
+    if (p->sgs.model_type > 0 && dim != 3) throw std::runtime_error("sgs models index three directions (src/fluxes.cpp:524-529)");
+    // elSize (src/rhs_operator.cpp:145-156): Mesh::GetElementSize(e, 1) / order, the smallest singular value of the
+    // Jacobian at the element centre [MFEM]; one-sided Jacobi (Hestenes) on the columns of J
+    elSize.assign(m->num_elements, 0.0);
+    for (int e = 0; e < m->num_elements; e++) {
+      double h;
+      if (m->elem_size) {
+        h = m->elem_size[e];
+      } else {
+        const double xi[3] = {0.5, 0.5, 0.5};
+        double x[3], J[9];
+        mesh.transform(e, xi, x, J);
+        h = min_singular_value(dim, J);
+      }
+      elSize[e] = h / d->order;
+    }
     if (d->use_roe && (dim != 2 || axisym || p->working_fluid != TPSRHS_DRY_AIR))
       throw std::runtime_error("Eval_Roe: 2-D, single species, not axisymmetric (src/riemann_solver.cpp:117-206)");
     rsolver.reset(new RiemannSolver(neq, mixture.get(), fluxes.get(), d->use_roe != 0));
@@ -428,8 +451,8 @@ struct Operator {
           interpGrad(F.e2, shape2.data(), g2);
           rsolver->Eval(u1, u2, fp.nor, fluxN);  // src/face_integrator.cpp:324
           double v1[MAXEQ * MAXDIM], v2[MAXEQ * MAXDIM];
-          fluxes->ComputeViscousFluxes(u1, g1, transip, 0.0, 0.0, v1);
-          fluxes->ComputeViscousFluxes(u2, g2, transip, 0.0, 0.0, v2);
+          fluxes->ComputeViscousFluxes(u1, g1, transip, elSize[F.e1], 0.0, v1);  // delta1, delta2: face_integrator.cpp:253-276
+          fluxes->ComputeViscousFluxes(u2, g2, transip, elSize[F.e2], 0.0, v2);
           for (int i = 0; i < neq * dim; i++) v1[i] = -0.5 * (v1[i] + v2[i]);
           for (int eq = 0; eq < neq; eq++)
             for (int d = 0; d < dim; d++) fluxN[eq] += v1[eq + d * neq] * fp.nor[d];
@@ -442,7 +465,7 @@ struct Operator {
               el1[k + eq * dof] -= shape1[k] * fluxN[eq];
             }
         } else {
-          bcs.at(F.attr)->computeBdrFlux(fp.nor, u1, g1, transip, 0.0, 0.0, fluxN,
+          bcs.at(F.attr)->computeBdrFlux(fp.nor, u1, g1, transip, elSize[F.e1], 0.0, fluxN,
                                          nrFaceOrdinal.empty() || nrFaceOrdinal[f] < 0 ? -1 : nrFaceOrdinal[f] * faceRule.npts + q);
           for (int eq = 0; eq < neq; eq++) fluxN[eq] *= fp.w;
           if (axisym)
@@ -485,7 +508,7 @@ struct Operator {
       for (int d = 0; d < dim; d++) xyz[d] = coords[i + d * N];
       fluxes->ComputeConvectiveFluxes(state, f);
       if (phys.eq_system != TPSRHS_EULER) {
-        fluxes->ComputeViscousFluxes(state, g, xyz, 0.0, 0.0, fv);
+        fluxes->ComputeViscousFluxes(state, g, xyz, elSize[i / dof], 0.0, fv);
         for (int k = 0; k < neq * dim; k++) f[k] -= fv[k];
       }
       for (int d = 0; d < dim; d++)
@@ -558,6 +581,7 @@ struct Operator {
   void setForcing(const tpsrhs_forcing *f) {
     spongeSigma.clear();
     spongeRadial.clear();
+    spongePlaneNodes.clear();
     heatNodes.clear();
     has_forcing = f != nullptr;
     if (!f) return;
@@ -570,6 +594,7 @@ struct Operator {
       mod = std::sqrt(mod);
       for (int d = 0; d < dim; d++) sz.normal[d] /= mod;
       std::vector<double> sigma(N, 0.0), radial;
+      std::vector<int64_t> nodesVec;
       if (sz.type == TPSRHS_SPONGE_ANNULUS) radial.assign(static_cast<size_t>(N) * 3, 0.0);
       for (int64_t n = 0; n < N; n++) {
         double Xn[3] = {0, 0, 0};
@@ -579,6 +604,7 @@ struct Operator {
         double distF = 0.;
         for (int d = 0; d < dim; d++) distF += sz.normal[d] * (Xn[d] - sz.point0[d]);
         if (sz.type == TPSRHS_SPONGE_PLANAR) {
+          if (std::fabs(distInit) < sz.tol) nodesVec.push_back(n);
           if (distInit > 0. && distF > 0.) {
             const double planeDistance = distF + distInit;
             sigma[n] = distInit / planeDistance / planeDistance;
@@ -588,6 +614,7 @@ struct Operator {
           for (int d = 0; d < dim; d++) tmp[d] = Xn[d] - sz.point_init[d] + distInit * sz.normal[d];
           for (int d = 0; d < dim; d++) R += tmp[d] * tmp[d];
           R = std::sqrt(R);
+          if (std::fabs(R - sz.r1) < sz.tol) nodesVec.push_back(n);
           if (distInit > 0. && distF > 0. && R - sz.r1 > 0.) {
             const double planeDistance = sz.r2 - sz.r1;
             sigma[n] = (R - sz.r1) / planeDistance / planeDistance;
@@ -597,6 +624,8 @@ struct Operator {
       }
       spongeSigma.push_back(sigma);
       spongeRadial.push_back(radial);
+      if (sz.solution_type != TPSRHS_SPONGE_MIXEDOUT) nodesVec.clear();
+      spongePlaneNodes.push_back(nodesVec);
     }
     for (int hs = 0; hs < f->num_heat_sources; hs++) {
       const tpsrhs_heat_source &h = f->heat_sources[hs];
@@ -644,9 +673,44 @@ struct Operator {
     }
   }
 
+  // SpongeZone::computeMixedOutValues, src/forcing_terms.cpp:713-743 (one rank: the MPI_Allreduce is the identity),
+  // with DryAir::computeConservedStateFromConvectiveFlux, src/equation_of_state.cpp:414-444
+  void computeMixedOutValues(int zn) {
+    if (phys.working_fluid != TPSRHS_DRY_AIR || axisym) throw std::runtime_error("mixed-out sponge: dry air, planar / 3-D");
+    const int64_t N = ndofs;
+    tpsrhs_sponge_zone &sz = forcing_in.sponge_zones[zn];
+    double meanNormalFluxes[MAXEQ + 1];
+    for (int eq = 0; eq <= neq; eq++) meanNormalFluxes[eq] = 0.;
+    for (int64_t node : spongePlaneNodes[zn]) {
+      double Upn[MAXEQ], Un[MAXEQ], f[MAXEQ * MAXDIM];
+      for (int eq = 0; eq < neq; eq++) Upn[eq] = Up[node + eq * N];
+      mixture->GetConservativesFromPrimitives(Upn, Un);
+      fluxes->ComputeConvectiveFluxes(Un, f);
+      for (int eq = 0; eq < neq; eq++)
+        for (int d = 0; d < dim; d++) meanNormalFluxes[eq] += sz.normal[d] * f[eq + d * neq];
+    }
+    meanNormalFluxes[neq] = static_cast<double>(spongePlaneNodes[zn].size());
+    for (int eq = 0; eq < neq; eq++) meanNormalFluxes[eq] /= meanNormalFluxes[neq];
+    const double gamma = mixture->GetSpecificHeatRatio();
+    const int iTh = 1 + nvel;
+    double temp = 0.;
+    for (int d = 0; d < dim; d++) temp += meanNormalFluxes[1 + d] * sz.normal[d];
+    const double A = 1. - 2. * gamma / (gamma - 1.);
+    const double B = 2 * temp / (gamma - 1.);
+    double C = -2. * meanNormalFluxes[0] * meanNormalFluxes[iTh];
+    for (int d = 0; d < nvel; d++) C += meanNormalFluxes[1 + d] * meanNormalFluxes[1 + d];
+    const double p = (-B - std::sqrt(B * B - 4. * A * C)) / (2. * A);
+    double Upm[MAXEQ];
+    Upm[0] = meanNormalFluxes[0] * meanNormalFluxes[0] / (temp - p);
+    Upm[iTh] = p / (mixture->GetGasConstant() * Upm[0]);
+    for (int d = 0; d < nvel; d++) Upm[1 + d] = (meanNormalFluxes[1 + d] - p * sz.normal[d]) / meanNormalFluxes[0];
+    mixture->GetConservativesFromPrimitives(Upm, sz.target_U);
+  }
+
   // SpongeZone::addSpongeZoneForcing, src/forcing_terms.cpp:637-711
   void spongeZone(int zn, double *y) {
     const int64_t N = ndofs;
+    if (forcing_in.sponge_zones[zn].solution_type == TPSRHS_SPONGE_MIXEDOUT) computeMixedOutValues(zn);  // updateTerms, :631-635
     const tpsrhs_sponge_zone &sz = forcing_in.sponge_zones[zn];
     const double *targetU = sz.target_U;
     double Upt[MAXEQ], targetCyl[MAXEQ];

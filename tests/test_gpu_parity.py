@@ -376,3 +376,56 @@ def test_hip_residual_is_conservative(kind, order):
         total, scale = o.integral(got[eq]), o.integral(np.abs(got[eq]))
         print(kind, "equation", eq, "integral", total, "of", scale)
         assert abs(total) < 1e-11 * scale
+
+
+# ---- the capacity limits of the reference's device build (MAXSPECIES = 8, MAXEQUATIONS = 13,
+# ---- MAXDOFS = 216 = hex p=5, src/dataStructures.hpp:41-65)
+@pytest.mark.parametrize("levels,ambi,geo,order,transport,two_t", [
+    (4, False, "3d", 2, capi.ARGON_MIXTURE, True),   # 7 species, 12 equations
+    (5, False, "3d", 3, capi.CONSTANT, True),        # 8 species, 13 equations = MAXEQUATIONS
+    (5, False, "axisym", 3, capi.CONSTANT, True),
+    (4, True, "axisym", 2, capi.ARGON_MIXTURE, True),  # ambipolar: 7 species, 5 active
+    (5, True, "3d", 1, capi.CONSTANT, False),
+    (4, False, "3d", 1, capi.ARGON_MIXTURE, False),
+    (4, False, "2d", 3, capi.ARGON_MIXTURE, True),
+])
+def test_plasma_seven_eight_species(levels, ambi, geo, order, transport, two_t):
+    """argon with 4 / 5 lumped excited levels (capi.argon_levels_physics: the two top levels are synthetic)"""
+    ph = capi.argon_levels_physics(levels, ambi, capi.NS, transport, two_t, True, radiation=(geo == "axisym"))
+    assert ph.mixture.num_species == 3 + levels
+    _boost_transport(ph, 30.0)
+    if geo == "axisym":
+        c = cases.argon_axisym(6, 8, order, physics=ph, r_in=0.0)
+    elif geo == "2d":
+        c = cases.Case("plasma_2d", meshgen.box_quad(5, 4, lengths=(0.2, 0.1), warp=0.08), capi.Disc(order, 0, 0, 0, 0), ph, [])
+    else:
+        c = cases.argon_cyl3d(4, 12, 3, order, physics=ph)
+    amp = 0.005 if order == 1 else 0.01
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=19, amp=amp), tol=_tol(amp))
+
+
+def test_argon_mixture_transport_species_limit():
+    """Gas:Ar mixture transport stops at 7 species (the reference asserts, src/gas_transport.cpp:905-911)"""
+    from tps_amd.rhs_operator import RHSoperator
+    ph = capi.argon_levels_physics(5, False, capi.NS, capi.ARGON_MIXTURE, True, True)
+    c = cases.argon_cyl3d(2, 8, 3, 1, physics=ph)
+    with pytest.raises(Exception, match="at most 7 species"):
+        RHSoperator(c.mesh, c.disc, c.physics, c.bcs)
+
+
+@pytest.mark.parametrize("geo,order,nsp,two_t,transport", [
+    ("3d", 4, 3, False, capi.ARGON_MINIMAL), ("3d", 5, 3, True, capi.ARGON_MINIMAL), ("axisym", 4, 6, True, capi.CONSTANT),
+    ("axisym", 5, 3, True, capi.ARGON_MIXTURE), ("3d", 4, 6, True, capi.ARGON_MIXTURE),
+])
+def test_plasma_orders_four_five(geo, order, nsp, two_t, transport):
+    """plasma kernels at p = 4 (125 nodes, two waves per element) and p = 5 (216 nodes = MAXDOFS, four waves)"""
+    if nsp == 3:
+        ph = capi.argon_ternary_physics(capi.NS, two_t, transport, "arrhenius", radiation=(geo == "axisym"))
+    else:
+        ph = capi.argon_six_species_physics(capi.NS, transport, two_t, True, radiation=(geo == "axisym"))
+    _boost_transport(ph, 30.0)
+    if geo == "axisym":
+        c = cases.argon_axisym(4, 5, order, physics=ph, r_in=0.0)
+    else:
+        c = cases.argon_cyl3d(2, 8, 3, order, physics=ph)
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=23, amp=0.01), tol=_tol(0.01))

@@ -194,6 +194,10 @@ struct ForcingDev {
     double normal[3], p0[3], pinit[3];
     double r1, r2, mult;
     double target[TPSRHS_MAXEQUATIONS];
+    // mixed-out target (SpongeZoneSolution::MIXEDOUT): nodes of the mix-out plane, and the sums over them
+    int mixed_out, n_plane;
+    const int *plane_nodes;  // [n_plane] device
+    double *msum;            // [NEQ + 1] device: sum of F_c . n per equation, number of nodes
   } sponge[TPSRHS_MAXSPONGEZONES];
   const double *joule;  // [ndofs] or NULL
 };
@@ -354,6 +358,9 @@ __device__ inline void face_geometry(const double *V, const Tab<C> &tab, int s, 
     n[0] = sg * (va[1] * vb[2] - va[2] * vb[1]);
     n[1] = sg * (va[2] * vb[0] - va[0] * vb[2]);
     n[2] = sg * (va[0] * vb[1] - va[1] * vb[0]);
+#pragma unroll
+    for (int i = 0; i < 3; i++)  // position (read by the viscous sponge only; dropped by the compiler elsewhere)
+      X[i] = V[c00 * 3 + i] + ta * (V[c10 * 3 + i] - V[c00 * 3 + i]) + tb * vb[i];
   }
 }
 
@@ -1211,6 +1218,16 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const type
     face_geometry_rt<C>(d, &sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
     if constexpr (PH::HEAVY) {
       PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, PH::AXISYM ? Xq[0] : -1.0, fn);
+    } else if constexpr (PH::LES) {  // delta1 of src/face_integrator.cpp:253, transip of :333
+      PointCtx pc;
+      pc.delta = prm.elem_delta[e];
+#pragma unroll
+      for (int k = 0; k < DIM; k++) pc.X[k] = Xq[k];
+      if (nb >= 0) {
+        PH::visc_flux_n(prm, v[rd], v[rd] + NEQ, n, fn, &pc);
+      } else {
+        PH::bc_visc_term(prm, prm.bc[-nb - 1], v[rd], v[rd] + NEQ, n, fn, &pc);
+      }
     } else {
       if (nb >= 0) {
         PH::visc_flux_n(prm, v[rd], v[rd] + NEQ, n, fn);
@@ -1308,7 +1325,13 @@ __device__ inline void visc_phase_heavy3d(const MeshDev &m, const int2 *sFI, con
     }
     // 0: no viscous term on this face, 1: interior face, 2: wall face (interior state, then wall-side state)
     const int np_lane = on ? PH::visc_passes(prm, nb) : 0;
-    const int npass = (__ballot(np_lane == 2) != 0) ? 2 : ((__ballot(np_lane >= 1) != 0) ? 1 : 0);
+    // the pass loop holds block-wide stages: its trip count is uniform over the block (one wave: a ballot;
+    // p = 4, 5: two / four waves share the element)
+    int npass;
+    if constexpr (C::BLOCK == 64)
+      npass = (__ballot(np_lane == 2) != 0) ? 2 : ((__ballot(np_lane >= 1) != 0) ? 1 : 0);
+    else
+      npass = __syncthreads_or(np_lane == 2) ? 2 : (__syncthreads_or(np_lane >= 1) ? 1 : 0);
     double fn[NEQ];
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) fn[eq] = 0.0;
@@ -1842,6 +1865,52 @@ __global__ __launch_bounds__(C::BLOCK) void k_bc_nr(MeshDev m, typename PH::Para
   for (int eq = 0; eq < NEQ; eq++) state_new[rec + eq] = newU[eq];
 }
 
+// SpongeZone::computeMixedOutValues (src/forcing_terms.cpp:713-743): the convective normal flux summed over the
+// nodes of the mix-out plane -- one block, fixed summation order -- then (after the sum over the ranks) the
+// mixed-out state of the mean flux becomes the zone's target.
+template <class C, class PH>
+__global__ __launch_bounds__(256) void k_mixed_out_sum(int64_t ndofs, typename PH::Params prm, const ForcingDev *fd, int z,
+                                                       const double *__restrict__ U) {
+  constexpr int NEQ = PH::NEQ;
+  const ForcingDev::Sponge &sz = fd->sponge[z];
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double acc[NEQ];
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) acc[eq] = 0.0;
+  for (int i = tid; i < sz.n_plane; i += 256) {
+    const int64_t n = sz.plane_nodes[i];
+    double u[NEQ], fn[NEQ];
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) u[eq] = field_ptr(U, eq, ndofs)[n];
+    PH::conv_flux_n(prm, u, PH::make_state(prm, u), sz.normal, fn);
+#pragma unroll
+    for (int eq = 0; eq < NEQ; eq++) acc[eq] += fn[eq];
+  }
+  for (int eq = 0; eq < NEQ; eq++) {
+    red[tid] = acc[eq];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) red[tid] += red[tid + s];
+      __syncthreads();
+    }
+    if (tid == 0) sz.msum[eq] = red[0];
+    __syncthreads();
+  }
+  if (tid == 0) sz.msum[NEQ] = static_cast<double>(sz.n_plane);
+}
+template <class C, class PH>
+__global__ void k_mixed_out_finish(typename PH::Params prm, ForcingDev *fd, int z) {
+  constexpr int NEQ = PH::NEQ;
+  ForcingDev::Sponge &sz = fd->sponge[z];
+  double mean[NEQ], tgt[NEQ];
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) mean[eq] = sz.msum[eq] / sz.msum[NEQ];
+  PH::state_from_mean_flux(prm, mean, sz.normal, tgt);
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) sz.target[eq] = tgt[eq];
+}
+
 // y += optional forcing terms: a streaming pass of its own (one lane per node), launched after k_flux
 // only when such a term is configured -- the hot sweeps carry neither its registers nor a branch.
 template <class C, class PH>
@@ -2086,7 +2155,7 @@ __device__ inline void face_flux_2d(const MeshDev &m, const typename PH::Params 
 }
 
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK, (C::NC && PH::MINW_FLUX > 2) ? 2 : PH::MINW_FLUX) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
+__global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2)) ? (PH::HEAVY ? 1 : 2) : PH::MINW_FLUX) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
                                                    const double *__restrict__ gradUp, const double *__restrict__ TA,
                                                    const double *__restrict__ TB, double *__restrict__ Y,
                                                    double *__restrict__ block_speed) {
@@ -2175,7 +2244,15 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::MINW_FLUX > 2) ? 2 : PH::MI
           PH::total_flux(prm, uc, st, fc, gr, PH::AXISYM ? radius : -1.0, F);
         else if constexpr (PH::AXISYM)
           PH::total_flux(prm, uc, st, gr, radius, F);
-        else
+        else if constexpr (PH::LES) {  // elSize and xyz of the node, src/rhs_operator.cpp:526-539
+          PointCtx pc;
+          double xn[DIM];
+#pragma unroll
+          for (int d = 0; d < DIM; d++) xn[d] = tab.x[idx[d]];
+          position<DIM>(&sV[le_n * C::NV * DIM], xn, pc.X);
+          pc.delta = prm.elem_delta[e0 + le_n];
+          PH::total_flux(prm, uc, st, gr, F, &pc);
+        } else
           PH::total_flux(prm, uc, st, gr, F);
       }
     }

@@ -242,6 +242,19 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
   // ConstantPressureGradient / SpongeZone / HeatSource / JouleHeating, after the last k_flux launch
   auto forcing = [&](const MeshDev &m) {
     if (!op->forcing_active) return;
+    if constexpr (PH::HAS_MIXED_OUT) {  // SpongeZone::updateTerms: computeMixedOutValues first (src/forcing_terms.cpp:631-635)
+      for (int z = 0; z < op->forcing.nsponge; z++) {
+        if (!op->forcing.sponge[z].mixed_out) continue;
+        hipLaunchKernelGGL((k_mixed_out_sum<C, PH>), dim3(1), dim3(256), 0, s, op->ndofs, prm, op->d_forcing, z, x);
+        HIP_CHECK(hipGetLastError());
+        if (op->reduce && op->topo.num_shared > 0) {  // MPI_Allreduce of meanNormalFluxes, :732-735
+          const int st = op->reduce(op->reduce_ctx, op->forcing.sponge[z].msum, PH::NEQ + 1, TPSRHS_REDUCE_SUM, s);
+          if (st != 0) throw std::runtime_error("mixed-out sponge: reduce callback failed");
+        }
+        hipLaunchKernelGGL((k_mixed_out_finish<C, PH>), dim3(1), dim3(1), 0, s, prm, op->d_forcing, z);
+        HIP_CHECK(hipGetLastError());
+      }
+    }
     const int grid = static_cast<int>((op->ndofs + 255) / 256);
     hipLaunchKernelGGL((k_forcing<C, PH>), dim3(grid), dim3(256), 0, s, m, prm, op->d_forcing, x, op->d_gradUp, y);
     HIP_CHECK(hipGetLastError());

@@ -42,7 +42,19 @@ struct DryAirParams {
   double nr_dt, ref_length;
   const double *bstate;
   const int *nr_ordinal;  // [face slot] -> ordinal among the faces of non-reflecting patches
+  // sub-grid scale model and viscous sponge of Fluxes (src/fluxes.cpp:223-246; the LES flavour of the kernels)
+  int sgs_type;  // 0 none, 1 Smagorinsky, 2 sigma
+  int vs_enabled;
+  double sgs_const, sgs_floor;
+  double vs_n[3], vs_p[3], vs_width, vs_ratio;
+  const double *elem_delta;  // [ne] Mesh::GetElementSize(e, 1) / order (src/rhs_operator.cpp:154)
   BcDev bc[MAXBC];
+};
+
+// Where a point sits, for the closures that depend on it (LES flavour): grid scale of its element and position
+struct PointCtx {
+  double delta;
+  double X[3];
 };
 
 // Slip wall in 2-D (computeSlipWallFlux, src/wallBC.cpp:326-428): the reference mirrors the velocity component
@@ -74,8 +86,11 @@ __host__ __device__ inline bool is_non_reflecting(int category, int type) {
 
 // NR_: instantiate the non-reflecting inlet / outlet types.  A flavour of its own, picked only when such a
 // patch exists: the extra ghost-state path costs the hot k_flux registers (measured +5 % at cfg2).
-template <int DIM_, bool NR_ = false>
+// LES_: the sub-grid scale models and the planar viscous sponge, evaluated wherever the molecular transport is
+// (a flavour of its own for the same reason).
+template <int DIM_, bool NR_ = false, bool LES_ = false>
 struct DryAirPhys {
+  static constexpr bool LES = LES_;
   static constexpr int DIM = DIM_;
   static constexpr int NVEL = DIM_;
   static constexpr int NEQ = DIM_ + 2;
@@ -253,14 +268,117 @@ struct DryAirPhys {
     t.k = p.cp_div_pr * t.visc;
     return t;
   }
+  // Fluxes::sgsSmag, src/fluxes.cpp:513-537 (three velocity components)
+  __device__ static inline double sgs_smagorinsky(const Params &p, double rho, const double *g, double delta) {
+    static_assert(DIM == 3, "the reference's strain tensor indexes three directions");
+    const double S0 = g[1 + 0 * NEQ], S1 = g[2 + 1 * NEQ], S2 = g[3 + 2 * NEQ];
+    const double S3 = 0.5 * (g[1 + 1 * NEQ] + g[2 + 0 * NEQ]);
+    const double S4 = 0.5 * (g[1 + 2 * NEQ] + g[3 + 0 * NEQ]);
+    const double S5 = 0.5 * (g[2 + 2 * NEQ] + g[3 + 1 * NEQ]);
+    double Smag = S0 * S0;
+    Smag += S1 * S1;
+    Smag += S2 * S2;
+    Smag += 2.0 * S3 * S3;
+    Smag += 2.0 * S4 * S4;
+    Smag += 2.0 * S5 * S5;
+    Smag = sqrt(2.0 * Smag);
+    const double d_model = p.sgs_const * fmax(delta - p.sgs_floor, 0.0);
+    return rho * d_model * d_model * Smag;
+  }
+  // Fluxes::sgsSigma, src/fluxes.cpp:543-665, the branch without LAPACK (eigenvalues of g^T g, its 12-digit pi)
+  __device__ static inline double sgs_sigma(const Params &p, double rho, const double *g, double delta) {
+    static_assert(DIM == 3, "three singular values");
+    const double sml = 1.0e-12, pi = 3.14159265359, onethird = 1. / 3.;
+    const double d_model = fmax(delta - p.sgs_floor, sml);
+    double Q[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        double q = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) q += g[k + 1 + i * NEQ] * g[k + 1 + j * NEQ];
+        Q[i][j] = q;
+      }
+    const double d4 = pow(d_model, 4);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Q[i][j] *= d4;
+    const double p1 = Q[0][1] * Q[0][1] + Q[0][2] * Q[0][2] + Q[1][2] * Q[1][2];
+    const double q = onethird * (Q[0][0] + Q[1][1] + Q[2][2]);
+    const double p2 = (Q[0][0] - q) * (Q[0][0] - q) + (Q[1][1] - q) * (Q[1][1] - q) + (Q[2][2] - q) * (Q[2][2] - q) + 2.0 * p1;
+    const double pp = sqrt(fmax(p2, 0.0) / 6.0);
+    double B[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) B[i][j] = (Q[i][j] - (i == j ? q : 0.0)) * (1.0 / fmax(pp, sml));
+    const double detB = B[0][0] * (B[1][1] * B[2][2] - B[2][1] * B[1][2]) - B[0][1] * (B[1][0] * B[2][2] - B[2][0] * B[1][2]) +
+                        B[0][2] * (B[1][0] * B[2][1] - B[2][0] * B[1][1]);
+    const double r = 0.5 * detB;
+    double phi;
+    if (r <= -1.0)
+      phi = onethird * pi;
+    else if (r >= 1.0)
+      phi = 0.0;
+    else
+      phi = onethird * acos(r);
+    double ev[3];
+    ev[0] = q + 2.0 * pp * cos(phi);
+    ev[2] = q + 2.0 * pp * cos(phi + (2.0 * onethird * pi));
+    ev[1] = 3.0 * q - ev[0] - ev[2];
+    const double s0 = sqrt(fmax(ev[0], sml)), s1 = sqrt(fmax(ev[1], sml)), s2 = sqrt(fmax(ev[2], sml));
+    double mu = s2 * (s0 - s1) * (s1 - s2);
+    mu = fmax(mu, 0.0);
+    mu /= (s0 * s0);
+    mu *= (p.sgs_const * p.sgs_const);
+    mu *= rho;
+    if (mu != mu) mu = 0.0;
+    return mu;
+  }
+  // Fluxes::viscSpongePlanar, src/fluxes.cpp:669-688 (the normal as given, not normalised)
+  __device__ static inline double visc_sponge_weight(const Params &p, const double *X) {
+    const double factor = fmax(p.vs_ratio, 1.0);
+    double dist = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) dist += (X[d] - p.vs_p[d]) * p.vs_n[d];
+    double wgt = 0.5 * (tanh(dist / p.vs_width - 2.0) + 1.0);
+    wgt *= (factor - 1.0);
+    wgt += 1.0;
+    return wgt;
+  }
+  // the transport of a point: molecular, then the sub-grid scale model and the viscous sponge (src/fluxes.cpp:216-246)
+  __device__ static inline Transport transport(const Params &p, const State &s, const double *U, const double *g,
+                                               const PointCtx *c) {
+    Transport t = transport(p, s);
+    if constexpr (LES_) {
+      if (p.sgs_type > 0) {
+        if constexpr (DIM == 3) {
+          const double pr_cp = t.visc / t.k;
+          const double mu_sgs = (p.sgs_type == 1) ? sgs_smagorinsky(p, U[0], g, c->delta) : sgs_sigma(p, U[0], g, c->delta);
+          t.bulk *= (1.0 + mu_sgs / t.visc);
+          t.visc += mu_sgs;
+          t.k += (mu_sgs / pr_cp);
+        }
+      }
+      if (p.vs_enabled) {
+        const double wgt = visc_sponge_weight(p, c->X);
+        t.visc *= wgt;
+        t.bulk *= wgt;
+        t.k *= wgt;
+      }
+    }
+    return t;
+  }
 
   // ComputeViscousFluxes, src/fluxes.cpp:178-335; g[eq + d*NEQ] = d(Up_eq)/dx_d; F[eq + d*NEQ]
   __device__ static inline void visc_flux(const Params &p, const double *U, const State &s, const double *g,
-                                          double *F) {
+                                          double *F, const PointCtx *c = nullptr) {
 #pragma unroll
     for (int i = 0; i < NEQ * DIM; i++) F[i] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
-    const Transport t = transport(p, s);
+    const Transport t = transport(p, s, U, g, c);
     double divV = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
@@ -283,13 +401,14 @@ struct DryAirPhys {
       F[(1 + NVEL) + i * NEQ] = vt + t.k * g[(1 + NVEL) + i * NEQ];
     }
   }
-  __device__ static inline void visc_flux(const Params &p, const double *U, const double *g, double *F) {
-    visc_flux(p, U, make_state(p, U), g, F);
+  __device__ static inline void visc_flux(const Params &p, const double *U, const double *g, double *F,
+                                          const PointCtx *c = nullptr) {
+    visc_flux(p, U, make_state(p, U), g, F, c);
   }
 
   // F_c - F_v as one tensor F[eq + d*NEQ] (src/rhs_operator.cpp:532-541)
   __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const double *g,
-                                           double *F) {
+                                           double *F, const PointCtx *c = nullptr) {
     const double H = U[1 + NVEL] + s.p;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
@@ -300,7 +419,7 @@ struct DryAirPhys {
       F[1 + NVEL + d * NEQ] = s.vel[d] * H;
     }
     if (p.eq_system == TPSRHS_EULER) return;
-    const Transport t = transport(p, s);
+    const Transport t = transport(p, s, U, g, c);
     double divV = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
@@ -320,12 +439,12 @@ struct DryAirPhys {
 
   // F_v(U, g) . n without forming the tensor
   __device__ static inline void visc_flux_n(const Params &p, const double *U, const double *g, const double *n,
-                                            double *Fn) {
+                                            double *Fn, const PointCtx *c = nullptr) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) Fn[eq] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
     const State s = make_state(p, U);
-    const Transport t = transport(p, s);
+    const Transport t = transport(p, s, U, g, c);
     double divV = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
@@ -346,12 +465,12 @@ struct DryAirPhys {
   // ComputeBdrViscousFluxes with zero prescribed species flux and, when `adiabatic`, zero heat
   // flux (src/fluxes.cpp:344-505 with the bcFlux_ of src/wallBC.cpp:86-111); nu = unit normal
   __device__ static inline void bdr_visc_flux(const Params &p, const double *Uw, const double *g, const double *nu,
-                                              bool adiabatic, double *Fn) {
+                                              bool adiabatic, double *Fn, const PointCtx *c = nullptr) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) Fn[eq] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
     const State sw = make_state(p, Uw);
-    const Transport t = transport(p, sw);
+    const Transport t = transport(p, sw, Uw, g, c);
     double divV = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];
@@ -537,6 +656,27 @@ struct DryAirPhys {
     U[1 + NVEL] = p.Rg * Up[0] * Up[1 + NVEL] / (p.gamma - 1.0) + 0.5 * Up[0] * k;
   }
 
+  // DryAir::computeConservedStateFromConvectiveFlux, src/equation_of_state.cpp:414-444 (mixed-out sponge target)
+  static constexpr bool HAS_MIXED_OUT = true;
+  __device__ static inline void state_from_mean_flux(const Params &p, const double *mf, const double *n, double *U) {
+    const double gamma = p.gamma;
+    double temp = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) temp += mf[1 + d] * n[d];
+    const double A = 1. - 2. * gamma / (gamma - 1.);
+    const double B = 2 * temp / (gamma - 1.);
+    double Cc = -2. * mf[0] * mf[1 + NVEL];
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) Cc += mf[1 + d] * mf[1 + d];
+    const double pr = (-B - sqrt(B * B - 4. * A * Cc)) / (2. * A);
+    double Up[NEQ];
+    Up[0] = mf[0] * mf[0] / (temp - pr);
+    Up[1 + NVEL] = pr / (p.Rg * Up[0]);
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) Up[1 + d] = (mf[1 + d] - pr * n[d]) / mf[0];
+    cons(p, Up, U);
+  }
+
   // ---- boundary conditions ------------------------------------------------------------------
   // ghost (second) state handed to the Riemann solver
   // (`bs`: this face point's record of the non-reflecting boundary state, or NULL)
@@ -596,7 +736,7 @@ struct DryAirPhys {
   // additive viscous part of the boundary flux: what the wall routines subtract from bdrFlux
   // after the Riemann solve (src/wallBC.cpp:303-319, 439-468, 487-509); zero for inlet/outlet
   __device__ static inline void bc_visc_term(const Params &p, const BcDev &bc, const double *U, const double *g,
-                                             const double *n, double *out) {
+                                             const double *n, double *out, const PointCtx *c = nullptr) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) out[eq] = 0.0;
     if (bc.category != TPSRHS_WALL || p.eq_system == TPSRHS_EULER || bc.type == TPSRHS_SLIP) return;  // slip: Riemann flux only
@@ -605,12 +745,12 @@ struct DryAirPhys {
     for (int d = 0; d < DIM; d++) nm += n[d] * n[d];
     nm = sqrt(nm);
     double fin[NEQ];
-    visc_flux_n(p, U, g, n, fin);
+    visc_flux_n(p, U, g, n, fin, c);
     double fw[NEQ];
     if (bc.type == TPSRHS_INV) {
       double Ug[NEQ];
       bc_ghost(p, bc, U, n, Ug);
-      visc_flux_n(p, Ug, g, n, fw);
+      visc_flux_n(p, Ug, g, n, fw, c);
     } else {
       double Uw[NEQ], nu[DIM];
 #pragma unroll
@@ -621,10 +761,10 @@ struct DryAirPhys {
       for (int d = 0; d < NVEL; d++) Uw[1 + d] = 0.0;
       if (bc.type == TPSRHS_VISC_ADIAB) {
         Uw[1 + NVEL] = pressure(p, U) / (p.gamma - 1.0);
-        bdr_visc_flux(p, Uw, g, nu, true, fw);
+        bdr_visc_flux(p, Uw, g, nu, true, fw, c);
       } else {
         Uw[1 + NVEL] = p.Rg / (p.gamma - 1.0) * U[0] * bc.data[0];
-        bdr_visc_flux(p, Uw, g, nu, false, fw);
+        bdr_visc_flux(p, Uw, g, nu, false, fw, c);
       }
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) fw[eq] *= nm;

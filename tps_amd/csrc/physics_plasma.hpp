@@ -205,10 +205,16 @@ struct PlasmaPhys {
   static constexpr bool HAS_SOURCE = true;
   static constexpr bool TWO_TEMPERATURE = TWOT;
   static constexpr int MAX_ORDER = 4;
-  static constexpr bool HAS_NR_BC = false;  // the reference's non-reflecting conditions are perfect-gas algebra
+  static constexpr bool HAS_NR_BC = false;
+  static constexpr bool LES = false;  // sub-grid scale models / viscous sponge: dry air, planar and 3-D  // the reference's non-reflecting conditions are perfect-gas algebra
+  static constexpr bool HAS_MIXED_OUT = false;  // mixed-out sponge target: dry air, planar / 3-D
   static constexpr bool VISC_USES_GRAD_RHO = true;  // mole-fraction gradients need grad(rho)
   static constexpr bool AXISYM = NVEL_ > DIM_;  // dim 2 with (r, z, theta) velocity components
-  static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : TPSRHS_PLASMA_MINW_GRAD3, MINW_FLUX = TPSRHS_PLASMA_MINW_FLUX;  // waves per SIMD asked of the allocator
+  // waves per SIMD asked of the allocator.  More than three species (9-13 equations): one wave per SIMD, 512
+  // registers -- at two the sweeps spilled 150-340 VGPRs to scratch, and two such instantiations returned
+  // scheduling-dependent wrong results (DESIGN.md "spilled instantiations")
+  static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : TPSRHS_PLASMA_MINW_GRAD3;
+  static constexpr int MINW_FLUX = (NSP_ > 3) ? 1 : TPSRHS_PLASMA_MINW_FLUX;
   typedef PlasmaParams<NSP_> Params;
   struct Transport {};
 

@@ -1,0 +1,3 @@
+// Plasma kernel family: dim 2, 2 velocity components, 8 species, ambipolar = false.
+#include "plasma_family.hpp"
+TPSRHS_PLASMA_FAMILY(pick_plasma_2d_n8, 2, 2, 8, false)

@@ -13,20 +13,28 @@ static void pick_plasma_orders(tpsrhs_operator *op) {
   if (op->nc) {
     // the Gauss-Lobatto pair: the ternary mixtures (the species count of test/inputs/argonMinimal.ini, which runs
     // on that pair), planar / 3-D
+#ifndef TPSRHS_PLASMA_HIGH_ORDERS
     if constexpr (NSP == 3 && NVEL == DIM) {
       pick_order_nc<DIM, PH>(op);
       return;
-    } else {
+    } else
+#endif
+    {
       throw Unsupported("Gauss-Lobatto basis + rule: built for dry air and the ternary plasma (planar 2-D, 3-D)");
     }
   }
   upload_tables(DIM, op->order);
   op->point_eval = &launch_point_eval<PH>;
   switch (op->order) {
+#ifndef TPSRHS_PLASMA_HIGH_ORDERS
     case 1: op->launch = &launch_all<DIM, 1, PH>; break;
     case 2: op->launch = &launch_all<DIM, 2, PH>; break;
     case 3: op->launch = &launch_all<DIM, 3, PH>; break;
-    default: throw Unsupported("plasma kernels are built for polynomial orders 1..3");
+#else  // the `_hi` translation units: orders 4 and 5 (MAXDOFS = 216 = hex p=5, src/dataStructures.hpp:41-65)
+    case 4: op->launch = &launch_all<DIM, 4, PH>; break;
+    case 5: op->launch = &launch_all<DIM, 5, PH>; break;
+#endif
+    default: throw Unsupported("plasma kernels of this family: polynomial order " + std::to_string(op->order) + " is not built");
   }
 }
 

@@ -19,8 +19,16 @@ DECL(pick_plasma_axi_n3a); DECL(pick_plasma_axi_n3); DECL(pick_plasma_axi_n6);
 DECL(pick_plasma_3d_n4a); DECL(pick_plasma_3d_n5a); DECL(pick_plasma_3d_n5);
 DECL(pick_plasma_2d_n4a); DECL(pick_plasma_2d_n5a); DECL(pick_plasma_2d_n5);
 DECL(pick_plasma_axi_n4a); DECL(pick_plasma_axi_n5a); DECL(pick_plasma_axi_n5);
+DECL(pick_plasma_3d_n7a); DECL(pick_plasma_3d_n7); DECL(pick_plasma_3d_n8a); DECL(pick_plasma_3d_n8);
+DECL(pick_plasma_2d_n7a); DECL(pick_plasma_2d_n7); DECL(pick_plasma_2d_n8a); DECL(pick_plasma_2d_n8);
+DECL(pick_plasma_axi_n7a); DECL(pick_plasma_axi_n7); DECL(pick_plasma_axi_n8a); DECL(pick_plasma_axi_n8);
+// polynomial orders 4 and 5 (the `_hi` translation units)
+DECL(pick_plasma_3d_n3a_hi); DECL(pick_plasma_3d_n3_hi); DECL(pick_plasma_3d_n6_hi);
+DECL(pick_plasma_2d_n3a_hi); DECL(pick_plasma_2d_n3_hi); DECL(pick_plasma_2d_n6_hi);
+DECL(pick_plasma_axi_n3a_hi); DECL(pick_plasma_axi_n3_hi); DECL(pick_plasma_axi_n6_hi);
 #undef DECL
 void pick_dryair_axisym(tpsrhs_operator *op);
+void pick_dryair_les(tpsrhs_operator *op);
 
 static thread_local std::string g_last_error;
 
@@ -182,6 +190,57 @@ void fill_plasma_params(tpsrhs_operator *op, const tpsrhs_disc *disc, const tpsr
   HIP_CHECK(hipMemcpy(dc, c.get(), sizeof(ChemDev), hipMemcpyHostToDevice));
   op->d_chem = dc;
   p.chem = dc;
+}
+
+// mfem::Mesh::GetElementSize(e, 1): the smallest singular value of the Jacobian at the element centre
+// (src/rhs_operator.cpp:154, src/face_integrator.cpp:253).  sqrt of the smallest eigenvalue of J^T J by cyclic
+// Jacobi rotations.  verts: [ne][2^dim][dim] lexicographic corners.
+std::vector<double> element_sizes(const std::vector<double> &verts, int dim, int ne) {
+  std::vector<double> h(ne);
+  const int nv = 1 << dim;
+  for (int e = 0; e < ne; e++) {
+    const double *V = &verts[static_cast<size_t>(e) * nv * dim];
+    double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // J[i][a] = d x_i / d xi_a at the centre
+    for (int v = 0; v < nv; v++)
+      for (int a = 0; a < dim; a++) {
+        const double sgn = ((v >> a) & 1) ? 1.0 : -1.0;
+        for (int i = 0; i < dim; i++) J[i][a] += sgn * V[v * dim + i] / (nv / 2);
+      }
+    double A[3][3];
+    for (int a = 0; a < dim; a++)
+      for (int b = 0; b < dim; b++) {
+        double t = 0.0;
+        for (int i = 0; i < dim; i++) t += J[i][a] * J[i][b];
+        A[a][b] = t;
+      }
+    for (int sweep = 0; sweep < 30; sweep++) {
+      double off = 0.0;
+      for (int a = 0; a < dim; a++)
+        for (int b = a + 1; b < dim; b++) off += A[a][b] * A[a][b];
+      if (off == 0.0) break;
+      for (int a = 0; a < dim; a++)
+        for (int b = a + 1; b < dim; b++) {
+          if (A[a][b] == 0.0) continue;
+          const double theta = (A[b][b] - A[a][a]) / (2.0 * A[a][b]);
+          const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+          const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+          for (int k = 0; k < dim; k++) {  // A <- A R
+            const double aka = A[k][a], akb = A[k][b];
+            A[k][a] = c * aka - sn * akb;
+            A[k][b] = sn * aka + c * akb;
+          }
+          for (int k = 0; k < dim; k++) {  // A <- R^T A
+            const double aak = A[a][k], abk = A[b][k];
+            A[a][k] = c * aak - sn * abk;
+            A[b][k] = sn * aak + c * abk;
+          }
+        }
+    }
+    double lmin = A[0][0];
+    for (int a = 1; a < dim; a++) lmin = std::min(lmin, A[a][a]);
+    h[e] = std::sqrt(std::max(lmin, 0.0));
+  }
+  return h;
 }
 
 // Inverse element mass matrices of the non-collocated pair: M_jk = sum_q w_q det J(q) phi_j(q) phi_k(q) with the
@@ -350,10 +409,12 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     const tpsrhs_perfect_mixture &mx = phys->mixture;
     if (!mx.is_electron_included) throw Unsupported("USER_DEFINED fluids without electrons are not built");
     const bool fam = (mx.num_species == 3) || (mx.num_species == 6 && !mx.ambipolar) || (mx.num_species == 4 && mx.ambipolar) ||
-                     (mx.num_species == 5);
+                     (mx.num_species == 5) || (mx.num_species == 7) || (mx.num_species == 8);
     if (!fam)
-      throw Unsupported("USER_DEFINED fluids: built species counts are 3 and 5 (ambipolar or not), 4 (ambipolar) and "
+      throw Unsupported("USER_DEFINED fluids: built species counts are 3, 5, 7 and 8 (ambipolar or not), 4 (ambipolar) and "
                         "6 (not ambipolar)");
+    if (mx.num_species > 7 && phys->transport_model == TPSRHS_ARGON_MIXTURE)  // the reference asserts, src/gas_transport.cpp:905-911
+      throw Unsupported("argon_mixture transport supports at most 7 species (Ar, Ar.+1, Ar_m, Ar_r, Ar_p, Ar_h, E)");
     if (mx.num_species != 3 && phys->transport_model == TPSRHS_ARGON_MINIMAL)
       throw Unsupported("argon_minimal transport is the ternary (Ar, Ar.+1, E) model");
     if (phys->transport_model != TPSRHS_CONSTANT && phys->transport_model != TPSRHS_ARGON_MINIMAL &&
@@ -389,6 +450,8 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   const int npe = (op->dim == 3) ? n1 * n1 * n1 : n1 * n1;
   op->ndofs = static_cast<int64_t>(op->ne) * npe;
 
+  if (plasma && (phys->sgs.model_type != TPSRHS_SGS_NONE || phys->visc_sponge.enabled))
+    throw Unsupported("sub-grid scale model / viscous sponge: built for dry air (planar 2-D and 3-D)");
   if (plasma) {
     const int nsp = phys->mixture.num_species;
     const bool ambi = phys->mixture.ambipolar != 0, two_t = phys->mixture.two_temperature != 0;
@@ -396,7 +459,9 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
       case 3: fill_plasma_params<3>(op, disc, phys, num_bcs, bcs); break;
       case 4: fill_plasma_params<4>(op, disc, phys, num_bcs, bcs); break;
       case 5: fill_plasma_params<5>(op, disc, phys, num_bcs, bcs); break;
-      default: fill_plasma_params<6>(op, disc, phys, num_bcs, bcs); break;
+      case 6: fill_plasma_params<6>(op, disc, phys, num_bcs, bcs); break;
+      case 7: fill_plasma_params<7>(op, disc, phys, num_bcs, bcs); break;
+      default: fill_plasma_params<8>(op, disc, phys, num_bcs, bcs); break;  // MAXSPECIES of the reference's device build
     }
     const int tr = (phys->transport_model == TPSRHS_CONSTANT)
                        ? TRANSPORT_CONSTANT
@@ -404,14 +469,27 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     typedef void (*pick_fn)(tpsrhs_operator *, bool, int);
     // families: 3 species (ambipolar / not), 6 (not), and the other counts of the reference's M2ulPhyS inputs --
     // 4 ambipolar (test/inputs/perfectGas.argon.ini), 5 ambipolar (perfectGas.air.ini), 5 not (input.malamas.test.ini)
-    const pick_fn table[3][6] = {
-        {pick_plasma_3d_n3a, pick_plasma_3d_n3, pick_plasma_3d_n6, pick_plasma_3d_n4a, pick_plasma_3d_n5a, pick_plasma_3d_n5},
-        {pick_plasma_2d_n3a, pick_plasma_2d_n3, pick_plasma_2d_n6, pick_plasma_2d_n4a, pick_plasma_2d_n5a, pick_plasma_2d_n5},
+    // (7 and 8 species: up to MAXSPECIES = 8 / MAXEQUATIONS = 13 of src/dataStructures.hpp:41-65)
+    const pick_fn table[3][10] = {
+        {pick_plasma_3d_n3a, pick_plasma_3d_n3, pick_plasma_3d_n6, pick_plasma_3d_n4a, pick_plasma_3d_n5a, pick_plasma_3d_n5,
+         pick_plasma_3d_n7a, pick_plasma_3d_n7, pick_plasma_3d_n8a, pick_plasma_3d_n8},
+        {pick_plasma_2d_n3a, pick_plasma_2d_n3, pick_plasma_2d_n6, pick_plasma_2d_n4a, pick_plasma_2d_n5a, pick_plasma_2d_n5,
+         pick_plasma_2d_n7a, pick_plasma_2d_n7, pick_plasma_2d_n8a, pick_plasma_2d_n8},
         {pick_plasma_axi_n3a, pick_plasma_axi_n3, pick_plasma_axi_n6, pick_plasma_axi_n4a, pick_plasma_axi_n5a,
-         pick_plasma_axi_n5}};
+         pick_plasma_axi_n5, pick_plasma_axi_n7a, pick_plasma_axi_n7, pick_plasma_axi_n8a, pick_plasma_axi_n8}};
+    // orders 4 and 5: the ternary mixtures and the six-species torch mixture
+    const pick_fn table_hi[3][3] = {{pick_plasma_3d_n3a_hi, pick_plasma_3d_n3_hi, pick_plasma_3d_n6_hi},
+                                    {pick_plasma_2d_n3a_hi, pick_plasma_2d_n3_hi, pick_plasma_2d_n6_hi},
+                                    {pick_plasma_axi_n3a_hi, pick_plasma_axi_n3_hi, pick_plasma_axi_n6_hi}};
     const int geo = (op->dim == 3) ? 0 : (disc->axisymmetric ? 2 : 1);
-    const int fam = (nsp == 6) ? 2 : (nsp == 4) ? 3 : (nsp == 5) ? (ambi ? 4 : 5) : (ambi ? 0 : 1);
-    table[geo][fam](op, two_t, tr);
+    const int fam = (nsp == 6) ? 2 : (nsp == 4) ? 3 : (nsp == 5) ? (ambi ? 4 : 5) : (nsp == 7) ? (ambi ? 6 : 7)
+                    : (nsp == 8) ? (ambi ? 8 : 9) : (ambi ? 0 : 1);
+    if (op->order >= 4 && !op->nc) {
+      if (fam > 2) throw Unsupported("plasma kernels of polynomial orders 4 and 5: built for 3 species and for 6 (not ambipolar)");
+      table_hi[geo][fam](op, two_t, tr);
+    } else {
+      table[geo][fam](op, two_t, tr);
+    }
   } else {
     DryAirParams &d = *new (op->params) DryAirParams;
     std::memset(&d, 0, sizeof(d));
@@ -435,7 +513,37 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     }
     bool any_nr = false;
     for (int i = 0; i < num_bcs; i++) any_nr = any_nr || is_non_reflecting(bcs[i].category, bcs[i].type);
-    if (disc->axisymmetric)
+    // Fluxes: sub-grid scale model and viscous sponge (src/fluxes.cpp:223-246) -> the LES flavour of the kernels
+    const bool les = phys->sgs.model_type != TPSRHS_SGS_NONE || phys->visc_sponge.enabled;
+    if (les) {
+      if (phys->sgs.model_type < 0 || phys->sgs.model_type > TPSRHS_SGS_SIGMA)
+        throw std::invalid_argument("unknown sgs.model_type");
+      if (disc->axisymmetric || op->nc || any_nr)
+        throw Unsupported("sub-grid scale model / viscous sponge: built for dry air, planar 2-D and 3-D, Gauss-Legendre pair, "
+                          "reflecting boundary types");
+      if (phys->sgs.model_type != TPSRHS_SGS_NONE && op->dim != 3)
+        throw Unsupported("sub-grid scale models need dim == 3 (the reference's strain tensor indexes three directions)");
+      if (phys->visc_sponge.enabled && !(phys->visc_sponge.width > 0.0))
+        throw std::invalid_argument("visc_sponge.width must be positive");
+      d.sgs_type = phys->sgs.model_type;
+      d.sgs_const = phys->sgs.model_const > 0.0 ? phys->sgs.model_const  // defaults of src/M2ulPhyS.cpp:2693-2698
+                                                : (d.sgs_type == TPSRHS_SGS_SMAGORINSKY ? 0.12 : (d.sgs_type == TPSRHS_SGS_SIGMA ? 0.135 : 0.0));
+      d.sgs_floor = phys->sgs.model_floor;
+      d.vs_enabled = phys->visc_sponge.enabled ? 1 : 0;
+      for (int k = 0; k < 3; k++) {
+        d.vs_n[k] = (k < op->dim) ? phys->visc_sponge.normal[k] : 0.0;  // vsd.n / vsd.p: dim entries, the rest 0 (:590-596)
+        d.vs_p[k] = (k < op->dim) ? phys->visc_sponge.point[k] : 0.0;
+      }
+      d.vs_width = phys->visc_sponge.enabled ? phys->visc_sponge.width : 1.0;
+      d.vs_ratio = phys->visc_sponge.enabled ? phys->visc_sponge.ratio : 1.0;
+      std::vector<double> delta = mesh->elem_size ? std::vector<double>(mesh->elem_size, mesh->elem_size + tp.ne)
+                                                  : element_sizes(tp.verts, op->dim, tp.ne);
+      for (double &v : delta) v /= op->order;  // elSize = GetElementSize(e, 1) / order, src/rhs_operator.cpp:154
+      double *dd = dev_upload(delta);
+      op->d_extra.push_back(dd);
+      d.elem_delta = dd;
+      pick_dryair_les(op);
+    } else if (disc->axisymmetric)
       pick_dryair_axisym(op);
     else if (op->dim == 3)
       any_nr ? pick_order<3, DryAirPhys<3, true>>(op) : pick_order<3, DryAirPhys<3>>(op);
@@ -802,8 +910,56 @@ int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *in) {
         d.r1 = s.r1;
         d.r2 = s.r2;
         d.mult = s.mult_factor;
-        for (int eq = 0; eq < TPSRHS_MAXEQUATIONS; eq++) d.target[eq] = eq < h->neq ? s.target_U[eq] : 0.0;
-        if (!(d.target[0] > 0.0)) throw std::invalid_argument("tpsrhs_set_forcing: sponge target density must be positive");
+        if (s.solution_type == TPSRHS_SPONGE_MIXEDOUT) {
+          // nodesInMixedOutPlane of the constructor, src/forcing_terms.cpp:553-606
+          if (h->phys.working_fluid != TPSRHS_DRY_AIR || h->nvel != dim)
+            throw Unsupported("mixed-out sponge zone: built for dry air, planar 2-D and 3-D");
+          if (!(s.tol > 0.0)) throw std::invalid_argument("tpsrhs_set_forcing: mixed-out sponge zone needs tol > 0");
+          const Tables1D t = make_tables(h->order, dim, h->nc, h->nc);
+          const int n1 = h->order + 1, npe = (dim == 3) ? n1 * n1 * n1 : n1 * n1, nv = 1 << dim;
+          std::vector<int> nodes;
+          for (int e = 0; e < h->ne; e++) {
+            const double *V = &h->topo.verts[static_cast<size_t>(e) * nv * dim];
+            for (int k = 0; k < npe; k++) {
+              const int idx[3] = {k % n1, (k / n1) % n1, k / (n1 * n1)};
+              double X[3] = {0.0, 0.0, 0.0};
+              for (int v = 0; v < nv; v++) {
+                double shp = 1.0;
+                for (int a = 0; a < dim; a++) shp *= ((v >> a) & 1) ? t.x[idx[a]] : 1.0 - t.x[idx[a]];
+                for (int i = 0; i < dim; i++) X[i] += shp * V[v * dim + i];
+              }
+              double dist_init = 0.0;
+              for (int a = 0; a < dim; a++) dist_init -= d.normal[a] * (X[a] - d.pinit[a]);
+              bool in_plane;
+              if (d.type == TPSRHS_SPONGE_PLANAR) {
+                in_plane = std::fabs(dist_init) < s.tol;
+              } else {
+                double R = 0.0;
+                for (int a = 0; a < dim; a++) {
+                  const double tt = X[a] - d.pinit[a] + dist_init * d.normal[a];
+                  R += tt * tt;
+                }
+                in_plane = std::fabs(std::sqrt(R) - d.r1) < s.tol;
+              }
+              if (in_plane) nodes.push_back(e * npe + k);
+            }
+          }
+          if (nodes.empty() && h->topo.num_shared == 0)
+            throw std::invalid_argument("tpsrhs_set_forcing: no node within tol of the mix-out plane");
+          d.mixed_out = 1;
+          d.n_plane = static_cast<int>(nodes.size());
+          int *dn = dev_upload(nodes);
+          double *ds = dev_alloc<double>(TPSRHS_MAXEQUATIONS + 1);
+          h->d_extra.push_back(dn);
+          h->d_extra.push_back(ds);
+          d.plane_nodes = dn;
+          d.msum = ds;
+          for (int eq = 0; eq < TPSRHS_MAXEQUATIONS; eq++) d.target[eq] = 0.0;
+        } else {
+          if (s.solution_type != TPSRHS_SPONGE_USERDEF) throw std::invalid_argument("tpsrhs_set_forcing: unknown sponge solution type");
+          for (int eq = 0; eq < TPSRHS_MAXEQUATIONS; eq++) d.target[eq] = eq < h->neq ? s.target_U[eq] : 0.0;
+          if (!(d.target[0] > 0.0)) throw std::invalid_argument("tpsrhs_set_forcing: sponge target density must be positive");
+        }
       }
     }
     h->forcing = f;

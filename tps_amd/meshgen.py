@@ -36,6 +36,7 @@ class HostMesh:
     shared_vertices: np.ndarray | None = None  # (nsf, 2^(dim-1)) local ids, sorted by global id
     shared_neighbor_rank: np.ndarray | None = None
     global_elements: np.ndarray | None = None  # (ne,) ids in the unpartitioned mesh
+    elem_size: np.ndarray | None = None  # (ne,) optional mfem::Mesh::GetElementSize(e, 1) (tpsrhs_mesh::elem_size)
 
     @property
     def num_elements(self) -> int:
