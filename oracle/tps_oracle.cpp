@@ -979,6 +979,21 @@ int tpsoracle_point_convective_flux(void *h, const double *state, double *flux) 
   static_cast<Operator *>(h)->fluxes->ComputeConvectiveFluxes(state, flux);
   return 0;
 }
+// the same at position `x` (dim entries) of an element of grid scale `delta`: the sub-grid scale models and the
+// viscous sponge read them (src/fluxes.cpp:223-246)
+int tpsoracle_point_viscous_flux_at(void *h, const double *state, const double *gradUp, const double *x, double delta,
+                                    double *flux) {
+  Operator *op = static_cast<Operator *>(h);
+  double transip[3] = {0, 0, 0};
+  for (int d = 0; d < op->dim; d++) transip[d] = x[d];
+  op->fluxes->ComputeViscousFluxes(state, gradUp, transip, delta, 0.0, flux);
+  return 0;
+}
+int tpsoracle_element_sizes(void *h, double *out) {  // elSize: GetElementSize(e, 1) / order
+  Operator *op = static_cast<Operator *>(h);
+  for (int e = 0; e < op->ne; e++) out[e] = op->elSize[e];
+  return op->ne;
+}
 int tpsoracle_point_viscous_flux(void *h, const double *state, const double *gradUp, double radius, double *flux) {
   double transip[3] = {radius, 0, 0};
   static_cast<Operator *>(h)->fluxes->ComputeViscousFluxes(state, gradUp, transip, 0.0, 0.0, flux);

@@ -55,6 +55,8 @@ def lib():
         L.tpsoracle_point_pressure.argtypes = [vp, _dp]
         L.tpsoracle_point_max_char_speed.argtypes = [vp, _dp]
         L.tpsoracle_point_viscous_flux.argtypes = [vp, _dp, _dp, C.c_double, _dp]
+        L.tpsoracle_point_viscous_flux_at.argtypes = [vp, _dp, _dp, _dp, C.c_double, _dp]
+        L.tpsoracle_element_sizes.argtypes = [vp, _dp]
         L.tpsoracle_point_bdr_viscous_flux.argtypes = [vp, _dp, _dp, C.c_double, _dp, _dp, C.POINTER(C.c_int), _dp]
         L.tpsoracle_point_lf.argtypes = [vp, _dp, _dp, _dp, _dp]
         L.tpsoracle_point_roe.argtypes = [vp, _dp, _dp, _dp, _dp]
@@ -198,6 +200,20 @@ class Oracle:
         out = np.zeros(self.neq * self.dim)
         lib().tpsoracle_point_viscous_flux(self.h, _p(s), _p(g), float(radius), _p(out))
         return out.reshape(self.dim, self.neq)
+
+    def viscous_flux_at(self, state, grad, x, delta):
+        """F_v[eq + d*neq] at position x in an element of grid scale delta (sub-grid scale models, viscous sponge)"""
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        g = np.ascontiguousarray(grad, dtype=np.float64)
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros(self.neq * self.dim)
+        lib().tpsoracle_point_viscous_flux_at(self.h, _p(s), _p(g), _p(xx), float(delta), _p(out))
+        return out
+
+    def element_sizes(self):
+        out = np.zeros(int(self.ndofs))
+        n = lib().tpsoracle_element_sizes(self.h, _p(out))
+        return out[:n]
 
     def bdr_viscous_flux(self, state, grad, normal, prim_flux=None, prim_flux_idxs=None, radius=-1.0):
         s = np.ascontiguousarray(state, dtype=np.float64)
