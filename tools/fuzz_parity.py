@@ -19,10 +19,12 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = 0.0
 t0 = time.time()
 for it in range(ncases):
-    fluid = rng.choice(["dry", "argon3", "argon3n", "argon6", "argon4a", "argon5a", "argon5"],
-                       p=[0.25, 0.25, 0.08, 0.15, 0.09, 0.09, 0.09])
+    fluid = rng.choice(["dry", "argon3", "argon3n", "argon6", "argon4a", "argon5a", "argon5", "argon7", "argon7a", "argon8",
+                        "argon8a"], p=[0.22, 0.2, 0.08, 0.14, 0.06, 0.06, 0.06, 0.05, 0.04, 0.05, 0.04])
     geo = rng.choice(["cyl3d", "box3d", "box2d", "axisym"])
-    order = int(rng.integers(1, (6 if geo != "axisym" else 5) if fluid == "dry" else 4))
+    # plasma: p = 1..3, and p = 4, 5 for the ternary and six-species families
+    pmax = (6 if geo != "axisym" else 5) if fluid == "dry" else (6 if fluid in ("argon3", "argon3n", "argon6") else 4)
+    order = int(rng.integers(1, pmax))
     eq = capi.NS if rng.random() < 0.85 else capi.EULER
     wall = int(rng.choice([capi.INV, capi.SLIP, capi.VISC_ADIAB, capi.VISC_ISOTH]))
     seed = int(rng.integers(1, 1000))
@@ -31,11 +33,22 @@ for it in range(ncases):
     desc = f"{fluid} {geo} p={order} eq={eq} wall={wall} seed={seed}"
     if fluid == "dry":
         ph = capi.dry_air_physics(eq, visc_mult=float(rng.choice([1.0, 50.0, 1000.0])), bulk_visc_mult=float(rng.random()))
+        if eq == capi.NS and geo in ("cyl3d", "box3d", "box2d") and rng.random() < 0.3:  # the LES flavour of the kernels
+            if geo != "box2d":
+                ph.sgs.model_type = int(rng.choice([capi.SGS_NONE, capi.SGS_SMAGORINSKY, capi.SGS_SIGMA]))
+                ph.sgs.model_floor = float(rng.choice([0.0, 0.002]))
+            if geo == "cyl3d" and rng.random() < 0.5:  # (not on the fully periodic boxes: DESIGN.md section 1)
+                vs = ph.visc_sponge
+                vs.enabled, vs.width, vs.ratio = 1, float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 20.0))
+                vs.normal[0], vs.normal[1], vs.point[0], vs.point[1] = rng.normal(), rng.normal(), rng.normal(), rng.normal()
+            desc += f" sgs={ph.sgs.model_type} sponge={ph.visc_sponge.enabled}"
     else:
         two_t = bool(rng.random() < 0.5)
-        if fluid in ("argon6", "argon4a", "argon5a", "argon5"):
-            levels, ambi = {"argon6": (3, False), "argon4a": (1, True), "argon5a": (2, True), "argon5": (2, False)}[fluid]
-            ph = capi.argon_levels_physics(levels, ambi, eq, int(rng.choice([capi.CONSTANT, capi.ARGON_MIXTURE])), two_t,
+        if fluid not in ("argon3", "argon3n"):
+            levels, ambi = {"argon6": (3, False), "argon4a": (1, True), "argon5a": (2, True), "argon5": (2, False),
+                            "argon7": (4, False), "argon7a": (4, True), "argon8": (5, False), "argon8a": (5, True)}[fluid]
+            trs = [capi.CONSTANT] if levels == 5 else [capi.CONSTANT, capi.ARGON_MIXTURE]  # mixture transport: <= 7 species
+            ph = capi.argon_levels_physics(levels, ambi, eq, int(rng.choice(trs)), two_t,
                                            bool(rng.random() < 0.7), radiation=bool(rng.random() < 0.5),
                                            third_order_ke=False)
         else:
