@@ -29,7 +29,9 @@ for it in range(ncases):
     wall = int(rng.choice([capi.INV, capi.SLIP, capi.VISC_ADIAB, capi.VISC_ISOTH]))
     seed = int(rng.integers(1, 1000))
     amp = 0.05 if fluid == "dry" else (0.005 if order == 1 else 0.01)
-    tol = RHS_RTOL * 0.05 / amp
+    # rounding grows with the order (the residual is a difference quotient over a p-times finer node spacing):
+    # (p / 3)^2 above p = 3 -- the sweep of round 2 saw 1.2 x the p <= 3 tolerance at p = 5 in 2 of 4 000 cases
+    tol = RHS_RTOL * 0.05 / amp * max(1.0, (order / 3.0) ** 2)
     desc = f"{fluid} {geo} p={order} eq={eq} wall={wall} seed={seed}"
     if fluid == "dry":
         ph = capi.dry_air_physics(eq, visc_mult=float(rng.choice([1.0, 50.0, 1000.0])), bulk_visc_mult=float(rng.random()))
