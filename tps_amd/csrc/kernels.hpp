@@ -1442,7 +1442,7 @@ __device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const 
 }
 
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::MINW_GRAD) void k_gradient(MeshDev m, typename PH::Params prm,
+__global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(C::DIM, C::P, C::NC)) void k_gradient(MeshDev m, typename PH::Params prm,
                                                        const double *__restrict__ U, const double *__restrict__ TA,
                                                        double *__restrict__ Upout, double *__restrict__ gradUp,
                                                        double *__restrict__ TB) {

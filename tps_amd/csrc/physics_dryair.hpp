@@ -105,6 +105,10 @@ struct DryAirPhys {
   static constexpr bool TWO_STEP = false;  // no state-only closure worth separating from the gradient terms
   struct FluxCoef {};
   static constexpr int MINW_GRAD = TPSRHS_MINW_GRAD, MINW_FLUX = TPSRHS_MINW_FLUX;  // launch-bound waves per SIMD
+  // k_gradient of the p = 3 hex (one wave per element, 10 KB of LDS): capped at 128 VGPRs = four waves per SIMD
+  // (natural allocation 133 = three; measured 0.403 -> 0.382 ms at cfg2 with 4 spilled VGPRs).  Not the LES flavour: its
+  // eddy-viscosity algebra needs the registers.
+  static constexpr int minw_grad(int dim, int p, int nc) { return (dim == 3 && p == 3 && !nc && !LES_) ? 4 : MINW_GRAD; }
   typedef DryAirParams Params;
 
   // One reciprocal of the density per state; everything else multiplies by it (the reference

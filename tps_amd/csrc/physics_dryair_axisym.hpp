@@ -22,6 +22,7 @@ struct DryAirAxiPhys {
   static constexpr bool VISC_USES_GRAD_RHO = false;
   static constexpr int MAX_ORDER = 4;
   static constexpr int MINW_GRAD = 1, MINW_FLUX = 2;
+  static constexpr int minw_grad(int, int, int) { return MINW_GRAD; }
   static constexpr bool LES = false;  // sub-grid scale models / viscous sponge: dry air, planar and 3-D
   static constexpr bool HAS_MIXED_OUT = false;  // mixed-out sponge target: dry air, planar / 3-D
   typedef DryAirParams Params;

@@ -214,6 +214,7 @@ struct PlasmaPhys {
   // registers -- at two the sweeps spilled 150-340 VGPRs to scratch, and two such instantiations returned
   // scheduling-dependent wrong results (DESIGN.md "spilled instantiations")
   static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : TPSRHS_PLASMA_MINW_GRAD3;
+  static constexpr int minw_grad(int, int, int) { return MINW_GRAD; }
   // (2-D / axisymmetric sweeps of four to six species stay at two: 20-200 spilled VGPRs, the state every round-1 and
   // round-2 sweep of the randomised parity driver ran in, and 20 % faster at torch6)
   static constexpr int MINW_FLUX = (NSP_ > 6 || (NSP_ > 3 && DIM_ == 3)) ? 1 : TPSRHS_PLASMA_MINW_FLUX;
