@@ -1,5 +1,5 @@
 """Scratch / spill / register report of every kernel in the built objects (tps_amd/csrc/_obj/*.o), read from the
-code-object metadata -- no recompilation.   python tools/spill_report.py [substring filter]
+code-object metadata -- no recompilation.   python tools/spill_report.py [substring filter] [--all]
 Prints the kernels that use scratch; the last line counts them."""
 import os
 import re
@@ -10,7 +10,9 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJ = os.path.join(ROOT, "tps_amd", "csrc", "_obj")
 LLVM = "/opt/rocm/lib/llvm/bin"
-flt = sys.argv[1] if len(sys.argv) > 1 else ""
+show_all = "--all" in sys.argv  # every matching kernel, not only those with scratch (adds the LDS bytes)
+args = [a for a in sys.argv[1:] if a != "--all"]
+flt = args[0] if args else ""
 total = spilled = 0
 with tempfile.TemporaryDirectory() as tmp:
     for o in sorted(os.listdir(OBJ)):
@@ -35,7 +37,9 @@ with tempfile.TemporaryDirectory() as tmp:
             scratch, vs, ss = get("private_segment_fixed_size"), get("vgpr_spill_count"), get("sgpr_spill_count")
             if scratch or vs:
                 spilled += 1
+            if scratch or vs or show_all:
                 dn = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
                 dn = re.sub(r"\(.*", "", dn).replace("tpsrhs::", "").replace("void ", "")
-                print(f"{o:24s} {dn:100s} vgpr {get('vgpr_count'):3d} scratch {scratch:4d} vgpr_spill {vs:3d} sgpr_spill {ss:3d}")
+                print(f"{o:24s} {dn:100s} vgpr {get('vgpr_count'):3d} scratch {scratch:4d} vgpr_spill {vs:3d} sgpr_spill {ss:3d}"
+                      + (f" lds {get('group_segment_fixed_size'):6d}" if show_all else ""))
 print(f"{spilled} of {total} kernels use scratch")
