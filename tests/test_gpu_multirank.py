@@ -22,7 +22,17 @@ def _free_port():
     return p
 
 
+MIXEDOUT = dict(type=capi.SPONGE_PLANAR, solution_type=capi.SPONGE_MIXEDOUT, normal=(-1.0, 0.0, 0.0), point0=(1.9, 0.0, 0.0),
+                point_init=(1.0, 0.0, 0.0), tol=0.06, mult_factor=2.0, target_U=[])
+
+
 def _case(world, kind):
+    if kind == "mixedout":  # mixed-out sponge zone: the plane sums are added over the ranks (tpsrhs_reduce_fn)
+        full = meshgen.scramble_orientations(meshgen.box_hex(8, 3, 3, lengths=(2.0, 1.0, 0.5)), 3)
+        owner = (np.arange(full.num_elements) * 5 // 3) % world  # the plane nodes are spread over every rank
+        ph = capi.dry_air_physics(capi.NS)
+        Ug = cases.dry_air_state(node_coordinates(full, 2), seed=4, amp=0.1)
+        return full, owner, 2, ph, [], Ug
     if kind == "slab":  # the weak-scaling partition of bench.py: spanwise slabs, both neighbours may be one rank
         full = meshgen.ogrid_cylinder(4, 12, 3 * world, span=2.0 * world)
         order = 3
@@ -95,6 +105,8 @@ def _worker(rank, world, port, q, kind, backend="gloo"):
         else:
             halo = HaloExchange(device=torch.device("cuda", dev))
         op = RHSoperator(part, disc, ph, bcs, device=dev, halo=halo)
+        if kind == "mixedout":
+            op.setForcing(capi.make_forcing(sponge_zones=[MIXEDOUT]))
         x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
         y = torch.empty_like(x)
         if kind.endswith("_nr"):  # second call: the boundary state of the first one is in use
@@ -124,7 +136,7 @@ ADV = (2.0e-5, 3, 0.1, 0.05)  # dt0, steps, CFL, hmin of the advance() leg
 
 
 @pytest.mark.parametrize("world,kind", [(2, "dry_air"), (3, "argon_2T"), (2, "slab"), (4, "slab"), (3, "axisym_2T"),
-                                        (3, "dry_air_nr"), (3, "axisym_slab")])
+                                        (3, "dry_air_nr"), (3, "axisym_slab"), (3, "mixedout")])
 def test_ranks_match_serial_oracle(world, kind):
     _run_ranks(world, kind, "gloo")
 
@@ -151,6 +163,14 @@ def _run_ranks(world, kind, backend):
         o.mult(Ug)
         ref = {"y": o.mult(Ug), "gradUp": o.gradients(), "max_char_speed": o.max_char_speed}
         ref_adv = o.advance(Ug, 0.0, ADV[0], ADV[1], False, ADV[2], ADV[3])
+    elif kind == "mixedout":
+        from oracle_lib import Oracle
+
+        o = Oracle(full, capi.Disc(order, 0, 0, 0, 0), ph, bcs)
+        y_plain = o.mult(Ug)
+        o.set_forcing(capi.make_forcing(sponge_zones=[MIXEDOUT]))
+        ref = {"y": o.mult(Ug), "gradUp": o.gradients(), "max_char_speed": o.max_char_speed}
+        assert np.abs(ref["y"] - y_plain).max(axis=1).min() > 0.0  # the zone is active in every equation
     else:
         ref = oracle_mult(full, capi.Disc(order, 0, 0, 1 if kind.startswith("axisym") else 0, 0), ph, bcs, Ug)
     ctx = mp.get_context("spawn")
