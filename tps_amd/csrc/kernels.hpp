@@ -2355,9 +2355,18 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
     // software pipeline over the direction pairs: the traces of pair d+1 are in flight while pair d runs
     NbTraces<C, NEQ> ta1, ta2;
     NbFlux<C, NEQ> tb1, tb2;
-    issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta1, tid);
-    issue_visc_traces<C, 1, NEQ>(sFI, e0, TB, tb1, tid);
+    // (not in 2-D with more than 8 equations: the prefetched pair costs 60+ registers of a kernel that already
+    // spills -- torch6 k_flux 1.41 -> 1.28 ms without it)
+    constexpr bool PIPE = !(DIM == 2 && NEQ > 8);
+    if (PIPE) {
+      issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta1, tid);
+      issue_visc_traces<C, 1, NEQ>(sFI, e0, TB, tb1, tid);
+    }
     face_flux_dir<C, PH, 0>(m, prm, e0, sU, sX, sY, sV, tab, ct, ta0, tb0, node_on, le_n, idx, z, tid);
+    if (!PIPE) {
+      issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta1, tid);
+      issue_visc_traces<C, 1, NEQ>(sFI, e0, TB, tb1, tid);
+    }
     FSTAMP(4);
     if (DIM == 3) {
       issue_neighbour_traces<C, (DIM == 3 ? 2 : 0), NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta2, tid);
