@@ -437,6 +437,22 @@ typedef struct tpsrhs_forcing {
  * SpongeZone and HeatSource.  NULL removes them. */
 int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *forcing);
 
+/* MixingLengthTransport (src/mixing_length_transport.cpp:44-131; [flow] useMixingLength, flow/mixing-length/...,
+ * src/M2ulPhyS.cpp:265-277, 2701-2708): an algebraic eddy viscosity rho l^2 |S| with l = min(0.41 d, max_mixing_length)
+ * on top of the molecular transport of the flux (viscosity, bulk viscosity, heavy-species conductivity; not the
+ * species diffusivities, not the source terms), d = the wall-distance grid function `distance_` of the reference:
+ * `distance` is its DEVICE array (NDofs doubles, owned by the caller, read at every Mult).  NULL switches the model off.
+ * Built for the 2-D kernels (planar and axisymmetric mixtures, axisymmetric dry air: the formulations of the reference's
+ * inputs that use it, test/inputs/plasma.ini:48, pipe.axisym.mix.ini:19); 3-D and planar dry air:
+ * TPSRHS_ERR_UNSUPPORTED. */
+typedef struct tpsrhs_mixing_length { /* mixingLengthTransportData (src/dataStructures.hpp:548-554) */
+  double max_mixing_length; /* 0 turns the model off, as in the reference */
+  double pr_ratio;          /* flow/mixing-length/Pr_ratio (`Prt_`), default 1 */
+  double lewis;             /* `Let_`: read by the reference, not used by its flux transport */
+  double bulk_multiplier;   /* bulk eddy viscosity = bulk_multiplier * mu_t */
+} tpsrhs_mixing_length;
+int tpsrhs_set_mixing_length(tpsrhs_handle h, const double *distance, const tpsrhs_mixing_length *params);
+
 /* JouleHeating (src/forcing_terms.cpp:443-471): `joule_heating` is the DEVICE array of the
  * `joule_heating_` grid function (NDofs doubles, owned by the caller, read at every Mult; the EM solver
  * refreshes it between steps).  Positive entries are added to the total-energy equation and, for a

@@ -305,6 +305,73 @@ class DryAirTransport : public TransportProperties {
 };
 
 // ------------------------------------------------------------------------------------------
+// MixingLengthTransport (src/mixing_length_transport.cpp:44-169): the molecular transport plus an algebraic eddy
+// viscosity in the flux properties; the source properties are the molecular ones
+// ------------------------------------------------------------------------------------------
+class MixingLengthTransport : public TransportProperties {
+ public:
+  TransportProperties *molecular_transport_;
+  double max_mixing_length_, Prt_, Let_, bulk_mult_;
+  MixingLengthTransport(GasMixture *mix, const tpsrhs_mixing_length &in, TransportProperties *molecular)
+      : TransportProperties(mix),
+        molecular_transport_(molecular),
+        max_mixing_length_(in.max_mixing_length),
+        Prt_(in.pr_ratio),
+        Let_(in.lewis),
+        bulk_mult_(in.bulk_multiplier) {}
+  void ComputeFluxTransportProperties(const double *state, const double *gradUp, const double *Efield, double radius,
+                                      double distance, double *transportBuffer, double *diffusionVelocity) override {
+    molecular_transport_->ComputeFluxTransportProperties(state, gradUp, Efield, radius, distance, transportBuffer,
+                                                         diffusionVelocity);
+    const double kappa = transportBuffer[HEAVY_THERMAL_CONDUCTIVITY];
+    const double mu = transportBuffer[VISCOSITY];
+    const double cp_over_Pr = kappa / mu;
+    double primitiveState[MAXEQ];
+    mixture->GetPrimitivesFromConservatives(state, primitiveState);
+    const double rho = state[0];
+    double ur = 0;
+    if (nvel != dim) ur = primitiveState[1];
+    double S = 0;
+    for (int i = 0; i < dim; i++)
+      for (int j = 0; j < dim; j++) {
+        const double ui_xj = gradUp[(1 + i) + j * num_equation];
+        const double uj_xi = gradUp[(1 + j) + i * num_equation];
+        const double Sij = 0.5 * (ui_xj + uj_xi);
+        S += 2 * Sij * Sij;
+      }
+    if (nvel != dim) {
+      const double ut = primitiveState[3];
+      const double ut_r = gradUp[3 + 0 * num_equation];
+      const double ut_z = gradUp[3 + 1 * num_equation];
+      double Szx = 0.5 * ut_r;
+      if (radius > 0) Szx -= 0.5 * ut / radius;
+      const double Szy = 0.5 * ut_z;
+      double Szz = 0.0;
+      if (radius > 0) Szz += ur / radius;
+      S += 2 * (2 * Szx * Szx + 2 * Szy * Szy + Szz * Szz);
+    }
+    S = std::sqrt(S);
+    double mixing_length = 0.41 * distance;
+    if (mixing_length > max_mixing_length_) mixing_length = max_mixing_length_;
+    const double mut = rho * mixing_length * mixing_length * S;
+    transportBuffer[VISCOSITY] += mut;
+    transportBuffer[BULK_VISCOSITY] += bulk_mult_ * mut;
+    const double Pr_over_Prt = Prt_;
+    const double kappat = mut * cp_over_Pr * Pr_over_Prt;
+    transportBuffer[HEAVY_THERMAL_CONDUCTIVITY] += kappat;
+  }
+  void ComputeSourceTransportProperties(const double *state, const double *Up, const double *gradUp, const double *Efield,
+                                        double distance, double *globalTransport, double *speciesTransport,
+                                        double *diffusionVelocity, double *n_sp) override {
+    molecular_transport_->ComputeSourceTransportProperties(state, Up, gradUp, Efield, distance, globalTransport,
+                                                           speciesTransport, diffusionVelocity, n_sp);
+  }
+  void GetViscosities(const double *conserved, const double *primitive, double *visc) override {
+    molecular_transport_->GetViscosities(conserved, primitive, visc);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
 // Fluxes (src/fluxes.cpp)
 // ------------------------------------------------------------------------------------------
 class Fluxes {

@@ -47,6 +47,8 @@ struct Operator {
   std::vector<std::vector<int64_t>> spongePlaneNodes;  // nodesInMixedOutPlane (:545-606)
   std::vector<std::vector<int64_t>> heatNodes;         // nodeList_ of each HeatSource (:890-917)
   std::vector<double> joule;                           // joule_heating_ grid function (empty: none)
+  std::vector<double> distance;                        // distance_ grid function (empty: none)
+  std::unique_ptr<tpsoracle::MixingLengthTransport> mixlen;  // wraps `transport` when useMixingLength (M2ulPhyS.cpp:265-277)
 
   RuleND volRule;   // order 2p
   RuleND faceRule;  // order OrderW + 2p on the reference segment/square
@@ -451,8 +453,13 @@ struct Operator {
           interpGrad(F.e2, shape2.data(), g2);
           rsolver->Eval(u1, u2, fp.nor, fluxN);  // src/face_integrator.cpp:324
           double v1[MAXEQ * MAXDIM], v2[MAXEQ * MAXDIM];
-          fluxes->ComputeViscousFluxes(u1, g1, transip, elSize[F.e1], 0.0, v1);  // delta1, delta2: face_integrator.cpp:253-276
-          fluxes->ComputeViscousFluxes(u2, g2, transip, elSize[F.e2], 0.0, v2);
+          double d1 = 0, d2 = 0;  // the distance function at the point, each side with its own shape functions (:303-308)
+          if (!distance.empty()) {
+            for (int k = 0; k < dof; k++) d1 += distance[static_cast<int64_t>(F.e1) * dof + k] * shape1[k];
+            for (int k = 0; k < dof; k++) d2 += distance[static_cast<int64_t>(F.e2) * dof + k] * shape2[k];
+          }
+          fluxes->ComputeViscousFluxes(u1, g1, transip, elSize[F.e1], d1, v1);  // delta1, delta2: face_integrator.cpp:253-276
+          fluxes->ComputeViscousFluxes(u2, g2, transip, elSize[F.e2], d2, v2);
           for (int i = 0; i < neq * dim; i++) v1[i] = -0.5 * (v1[i] + v2[i]);
           for (int eq = 0; eq < neq; eq++)
             for (int d = 0; d < dim; d++) fluxN[eq] += v1[eq + d * neq] * fp.nor[d];
@@ -465,7 +472,10 @@ struct Operator {
               el1[k + eq * dof] -= shape1[k] * fluxN[eq];
             }
         } else {
-          bcs.at(F.attr)->computeBdrFlux(fp.nor, u1, g1, transip, elSize[F.e1], 0.0, fluxN,
+          double d1 = 0;  // src/BCintegrator.cpp:409-412
+          if (!distance.empty())
+            for (int k = 0; k < dof; k++) d1 += distance[static_cast<int64_t>(F.e1) * dof + k] * shape1[k];
+          bcs.at(F.attr)->computeBdrFlux(fp.nor, u1, g1, transip, elSize[F.e1], d1, fluxN,
                                          nrFaceOrdinal.empty() || nrFaceOrdinal[f] < 0 ? -1 : nrFaceOrdinal[f] * faceRule.npts + q);
           for (int eq = 0; eq < neq; eq++) fluxN[eq] *= fp.w;
           if (axisym)
@@ -508,7 +518,7 @@ struct Operator {
       for (int d = 0; d < dim; d++) xyz[d] = coords[i + d * N];
       fluxes->ComputeConvectiveFluxes(state, f);
       if (phys.eq_system != TPSRHS_EULER) {
-        fluxes->ComputeViscousFluxes(state, g, xyz, elSize[i / dof], 0.0, fv);
+        fluxes->ComputeViscousFluxes(state, g, xyz, elSize[i / dof], distance.empty() ? 0.0 : distance[i], fv);
         for (int k = 0; k < neq * dim; k++) f[k] -= fv[k];
       }
       for (int d = 0; d < dim; d++)
@@ -882,6 +892,19 @@ int tpsoracle_set_forcing(void *h, const tpsrhs_forcing *f) {
     return 1;
   }
 }
+int tpsoracle_set_mixing_length(void *h, const double *dist, const tpsrhs_mixing_length *in) {  // HOST array, copied
+  Operator *op = static_cast<Operator *>(h);
+  if (dist && in) {
+    op->distance.assign(dist, dist + op->ndofs);
+    op->mixlen.reset(new tpsoracle::MixingLengthTransport(op->mixture.get(), *in, op->transport.get()));
+    op->fluxes->transport = op->mixlen.get();
+  } else {
+    op->distance.clear();
+    op->fluxes->transport = op->transport.get();
+    op->mixlen.reset();
+  }
+  return 0;
+}
 int tpsoracle_set_joule_heating(void *h, const double *jh) {  // HOST array, copied; NULL disables
   Operator *op = static_cast<Operator *>(h);
   if (jh)
@@ -993,6 +1016,13 @@ int tpsoracle_element_sizes(void *h, double *out) {  // elSize: GetElementSize(e
   Operator *op = static_cast<Operator *>(h);
   for (int e = 0; e < op->ne; e++) out[e] = op->elSize[e];
   return op->ne;
+}
+// ... at wall distance `distance` (the mixing-length model reads it)
+int tpsoracle_point_viscous_flux_dist(void *h, const double *state, const double *gradUp, double radius, double distance,
+                                      double *flux) {
+  double transip[3] = {radius, 0, 0};
+  static_cast<Operator *>(h)->fluxes->ComputeViscousFluxes(state, gradUp, transip, 0.0, distance, flux);
+  return 0;
 }
 int tpsoracle_point_viscous_flux(void *h, const double *state, const double *gradUp, double radius, double *flux) {
   double transip[3] = {radius, 0, 0};

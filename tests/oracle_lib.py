@@ -121,6 +121,18 @@ class Oracle:
         if st != 0:
             raise RuntimeError("oracle: " + lib().tpsoracle_last_error().decode())
 
+    def set_mixing_length(self, distance, max_mixing_length=0.0, pr_ratio=1.0, lewis=1.0, bulk_multiplier=0.0):
+        """MixingLengthTransport around the molecular transport; distance: host array of NDofs entries or None"""
+        L = lib()
+        L.tpsoracle_set_mixing_length.argtypes = [C.c_void_p, _dp, C.POINTER(capi.MixingLength)]
+        if distance is None:
+            L.tpsoracle_set_mixing_length(self.h, None, None)
+            return
+        d = np.ascontiguousarray(distance, dtype=np.float64)
+        assert d.size == self.ndofs
+        prm = capi.MixingLength(float(max_mixing_length), float(pr_ratio), float(lewis), float(bulk_multiplier))
+        L.tpsoracle_set_mixing_length(self.h, _p(d), C.byref(prm))
+
     def set_joule_heating(self, jh):
         if jh is None:
             lib().tpsoracle_set_joule_heating(self.h, None)

@@ -99,6 +99,11 @@ class Radiation(C.Structure):
     _fields_ = [("model", C.c_int), ("nec_table", Table)]
 
 
+class MixingLength(C.Structure):  # mixingLengthTransportData, [flow/mixing-length]
+    _fields_ = [("max_mixing_length", C.c_double), ("pr_ratio", C.c_double), ("lewis", C.c_double),
+                ("bulk_multiplier", C.c_double)]
+
+
 class Sgs(C.Structure):  # [flow] sgsModel / sgsModelConstant / sgsFloor
     _fields_ = [("model_type", C.c_int), ("model_const", C.c_double), ("model_floor", C.c_double)]
 
@@ -566,6 +571,7 @@ def load():
     lib.tpsrhs_set_dt.argtypes = [vp, C.c_double]
     lib.tpsrhs_set_forcing.argtypes = [vp, C.POINTER(Forcing)]
     lib.tpsrhs_set_joule_heating.argtypes = [vp, C.c_void_p]
+    lib.tpsrhs_set_mixing_length.argtypes = [vp, C.c_void_p, C.POINTER(MixingLength)]
     lib.tpsrhs_face_tables.restype = C.c_int
     lib.tpsrhs_face_tables.argtypes = [C.POINTER(Mesh), C.c_int, C.POINTER(BC), vp, vp, vp, vp]
     lib.tpsrhs_status_string.restype = C.c_char_p
@@ -581,7 +587,7 @@ EXPORTED_SYMBOLS = [
     "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
     "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_mult_times", "tpsrhs_kernel_bytes",
     "tpsrhs_eval_pointwise", "tpsrhs_table_eval", "tpsrhs_math_eval", "tpsrhs_face_tables",
-    "tpsrhs_rk4_step", "tpsrhs_advance", "tpsrhs_set_dt", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_status_string",
+    "tpsrhs_rk4_step", "tpsrhs_advance", "tpsrhs_set_dt", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_set_mixing_length", "tpsrhs_status_string",
     "tpsrhs_last_error", "tpsrhs_version",
 ]
 

@@ -210,6 +210,7 @@ struct MeshDev {
   const double *verts;         // [ne][NV][DIM] lexicographic corners
   const int2 *face_info;       // [ne*NFACES] {neighbour slot | -(bc+1), orientation code}
   const double *minv;          // non-collocated variant: [ne][NPE][NPE] inverse element mass matrices (symmetric)
+  MixLenDev ml;                // MixingLengthTransport (2-D kernels): wall-distance grid function, or distance = NULL
 };
 
 // Face records of the block's elements -> LDS, once, so that no later stage has a global load on the
@@ -1192,10 +1193,17 @@ __device__ inline void face_geometry_rt(int d, const double *verts, const Tab<C>
 }
 // ... and the point physics on them.  `d` is a run-time value here so that physics with a large body
 // (PH::HEAVY: plasma transport) is instantiated once per kernel, not once per direction pair.
+// the wall distance at a lane's face quadrature points (mixing-length model), by value
+template <int ROUNDS>
+struct FaceDist {
+  bool on = false;
+  double d[ROUNDS] = {};
+};
 template <class C, class PH, bool BOTH = false>
 __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0, int d,
                                    double (&v)[BOTH ? C::Q2_ROUNDS : C::Q_ROUNDS][GradLds<C, PH>::NVF], const double *sV,
-                                   const Tab<C> &tab, double *__restrict__ TB, int tid) {
+                                   const Tab<C> &tab, double *__restrict__ TB, int tid,
+                                   const FaceDist<BOTH ? C::Q2_ROUNDS : C::Q_ROUNDS> &dq = FaceDist<BOTH ? C::Q2_ROUNDS : C::Q_ROUNDS>()) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   constexpr int ROUNDS = BOTH ? C::Q2_ROUNDS : C::Q_ROUNDS, ITEMS = BOTH ? C::TQ2 : C::TQ;
 #pragma unroll
@@ -1216,7 +1224,9 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const type
     PH::clamp_species(v[rd]);
     double n[DIM], wq, Xq[DIM];
     face_geometry_rt<C>(d, &sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
-    if constexpr (PH::HEAVY) {
+    if constexpr (PH::HEAVY && DIM == 2) {  // dq: the wall distance at the points (mixing-length model) or NULL
+      PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, PH::AXISYM ? Xq[0] : -1.0, fn, dq.on ? eddy_at(m.ml, dq.d[rd]) : eddy_off());
+    } else if constexpr (PH::HEAVY) {
       PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, PH::AXISYM ? Xq[0] : -1.0, fn);
     } else if constexpr (PH::LES) {  // delta1 of src/face_integrator.cpp:253, transip of :333
       PointCtx pc;
@@ -1381,7 +1391,7 @@ template <class C, class PH>
 __device__ inline void visc_phase_2d(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
                                      const double *sU, const double *g, bool node_on, double *sJ, double *Tb,
                                      const double *sV, const Tab<C> &tab, const Tables1D &ct, double *__restrict__ TB,
-                                     int tid) {
+                                     int tid, const double *sDist = nullptr) {
   static_assert(C::DIM == 2, "2-D only");
   constexpr int NEQ = PH::NEQ;
   typedef GradLds<C, PH> L;
@@ -1410,6 +1420,30 @@ __device__ inline void visc_phase_2d(const MeshDev &m, const int2 *sFI, const ty
     block_sync<C::BLOCK>();
   };
   chunk(std::integral_constant<int, NEQ>(), sU, 0);
+  // mixing-length model: the nodal wall distance interpolated to the face points like a field
+  // (src/face_integrator.cpp:303-308, src/BCintegrator.cpp:409-412); block-uniform branch
+  FaceDist<C::Q2_ROUNDS> dq;
+  dq.on = sDist != nullptr;
+  if (sDist) {
+    trace_lines<C, 0, 1>(sDist, Tb, ct, tid);
+    trace_lines<C, 1, 1>(sDist, Tb + L::CH * C::TN, ct, tid);
+    block_sync<C::BLOCK>();
+#pragma unroll
+    for (int rd = 0; rd < C::Q2_ROUNDS; rd++) {
+      int item = tid + rd * C::BLOCK;
+      dq.d[rd] = 0.0;
+      if (item < C::TQ2) {
+        const int d = item / C::TQ;
+        item -= d * C::TQ;
+        const int pf = item / C::NQ, q = item - pf * C::NQ;
+        double bq[C::N1];
+#pragma unroll
+        for (int a = 0; a < C::N1; a++) bq[a] = tab.B[q * C::N1 + a];
+        dq.d[rd] = interp2_point<C>(Tb + d * (L::CH * C::TN), nullptr, bq, pf, q);
+      }
+    }
+    block_sync<C::BLOCK>();
+  }
 #pragma unroll
   for (int c = 1; c <= 2; c++) {
     const double *src;
@@ -1429,7 +1463,7 @@ __device__ inline void visc_phase_2d(const MeshDev &m, const int2 *sFI, const ty
     }
     chunk(std::integral_constant<int, NG>(), src, c * NEQ + G0);
   }
-  visc_points<C, PH, true>(m, sFI, prm, e0, 0, v, sV, tab, TB, tid);
+  visc_points<C, PH, true>(m, sFI, prm, e0, 0, v, sV, tab, TB, tid, dq);
 }
 template <class C, class PH, int D>
 __device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
@@ -1597,7 +1631,19 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
   // ---- viscous normal-flux traces (T chunk in the sUp region: the nodal Up values are dead)
   if (!(TPSRHS_ABLATE & 16)) {
     if constexpr (DIM == 2) {
-      visc_phase_2d<C, PH>(m, sFI, prm, e0, sU, g, node_on, sJ, sUp, sV, tab, ct, TB, tid);
+      if constexpr (PH::HEAVY) {
+        // mixing-length model (tpsrhs_set_mixing_length): the nodal wall distance of the block's elements
+        __shared__ double sDist[C::NODES];
+        const bool ml_on = m.ml.distance != nullptr;  // uniform over the grid
+        if (ml_on) {
+          if (tid < C::NODES)
+            sDist[tid] = node_on ? m.ml.distance[static_cast<int64_t>(e0 + le_n) * C::NPE + nd] : 0.0;
+          block_sync<C::BLOCK>();
+        }
+        visc_phase_2d<C, PH>(m, sFI, prm, e0, sU, g, node_on, sJ, sUp, sV, tab, ct, TB, tid, ml_on ? sDist : nullptr);
+      } else {
+        visc_phase_2d<C, PH>(m, sFI, prm, e0, sU, g, node_on, sJ, sUp, sV, tab, ct, TB, tid);
+      }
     } else if constexpr (PH::TWO_STEP && C::Q_ROUNDS == 1 && !(TPSRHS_ABLATE & 256)) {
       visc_phase_heavy3d<C, PH>(m, sFI, prm, e0, sU, sJ, sUp, sW, sV, tab, ct, TB, tid STAMP_ARG);
     } else if constexpr (PH::HEAVY) {
@@ -2240,7 +2286,14 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
 #pragma unroll
         for (int k = 0; k < NEQ * DIM; k++) F[k] = uc[k % NEQ] + gr[k];
       } else {
-        if constexpr (PH::TWO_STEP)
+        if constexpr (PH::HEAVY && DIM == 2) {  // (+ the mixing-length eddy viscosity when a distance function is set)
+          const bool ml_on = m.ml.distance != nullptr;
+          const EddyCtx ec = eddy_at(m.ml, ml_on ? m.ml.distance[static_cast<int64_t>(e0 + le_n) * C::NPE + nd] : 0.0);
+          if constexpr (PH::TWO_STEP)
+            PH::total_flux(prm, uc, st, fc, gr, PH::AXISYM ? radius : -1.0, F, ec);
+          else
+            PH::total_flux(prm, uc, st, gr, radius, F, ec);
+        } else if constexpr (PH::TWO_STEP)
           PH::total_flux(prm, uc, st, fc, gr, PH::AXISYM ? radius : -1.0, F);
         else if constexpr (PH::AXISYM)
           PH::total_flux(prm, uc, st, gr, radius, F);

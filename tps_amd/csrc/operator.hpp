@@ -76,6 +76,7 @@ struct tpsrhs_operator {
   double *d_xh = nullptr, *d_yh = nullptr;  // staging for tpsrhs_mult_host
   double *d_rk = nullptr;                   // k | y | z of tpsrhs_rk4_step
   unsigned long long *d_nan = nullptr;
+  MixLenDev mixlen = {nullptr, 0.0, 1.0, 0.0};  // MixingLengthTransport (tpsrhs_set_mixing_length); distance NULL: off
   ForcingDev forcing = {};                  // host copy of the optional forcing terms (tpsrhs_set_forcing / _joule_heating)
   ForcingDev *d_forcing = nullptr;
   bool forcing_active = false;
@@ -135,6 +136,7 @@ struct tpsrhs_operator {
     m.verts = d_verts;
     m.face_info = d_face_info;
     m.minv = d_minv;
+    m.ml = mixlen;
     return m;
   }
   ~tpsrhs_operator() {

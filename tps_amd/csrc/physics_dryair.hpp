@@ -51,6 +51,54 @@ struct DryAirParams {
   BcDev bc[MAXBC];
 };
 
+// MixingLengthTransport (src/mixing_length_transport.cpp:62-131): the wall-distance grid function and the model's
+// constants (tpsrhs_set_mixing_length); `distance` NULL = off.  Read by the 2-D kernels.
+struct MixLenDev {
+  const double *distance;  // [NDofs] device, owned by the caller
+  double lmax, prt, bulk;
+};
+struct EddyCtx {  // what a closure needs of it at one point, by value: the constants and the (interpolated) distance
+  bool on;
+  double dist, lmax, prt, bulk;
+};
+__device__ inline EddyCtx eddy_off() { return EddyCtx{false, 0.0, 0.0, 0.0, 0.0}; }
+__device__ inline EddyCtx eddy_at(const MixLenDev &ml, double dist) {
+  return EddyCtx{ml.distance != nullptr, dist, ml.lmax, ml.prt, ml.bulk};
+}
+// eddy viscosity rho l^2 |S| added to the molecular viscosity / raw bulk viscosity / heavy conductivity of a point
+// (g[eq + d*NEQ]: the primitive gradient; NVEL = 3 with DIM = 2: the axisymmetric strain terms)
+template <int DIM, int NVEL, int NEQ>
+__device__ inline void add_mixing_length(const EddyCtx &ec, const double *U, const double *g, double radius, double &visc,
+                                         double &bulk, double &k) {
+  if (!ec.on) return;
+  const double cp_over_pr = k / visc;
+  const double rho = U[0];
+  double S = 0.0;
+#pragma unroll
+  for (int i = 0; i < DIM; i++)
+#pragma unroll
+    for (int j = 0; j < DIM; j++) {
+      const double Sij = 0.5 * (g[(1 + i) + j * NEQ] + g[(1 + j) + i * NEQ]);
+      S += 2 * Sij * Sij;
+    }
+  if constexpr (NVEL != DIM) {
+    const double ur = U[1] / rho, ut = U[3] / rho;
+    double Szx = 0.5 * g[3 + 0 * NEQ];
+    if (radius > 0) Szx -= 0.5 * ut / radius;
+    const double Szy = 0.5 * g[3 + 1 * NEQ];
+    double Szz = 0.0;
+    if (radius > 0) Szz += ur / radius;
+    S += 2 * (2 * Szx * Szx + 2 * Szy * Szy + Szz * Szz);
+  }
+  S = sqrt(S);
+  double l = 0.41 * ec.dist;
+  if (l > ec.lmax) l = ec.lmax;
+  const double mut = rho * l * l * S;
+  visc += mut;
+  bulk += ec.bulk * mut;
+  k += mut * cp_over_pr * ec.prt;
+}
+
 // Where a point sits, for the closures that depend on it (LES flavour): grid scale of its element and position
 struct PointCtx {
   double delta;

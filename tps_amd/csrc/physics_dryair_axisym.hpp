@@ -98,10 +98,11 @@ struct DryAirAxiPhys {
   }
   // Fv(U, g) . n with the axisymmetric stresses; `zero_heat` drops the conduction term (adiabatic wall)
   __device__ static inline void visc_normal_flux(const Params &p, const double *U, const double *g, const double *n,
-                                                 double radius, bool zero_heat, double *Fn) {
+                                                 double radius, bool zero_heat, double *Fn, const EddyCtx &ec = eddy_off()) {
     const State s = make_state(p, U);
     double visc, bulkv, k;
     transport(p, s, visc, bulkv, k);
+    add_mixing_length<DIM, NVEL, NEQ>(ec, U, g, radius, visc, bulkv, k);
     const double bulk = bulkv - 2. / 3. * visc;
     double divV = g[1 + 0 * NEQ] + g[2 + 1 * NEQ];
     if (radius > 0) divV += s.vel[0] / radius;
@@ -128,7 +129,7 @@ struct DryAirAxiPhys {
     Fn[ITH] = e;
   }
   __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const double *g,
-                                           double radius, double *F) {
+                                           double radius, double *F, const EddyCtx &ec = eddy_off()) {
     const double H = U[ITH] + s.p;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
@@ -143,7 +144,7 @@ struct DryAirAxiPhys {
     for (int d = 0; d < DIM; d++) {
       const double nd[DIM] = {d == 0 ? 1.0 : 0.0, d == 1 ? 1.0 : 0.0};
       double fv[NEQ];
-      visc_normal_flux(p, U, g, nd, radius, false, fv);
+      visc_normal_flux(p, U, g, nd, radius, false, fv, ec);
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) F[eq + d * NEQ] -= fv[eq];
     }
@@ -187,16 +188,20 @@ struct DryAirAxiPhys {
   }
   // the viscous trace of one face quadrature point (see PlasmaPhys::visc_trace)
   __device__ static inline void visc_trace(const Params &p, int nb, const double *U, const double *g, const double *n,
-                                           double radius, double *fn) {
+                                           double radius, double *fn, const EddyCtx &ec = eddy_off()) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) fn[eq] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
     if (nb >= 0) {
-      visc_normal_flux(p, U, g, n, radius, false, fn);
+      visc_normal_flux(p, U, g, n, radius, false, fn, ec);
       return;
     }
     const BcDev &bc = p.bc[-nb - 1];
     if (bc.category != TPSRHS_WALL || bc.type == TPSRHS_SLIP) return;  // slip wall: Riemann flux only (src/wallBC.cpp:326-428)
+    // the wall routines hand the flux class distance 0 (viscous walls, src/wallBC.cpp:441-536) or the interpolated
+    // distance (inviscid wall, :309-313)
+    EddyCtx wec = ec;
+    if (bc.type != TPSRHS_INV) wec.dist = 0.0;
     double Uw[NEQ], f[NEQ];
     bool adiabatic = false;
     if (bc.type == TPSRHS_INV) {
@@ -214,10 +219,10 @@ struct DryAirAxiPhys {
         Uw[ITH] = p.Rg / (p.gamma - 1.0) * U[0] * bc.data[0];
       }
     }
-    visc_normal_flux(p, Uw, g, n, radius, adiabatic, f);
+    visc_normal_flux(p, Uw, g, n, radius, adiabatic, f, wec);
 #pragma unroll
     for (int eq = 1; eq < NEQ; eq++) fn[eq] = -0.5 * f[eq];
-    visc_normal_flux(p, U, g, n, radius, false, f);
+    visc_normal_flux(p, U, g, n, radius, false, f, wec);
 #pragma unroll
     for (int eq = 1; eq < NEQ; eq++) fn[eq] -= 0.5 * f[eq];
   }

@@ -767,7 +767,7 @@ struct PlasmaPhys {
   // ComputeViscousFluxes, src/fluxes.cpp:178-335 (3-D / planar 2-D part); Fv[eq + d*NEQ]
   // (the state-only closure `c` -- transport_coeffs -- is evaluated by the caller, before it touches the gradient)
   __device__ static inline void visc_flux(const Params &p, const double *U, const State &s, const TCoef &c,
-                                          const double *g, double radius, double *Fv) {
+                                          const double *g, double radius, double *Fv, const EddyCtx &ec = eddy_off()) {
 #pragma unroll
     for (int i = 0; i < NEQ * DIM; i++) Fv[i] = 0.0;
     if (p.eq_system == TPSRHS_EULER) return;
@@ -778,6 +778,7 @@ struct PlasmaPhys {
     t.bulk = c.bulk;
     t.k = c.k;
     t.ke = c.ke;
+    if constexpr (DIM == 2) add_mixing_length<DIM, NVEL, NEQ>(ec, U, g, radius, t.visc, t.bulk, t.k);
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
       double gs[NEQ], V[NSP];
@@ -841,9 +842,9 @@ struct PlasmaPhys {
     transport_coeffs(p, U, s.Th, s.Te, true, c);
   }
   __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const FluxCoef &c,
-                                           const double *g, double radius, double *F) {
+                                           const double *g, double radius, double *F, const EddyCtx &ec = eddy_off()) {
     double Fv[NEQ * DIM];
-    visc_flux(p, U, s, c, g, radius, Fv);
+    visc_flux(p, U, s, c, g, radius, Fv, ec);
     const double H = U[ITH] + s.p;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
@@ -878,10 +879,11 @@ struct PlasmaPhys {
     return w;
   }
   __device__ static inline void visc_normal_flux(const Params &p, const double *U, const double *g, const double *n,
-                                                 double radius, const WallFlux &w, double *Fn) {
+                                                 double radius, const WallFlux &w, double *Fn, const EddyCtx &ec = eddy_off()) {
     const State s = make_state(p, U);
     Trans t;
     transport(p, U, s.Th, s.Te, g, !w.species, t);
+    if constexpr (DIM == 2) add_mixing_length<DIM, NVEL, NEQ>(ec, U, g, radius, t.visc, t.bulk, t.k);
     double h[NSP], Vn[NSP];
     enthalpies(p, s, h);
 #pragma unroll
@@ -1240,17 +1242,21 @@ struct PlasmaPhys {
   // evaluate the first before they bring the gradient into registers (flux_coeffs / visc_point_coeffs)
   static constexpr bool TWO_STEP = true;
   __device__ static inline void visc_trace(const Params &p, int nb, const double *U, const double *g, const double *n,
-                                           double radius, double *fn) {
+                                           double radius, double *fn, const EddyCtx &ec = eddy_off()) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) fn[eq] = 0.0;
     const int npass = visc_passes(p, nb);
+    // mixing length: the wall routines hand the flux class distance 0 (viscous walls, src/wallBC.cpp:441-536) or the
+    // interpolated distance (inviscid wall, :309-313)
+    EddyCtx wec = ec;
+    if (DIM == 2 && nb < 0 && p.bc[nb < 0 ? -nb - 1 : 0].type != TPSRHS_INV) wec.dist = 0.0;
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < npass; pass++) {
       double Us[NEQ];
       WallFlux w;
       visc_pass_state(p, nb, pass, U, n, Us, w);
       double f[NEQ];
-      visc_normal_flux(p, Us, g, n, radius, w, f);
+      visc_normal_flux(p, Us, g, n, radius, w, f, wec);
       if (nb >= 0) {
 #pragma unroll
         for (int eq = 0; eq < NEQ; eq++) fn[eq] = f[eq];

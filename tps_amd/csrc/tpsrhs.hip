@@ -968,6 +968,28 @@ int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *in) {
   });
 }
 
+int tpsrhs_set_mixing_length(tpsrhs_handle h, const double *distance, const tpsrhs_mixing_length *in) {
+  if (!h) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_set_mixing_length: NULL handle");
+  return guarded([&] {
+    if (distance) {
+      if (!in) throw std::invalid_argument("tpsrhs_set_mixing_length: parameters missing");
+      // the 2-D kernels with the `heavy` closure interface: mixtures (planar, axisymmetric), axisymmetric dry air
+      const bool plasma = h->phys.working_fluid == TPSRHS_USER_DEFINED;
+      if (h->dim != 2 || !(plasma || h->nvel == 3))
+        throw Unsupported("mixing-length model: built for the 2-D kernels (mixtures planar / axisymmetric, dry air axisymmetric)");
+      if (h->nc) throw Unsupported("mixing-length model: Gauss-Legendre pair");
+      if (!(in->max_mixing_length >= 0.0)) throw std::invalid_argument("tpsrhs_set_mixing_length: negative max_mixing_length");
+      h->mixlen.distance = distance;
+      h->mixlen.lmax = in->max_mixing_length;
+      h->mixlen.prt = in->pr_ratio;
+      h->mixlen.bulk = in->bulk_multiplier;
+    } else {
+      h->mixlen.distance = nullptr;
+    }
+    h->config_epoch++;  // a captured time-loop graph holds the old pointer
+  });
+}
+
 int tpsrhs_set_joule_heating(tpsrhs_handle h, const double *joule_heating) {
   if (!h) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_set_joule_heating: NULL handle");
   return guarded([&] {

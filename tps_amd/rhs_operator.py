@@ -186,6 +186,21 @@ class RHSoperator:
         if st != 0:
             raise TpsRhsError(st, "tpsrhs_set_joule_heating")
 
+    def setMixingLength(self, distance, max_mixing_length=0.0, pr_ratio=1.0, lewis=1.0, bulk_multiplier=0.0):
+        """``MixingLengthTransport`` (``src/mixing_length_transport.cpp``, ``[flow] useMixingLength``): ``distance`` =
+        the wall-distance grid function, a float64 CUDA tensor of NDofs entries read at every ``Mult`` (kept alive
+        here), or ``None`` to switch the model off."""
+        if distance is not None:
+            if (distance.dtype != torch.float64 or not distance.is_cuda or not distance.is_contiguous()
+                    or distance.numel() != self.NDofs):
+                raise ValueError("expected a contiguous float64 CUDA tensor of NDofs entries")
+        self._distance = distance
+        prm = capi.MixingLength(float(max_mixing_length), float(pr_ratio), float(lewis), float(bulk_multiplier))
+        st = self._lib.tpsrhs_set_mixing_length(self._h, C.c_void_p(distance.data_ptr()) if distance is not None else None,
+                                                C.byref(prm))
+        if st != 0:
+            raise TpsRhsError(st, "tpsrhs_set_mixing_length")
+
     def kernel_bytes(self):
         names = (C.c_char_p * 8)()
         b = (C.c_double * 8)()
