@@ -156,6 +156,13 @@ class RHSoperatorHIP : public mfem::TimeDependentOperator {
   void updateGradients(const mfem::Vector &x) const { check(tpsrhs_update_gradients(h_, x.Read())); }
   void getPrimitives(mfem::Vector &up) const { check(tpsrhs_get_primitives(h_, up.Write())); }
   void getGradients(mfem::Vector &gradUp) const { check(tpsrhs_get_gradients(h_, gradUp.Write())); }
+  // the optional terms of the reference's constructor: forcing.Append(...) (src/rhs_operator.cpp:101-166), the
+  // joule_heating_ and distance_ grid functions (device arrays owned by the caller; NULL-sized vector = off)
+  void setForcing(const tpsrhs_forcing *f) { check(tpsrhs_set_forcing(h_, f)); }
+  void setJouleHeating(const mfem::Vector *jh) { check(tpsrhs_set_joule_heating(h_, jh ? jh->Read() : nullptr)); }
+  void setMixingLength(const mfem::Vector *distance, const tpsrhs_mixing_length &prm) {
+    check(tpsrhs_set_mixing_length(h_, distance ? distance->Read() : nullptr, &prm));
+  }
   tpsrhs_handle handle() const { return h_; }
   int num_equation() const { return tpsrhs_num_equation(h_); }
 
