@@ -31,8 +31,8 @@ def target(rho, vel, p):
 
 
 for it in range(ncases):
-    geo = rng.choice(["cyl3d", "chan2d", "plasma3d"], p=[0.45, 0.4, 0.15])
-    order = int(rng.integers(1, 6 if geo != "plasma3d" else 3))
+    geo = rng.choice(["cyl3d", "chan2d", "plasma3d", "axi"], p=[0.4, 0.3, 0.1, 0.2])
+    order = int(rng.integers(1, 6 if geo in ("cyl3d", "chan2d") else (4 if geo == "axi" else 3)))
     seed = int(rng.integers(1, 1000))
     feats = []
     try:
@@ -56,6 +56,22 @@ for it in range(ncases):
             if rng.random() < 0.3:
                 disc.use_roe = 1
                 feats.append("roe")
+        elif geo == "axi":  # axisymmetric tube: dry air or an argon mixture, with the mixing-length model
+            wall = int(rng.choice([capi.INV, capi.VISC_ADIAB, capi.VISC_ISOTH]))
+            fl = rng.choice(["dry", "ternary", "six"])
+            if fl == "dry":
+                c = cases.dry_air_axisym(int(rng.integers(3, 7)), int(rng.integers(3, 8)), order, capi.NS, wall)
+                c.physics.dry_air.visc_mult = float(rng.choice([1.0, 50.0]))
+                amp = 0.05
+            else:
+                ph_ = (capi.argon_ternary_physics(capi.NS, bool(rng.random() < 0.5), int(rng.choice([capi.CONSTANT, capi.ARGON_MINIMAL])), "arrhenius")
+                       if fl == "ternary" else capi.argon_six_species_physics(capi.NS, int(rng.choice([capi.CONSTANT, capi.ARGON_MIXTURE])), True, True))
+                c = cases.argon_axisym(int(rng.integers(3, 7)), int(rng.integers(3, 8)), order, physics=ph_, wall_type=wall)
+                amp = 0.005 if order == 1 else 0.01
+            mesh, disc, ph, bcs = c.mesh, c.disc, c.physics, c.bcs
+            U = c.state(seed=seed, amp=amp)
+            tang, dim = None, 2
+            feats.append(fl)
         else:
             two_t = bool(rng.random() < 0.5)
             c = cases.argon_cyl3d(4, int(rng.integers(8, 12)), 3, order, two_t, int(rng.choice([capi.CONSTANT, capi.ARGON_MINIMAL])), "arrhenius",
@@ -63,7 +79,7 @@ for it in range(ncases):
             mesh, disc, ph, bcs = c.mesh, c.disc, c.physics, c.bcs
             U = c.state(seed=seed, amp=0.005)
             tang, dim = None, 3
-        dry = geo != "plasma3d"
+        dry = geo in ("cyl3d", "chan2d")
         if dry and rng.random() < 0.6:
             typ = int(rng.choice([capi.SUB_P_NR, capi.SUB_MF_NR, capi.SUB_MF_NR_PW]))
             bcs[1] = nr_bc(2, capi.OUTLET, typ, [101000.0] if typ == capi.SUB_P_NR else [24.0 * 3.0], tang, 3.0)
@@ -87,6 +103,9 @@ for it in range(ncases):
                 kw["sponge_zones"] = [dict(type=capi.SPONGE_PLANAR, normal=(-1.0, float(rng.uniform(-0.2, 0.2)), 0.0),
                                            point0=(2 * x0, 0.0, 0.0), point_init=(x0, 0.0, 0.0), mult_factor=float(rng.uniform(0.2, 2.0)),
                                            target_U=tu)]
+                if dry and rng.random() < 0.4:  # mixed-out target: the plane through point_init, a generous node tolerance
+                    kw["sponge_zones"][0].update(solution_type=capi.SPONGE_MIXEDOUT, tol=1.0 if geo == "cyl3d" else 0.12)
+                    feats.append("mixedout")
             forcing = capi.make_forcing(**kw)
             feats.append("forcing:" + ",".join(sorted(k[:4] for k in kw)))
         joule = rng.uniform(-1e4, 5e4, U.shape[1]) if (dim == 3 and rng.random() < 0.3) else None
@@ -102,6 +121,14 @@ for it in range(ncases):
         o.set_joule_heating(joule)
         jt = None if joule is None else torch.tensor(joule, dtype=torch.float64, device=op.device)
         op.setJouleHeating(jt)
+        if geo == "axi" and rng.random() < 0.8:
+            dist = np.ascontiguousarray(0.05 - node_coordinates(mesh, order)[0])  # distance to the tube wall
+            prm = dict(max_mixing_length=float(rng.choice([1e-3, 4e-3, 1.0])), pr_ratio=float(rng.uniform(0.5, 1.2)),
+                       bulk_multiplier=float(rng.choice([0.0, 1.0])))
+            o.set_mixing_length(dist, **prm)
+            dt_ = torch.tensor(dist, dtype=torch.float64, device=op.device)
+            op.setMixingLength(dt_, **prm)
+            desc += " mixlen"
         x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
         errs = []
         if use_advance:
@@ -117,6 +144,8 @@ for it in range(ncases):
             y = torch.empty_like(x)
             for call in range(3):
                 ref = o.mult(U)
+                if not np.isfinite(ref).all():
+                    raise FloatingPointError("oracle not finite (inadmissible input)")
                 op.Mult(x, y)
                 got = y.cpu().numpy().reshape(U.shape)
                 scale = np.abs(ref).max(axis=1)
@@ -124,7 +153,7 @@ for it in range(ncases):
                 errs.append((np.abs(got - ref).max(axis=1) / np.maximum(scale, 1e-300)).max())
         op.close()
         err = max(errs)
-        tol = TOL * (10 if geo == "plasma3d" else 1)
+        tol = TOL * (10 if (geo == "plasma3d" or (geo == "axi" and feats[0] != "dry")) else 1)
         worst = max(worst, err / tol)
         print(f"[{it}] {desc}: {err:.2e}" + ("" if err < tol else "   <<<<<< FAIL"), flush=True)
     except Exception as exc:  # noqa: BLE001
