@@ -661,7 +661,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Par
   constexpr int NEQ = PH::NEQ;
   const Tables1D &ct = c_tab[C::NC][C::DIM - 2][C::P];
   __shared__ double sF[2 * NEQ * C::NODES];
-  __shared__ double sT[2 * NEQ * C::TN];
+  __shared__ double sT[(C::DIM == 2 ? 2 : 1) * 2 * NEQ * C::TN];
   const int tid = threadIdx.x;
   const int bid = m.blocks ? m.blocks[blockIdx.x] : static_cast<int>(blockIdx.x);
   const int e0 = bid * C::EPB;
@@ -682,9 +682,26 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Par
     }
   }
   block_sync<C::BLOCK>();
-  traces_dir<C, PH, 0>(m, e0, sF, sT, TA, ct, tid);
-  traces_dir<C, PH, 1>(m, e0, sF, sT, TA, ct, tid);
-  if (C::DIM == 3) traces_dir<C, PH, (C::DIM == 3 ? 2 : 0)>(m, e0, sF, sT, TA, ct, tid);
+  if constexpr (C::DIM == 2) {
+    // quads: a face record field is p+1 doubles (32 B at p = 3), so the per-direction store of traces_dir writes
+    // 32-byte pieces.  Both direction pairs go to LDS first; the records of a block's elements are contiguous in TA
+    // (slot = e * NFACES + f), so the block then streams them out as one run of full 512-byte rows.
+    trace_lines<C, 0, 2 * NEQ>(sF, sT, ct, tid);
+    trace_lines<C, 1, 2 * NEQ>(sF, sT + 2 * NEQ * C::TN, ct, tid);
+    block_sync<C::BLOCK>();
+    constexpr int REC = 2 * NEQ * C::NF, PER_E = C::NFACES * REC;
+    double *out = TA + static_cast<int64_t>(e0) * PER_E;
+    for (int o = tid; o < C::EPB * PER_E; o += C::BLOCK) {
+      const int le = o / PER_E, r = o - le * PER_E;
+      const int f = r / REC, r2 = r - f * REC;
+      const int fld = r2 / C::NF, fn = r2 - fld * C::NF;
+      if (e0 + le < m.ne) out[o] = ldsr(&sT[(f >> 1) * (2 * NEQ * C::TN) + fld * C::TN + (2 * le + (f & 1)) * C::NF + fn]);
+    }
+  } else {
+    traces_dir<C, PH, 0>(m, e0, sF, sT, TA, ct, tid);
+    traces_dir<C, PH, 1>(m, e0, sF, sT, TA, ct, tid);
+    traces_dir<C, PH, (C::DIM == 3 ? 2 : 0)>(m, e0, sF, sT, TA, ct, tid);
+  }
 }
 
 // =============================================================================================
