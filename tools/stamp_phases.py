@@ -18,7 +18,7 @@ from tps_amd.rhs_operator import RHSoperator, node_coordinates  # noqa: E402
 sys.argv = [sys.argv[0]]
 import bench  # noqa: E402
 
-order, physics, make_bcs, make_state, description, _ = bench.workload("argon_p3")
+order, physics, make_bcs, make_state, description, _ = bench.workload(os.environ.get("STAMP_WORKLOAD", "argon_p3"))  # or cfg3
 mesh = meshgen.ogrid_cylinder_slab(28, 112, 16, 0, 1)
 disc = capi.Disc(order, 0, 0, 0, 0)
 X = node_coordinates(mesh, order)
@@ -29,7 +29,7 @@ y = torch.empty_like(x)
 lib = capi.load()
 import numpy as np  # noqa: E402
 
-nblocks = mesh.num_elements
+nblocks = mesh.num_elements // (2 if order == 2 else 1)  # elements per block: one p = 3 hex, two p = 2 hexes
 buf = np.zeros((nblocks, 16), dtype=np.uint32)
 for _ in range(3):
     op.Mult(x, y)
