@@ -46,10 +46,11 @@ def test_struct_sizes_match_header():
 
     names = ["tpsrhs_mesh", "tpsrhs_disc", "tpsrhs_dry_air", "tpsrhs_perfect_mixture", "tpsrhs_constant_transport",
              "tpsrhs_gas_transport", "tpsrhs_table", "tpsrhs_chemistry", "tpsrhs_radiation", "tpsrhs_physics",
-             "tpsrhs_bc", "tpsrhs_runtime", "tpsrhs_heat_source", "tpsrhs_sponge_zone", "tpsrhs_forcing"]
+             "tpsrhs_bc", "tpsrhs_runtime", "tpsrhs_heat_source", "tpsrhs_sponge_zone", "tpsrhs_forcing", "tpsrhs_sgs",
+             "tpsrhs_visc_sponge", "tpsrhs_mixing_length"]
     mirror = [capi.Mesh, capi.Disc, capi.DryAir, capi.PerfectMixture, capi.ConstantTransport, capi.GasTransport,
               capi.Table, capi.Chemistry, capi.Radiation, capi.Physics, capi.BC, capi.Runtime, capi.HeatSource,
-              capi.SpongeZone, capi.Forcing]
+              capi.SpongeZone, capi.Forcing, capi.Sgs, capi.ViscSponge, capi.MixingLength]
     src = '#include <stdio.h>\n#include "tpsrhs.h"\nint main(){' + "".join(
         f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as td:
