@@ -44,6 +44,11 @@ for it in range(ncases):
                 vs.enabled, vs.width, vs.ratio = 1, float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 20.0))
                 vs.normal[0], vs.normal[1], vs.point[0], vs.point[1] = rng.normal(), rng.normal(), rng.normal(), rng.normal()
             desc += f" sgs={ph.sgs.model_type} sponge={ph.visc_sponge.enabled}"
+            if ph.sgs.model_type == capi.SGS_SIGMA:
+                # the eigenvalue route of the sigma model (acos of a ratio that approaches +-1 for nearly two-dimensional
+                # strain) amplifies the rounding of the gradient: "more sensitive to perturbations in g", src/fluxes.cpp:
+                # 584-587; 2 of 5 000 cases of the round-2 sweep reached 1.6e-11
+                tol *= 5
     else:
         two_t = bool(rng.random() < 0.5)
         if fluid not in ("argon3", "argon3n"):
@@ -86,7 +91,13 @@ for it in range(ncases):
             mesh = meshgen.scramble_orientations(mesh, seed)
             disc, bcs = capi.Disc(order, 0, 0, 0, 0), []
             c = None
-        X = node_coordinates(mesh, order)
+        # the non-collocated Gauss-Lobatto pair: dry air and the ternary mixtures, planar 2-D / 3-D, p <= 3, no LES flavour
+        gll = (geo != "axisym" and order <= 3 and fluid in ("dry", "argon3", "argon3n") and rng.random() < 0.2
+               and not (fluid == "dry" and (ph.sgs.model_type or ph.visc_sponge.enabled)))
+        if gll:
+            disc = capi.Disc(order, 1, 1, 0, 0)
+            desc += " GLL"
+        X = node_coordinates(mesh, order, 1 if gll else 0)
         if fluid == "dry":
             U = cases.dry_air_state(X, seed=seed, nvel=3 if disc.axisymmetric else None,
                                     vel0=(1.0, 20.0, 3.0) if disc.axisymmetric else (20.0, 0.0, 0.0))
