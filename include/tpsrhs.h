@@ -222,7 +222,8 @@ typedef struct tpsrhs_sgs {
 } tpsrhs_sgs;
 typedef struct tpsrhs_visc_sponge { /* viscositySpongeData (src/M2ulPhyS.cpp:583-600) */
   int enabled;
-  double normal[3], point[3]; /* used as given (not normalised), as the reference does */
+  double normal[3], point[3]; /* the normal is normalised, as the constructor of every CPU build of the reference does
+                               * (src/fluxes.cpp:77-90; its device constructor :98-125 does not) */
   double width, ratio;
 } tpsrhs_visc_sponge;
 
@@ -275,8 +276,10 @@ typedef int (*tpsrhs_halo_fn)(void *ctx, int phase, const double *send, double *
  * ordered on `stream`.  SUM: the MPI_Allreduce of the boundary means of the non-reflecting inlet/outlet conditions
  * (src/outletBC.cpp:533-540, src/inletBC.cpp:548-555; one call per Mult for all such patches together --
  * ranks without faces on a patch contribute zeros, so the job-wide sum equals the reference's
- * per-patch communicator).  MIN: the MPI_Allreduce of the time step in tpsrhs_advance
- * (src/M2ulPhyS.cpp:2013-2016).  Return 0 on success. */
+ * per-patch communicator), and of the plane sums of a mixed-out sponge zone (src/forcing_terms.cpp:732-735).
+ * MIN: the MPI_Allreduce of the time step in tpsrhs_advance (src/M2ulPhyS.cpp:2013-2016).  Return 0 on success.
+ * `stream` may be NULL: that is the legacy default stream, and the implementation must order its work THERE (a
+ * torch-based hook maps it to torch.cuda.default_stream -- torch.cuda.ExternalStream(0) is a different stream). */
 enum tpsrhs_reduce_op { TPSRHS_REDUCE_SUM = 0, TPSRHS_REDUCE_MIN = 1 };
 typedef int (*tpsrhs_reduce_fn)(void *ctx, double *values, int count, int op, void *stream);
 
@@ -285,8 +288,8 @@ typedef struct tpsrhs_runtime {
   void *stream;          /* hipStream_t for all work of this operator, NULL = default stream */
   tpsrhs_halo_fn halo;   /* required when mesh.num_shared_faces > 0 */
   void *halo_ctx;
-  tpsrhs_reduce_fn reduce; /* required when mesh.num_shared_faces > 0 and a non-reflecting patch exists, or
-                            * tpsrhs_advance runs with a variable time step */
+  tpsrhs_reduce_fn reduce; /* required when mesh.num_shared_faces > 0 and a non-reflecting patch exists, a mixed-out
+                            * sponge zone is set, or tpsrhs_advance runs with a variable time step */
   void *reduce_ctx;
 } tpsrhs_runtime;
 

@@ -111,7 +111,13 @@ class RHSoperatorHIP : public mfem::TimeDependentOperator {
     if (!shared.empty() && !exchange_.halo)
       throw std::runtime_error("RHSoperatorHIP: the mesh is partitioned but no halo exchange was supplied");
 
-    tpsrhs_mesh m;
+    // Mesh::GetElementSize(e, 1) [MFEM]: the grid scale of the sub-grid scale models and of the viscous sponge
+    // (src/rhs_operator.cpp:145-156); exact on curved or periodic meshes, where the corner coordinates are not
+    std::vector<double> esize(mesh->GetNE());
+    for (int e = 0; e < mesh->GetNE(); e++) esize[e] = mesh->GetElementSize(e, 1);
+
+    tpsrhs_mesh m = {};
+    m.elem_size = esize.data();
     m.dim = dim;
     m.num_vertices = mesh->GetNV();
     m.num_elements = mesh->GetNE();
@@ -123,7 +129,7 @@ class RHSoperatorHIP : public mfem::TimeDependentOperator {
     m.num_shared_faces = static_cast<int>(srank.size());
     m.shared_vertices = sv.data();
     m.shared_neighbor_rank = srank.data();
-    tpsrhs_runtime rt;
+    tpsrhs_runtime rt = {};
     rt.device = device;
     rt.stream = stream;
     rt.halo = exchange_.halo;

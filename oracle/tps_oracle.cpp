@@ -91,6 +91,12 @@ struct Operator {
                                : (p->sgs.model_type == 1 ? 0.12 : (p->sgs.model_type == 2 ? 0.135 : 0.0));
     fluxes->sgs_model_floor_ = p->sgs.model_floor;
     fluxes->vsd_ = p->visc_sponge;
+    if (fluxes->vsd_.enabled) {  // "ensure normal is actually a unit normal", the host constructor src/fluxes.cpp:77-90
+      double Nmag = 0;
+      for (int d = 0; d < dim; d++) Nmag += fluxes->vsd_.normal[d] * fluxes->vsd_.normal[d];
+      Nmag = std::sqrt(Nmag);
+      for (int d = 0; d < dim; d++) fluxes->vsd_.normal[d] /= Nmag;
+    }
     if (p->sgs.model_type > 0 && dim != 3) throw std::runtime_error("sgs models index three directions (src/fluxes.cpp:524-529)");
     // elSize (src/rhs_operator.cpp:145-156): Mesh::GetElementSize(e, 1) / order, the smallest singular value of the
     // Jacobian at the element centre [MFEM]; one-sided Jacobi (Hestenes) on the columns of J

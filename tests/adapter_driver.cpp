@@ -1,7 +1,7 @@
 // Test driver of include/tpsrhs_mfem_adapter.hpp (the role of utils/compute_rhs.cpp:60-102: build the operator,
 // one rhsOperator->Mult(U, rhs)).  Reads a case file written by tests/test_adapter.py:
-//   int32: dim, nv, ne, nbe, neq, order ; int32 elem_vertices[ne*2^dim] ; f64 elem_coords[ne*2^dim*dim] ;
-//   int32 bdr_vertices[nbe*2^(dim-1)] ; int32 bdr_attributes[nbe] ; f64 x[neq*ndofs]
+//   int32: dim, nv, ne, nbe, neq, order, sgs model, pad ; int32 elem_vertices[ne*2^dim] ; f64 elem_coords[ne*2^dim*dim] ;
+//   int32 bdr_vertices[nbe*2^(dim-1)] ; int32 bdr_attributes[nbe] ; f64 elem_size[ne] ; f64 x[neq*ndofs]
 // physics: dry air, Navier-Stokes; boundary conditions: the cylinder patches 1 / 2 / 3 of tps_amd.cases.
 // Writes y (f64) and max_char_speed.  Exit codes: 0 ok, 3 the library reported "no device", 1 anything else.
 #include <cstdint>
@@ -25,8 +25,8 @@ int main(int argc, char **argv) {
   try {
     FILE *f = fopen(argv[1], "rb");
     if (!f) throw std::runtime_error("cannot open case file");
-    const std::vector<int32_t> hd = rd<int32_t>(f, 6);
-    const int dim = hd[0], nv = hd[1], ne = hd[2], nbe = hd[3], neq = hd[4], order = hd[5];
+    const std::vector<int32_t> hd = rd<int32_t>(f, 8);
+    const int dim = hd[0], nv = hd[1], ne = hd[2], nbe = hd[3], neq = hd[4], order = hd[5], sgs = hd[6];
     mfem::ParMesh mesh;
     mesh.dim = dim;
     mesh.nv = nv;
@@ -34,6 +34,7 @@ int main(int argc, char **argv) {
     mesh.elem_coords = rd<double>(f, (static_cast<size_t>(ne) << dim) * dim);
     mesh.bdr_vertices = rd<int32_t>(f, static_cast<size_t>(nbe) << (dim - 1));
     mesh.bdr_attributes = rd<int32_t>(f, nbe);
+    mesh.elem_size = rd<double>(f, ne);
     int npe = 1;
     for (int d = 0; d < dim; d++) npe *= order + 1;
     const int vsize = neq * ne * npe;
@@ -58,6 +59,7 @@ int main(int argc, char **argv) {
     ph.dry_air.sutherland_C1 = 1.458e-6;
     ph.dry_air.sutherland_S0 = 110.4;
     ph.dry_air.sutherland_Pr = 0.71;
+    ph.sgs.model_type = sgs;  // [flow] sgsModel: the adapter must hand over the element sizes (tpsrhs_mesh::elem_size)
     std::vector<tpsrhs_bc> bcs(3);
     std::memset(bcs.data(), 0, 3 * sizeof(tpsrhs_bc));
     bcs[0].attribute = 1, bcs[0].category = TPSRHS_INLET, bcs[0].type = TPSRHS_SUB_DENS_VEL;

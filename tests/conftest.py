@@ -13,14 +13,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
-def pytest_collection_modifyitems(config, items):
-    """The multi-process tests (rank processes spawned next to the test process, all sharing the one GPU of the box)
-    run after the single-process ones: with `-x` a failure there then does not hide the rest of the suite."""
-    late = [it for it in items if "multirank" in it.nodeid or "halo_gloo" in it.nodeid]
-    if late:
-        items[:] = [it for it in items if it not in late] + late
-
-
 @pytest.fixture(scope="session", autouse=True)
 def _native_libraries_built():
     """The tests need the product library and the oracle; build them when a fresh checkout has neither

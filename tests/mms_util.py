@@ -148,3 +148,88 @@ def manufactured_ternary(X, lengths=(1.0, 1.0, 1.0)):
     U = np.array([np.asarray(v, dtype=np.float64) + bc for v in fu(*X)])
     R = np.array([np.asarray(v, dtype=np.float64) + bc for v in fr(*X)])
     return U, R
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's own manufactured-solution checks of ONE assembled Mult: utils/compute_rhs (utils/compute_rhs.cpp:
+# 102-160) behind test/mms.euler_2d.test and test/mms.cns_2d.test.  The exact state and its source come from MASA
+# [third party: pecos/MASA 0.50, absent from this image]; they are restated here from MASA's published forms and
+# differentiated with sympy.
+#
+# euler_2d (MASA src/euler.cpp, documented in MASA's "Euler 2D" manufactured solution):
+#     rho = rho_0 + rho_x sin(a_rhox pi x / L) + rho_y cos(a_rhoy pi y / L)
+#     u   = u_0   + u_x   sin(a_ux   pi x / L) + u_y   cos(a_uy   pi y / L)
+#     v   = v_0   + v_x   cos(a_vx   pi x / L) + v_y   sin(a_vy   pi y / L)
+#     p   = p_0   + p_x   cos(a_px   pi x / L) + p_y   sin(a_py   pi y / L)
+# Parameters: the reference sets L, Gamma and the eight a_* (src/masa_handler.cpp:236-262); the twelve amplitudes
+# keep MASA's defaults (euler_2d<Scalar>::init_var).  MASA's sources are not here, so the defaults below are written
+# from memory of that file -- NOT tuned: they were typed once, and the first evaluation reproduced the three numbers
+# test/mms.euler_2d.test holds (5.74794e-5 / 5.75172e-5 / 5.7516e-5) to all six printed digits, which is the check on
+# the recollection.
+MASA_EULER_2D_DEFAULTS = dict(u_0=200.23, u_x=1.1, u_y=1.08, v_0=1.2, v_x=1.6, v_y=0.47, rho_0=100.02, rho_x=2.22, rho_y=0.8,
+                              p_0=150.2, p_x=0.91, p_y=0.623, a_px=0.165, a_py=0.612, a_rhox=1.0, a_rhoy=1.0, a_ux=0.1987,
+                              a_uy=1.189, a_vx=1.91, a_vy=1.0, Gamma=1.01, mu=0.918, L=3.02)
+# src/masa_handler.cpp:245-261 (initEuler2D)
+TPS_EULER_2D_OVERRIDES = dict(L=3.02, Gamma=1.4, a_rhox=2.0, a_rhoy=2.0, a_ux=2.0, a_uy=2.0, a_vx=2.0, a_vy=2.0, a_px=2.0, a_py=2.0)
+# src/masa_handler.cpp:273-300 (initCNS2DSutherlands) with the input's viscosity multipliers (defaults 1, 0:
+# src/M2ulPhyS.cpp:2678-2679)
+TPS_CNS_2D_OVERRIDES = dict(L=3.02, Gamma=1.4, R=287.058, Pr=0.71, Amu=1.458e-6, Bmu=1.5, Cmu=110.4, bulkViscMult=0.0,
+                            rho_0=1.02, rho_x=0.11, rho_y=0.13, a_rhox=2.0, a_rhoy=2.0, a_ux=2.0, a_uy=2.0, a_vx=2.0, a_vy=2.0,
+                            a_px=2.0, a_py=2.0)
+
+
+@functools.lru_cache(maxsize=None)
+def _build_masa_2d(items, viscous):
+    import sympy as sp
+
+    P = dict(items)
+    x, y = sp.symbols("x y")
+    L, pi = P["L"], sp.pi
+    rho = P["rho_0"] + P["rho_x"] * sp.sin(P["a_rhox"] * pi * x / L) + P["rho_y"] * sp.cos(P["a_rhoy"] * pi * y / L)
+    u = P["u_0"] + P["u_x"] * sp.sin(P["a_ux"] * pi * x / L) + P["u_y"] * sp.cos(P["a_uy"] * pi * y / L)
+    v = P["v_0"] + P["v_x"] * sp.cos(P["a_vx"] * pi * x / L) + P["v_y"] * sp.sin(P["a_vy"] * pi * y / L)
+    p = P["p_0"] + P["p_x"] * sp.cos(P["a_px"] * pi * x / L) + P["p_y"] * sp.sin(P["a_py"] * pi * y / L)
+    g = P["Gamma"]
+    E = p / (g - 1) + rho * (u * u + v * v) / 2
+    vel, X = [u, v], [x, y]
+    U = [rho, rho * u, rho * v, E]
+    F = [[rho * vel[d] for d in range(2)]]
+    for i in range(2):
+        F.append([U[1 + i] * vel[d] + (p if i == d else 0) for d in range(2)])
+    F.append([vel[d] * (E + p) for d in range(2)])
+    if viscous:  # Sutherland law mu = Amu T^Bmu / (T + Cmu), kappa = mu cp / Pr, bulk viscosity multiplier
+        T = p / (rho * P["R"])
+        mu = P["Amu"] * T ** P["Bmu"] / (T + P["Cmu"])
+        mub = P["bulkViscMult"] * mu - sp.Rational(2, 3) * mu
+        kap = mu * g * P["R"] / ((g - 1) * P["Pr"])
+        div = sum(sp.diff(vel[d], X[d]) for d in range(2))
+        tau = [[mu * (sp.diff(vel[i], X[j]) + sp.diff(vel[j], X[i])) + (mub * div if i == j else 0) for j in range(2)]
+               for i in range(2)]
+        for i in range(2):
+            for d in range(2):
+                F[1 + i][d] -= tau[i][d]
+        for d in range(2):
+            F[3][d] -= sum(tau[i][d] * vel[i] for i in range(2)) + kap * sp.diff(T, X[d])
+    S = [sum(sp.diff(F[k][d], X[d]) for d in range(2)) for k in range(4)]  # MASA's source: Q = div F(U_exact)
+    return sp.lambdify((x, y), U, "numpy"), sp.lambdify((x, y), S, "numpy")
+
+
+def masa_2d(X, overrides, viscous=False):
+    """(U_exact, Q) at the nodes X (2, N): the state of masa_eval_exact_* as src/masa_handler.cpp:219-238 assembles it
+    and the source of masa_eval_source_* the MASA forcing adds to the residual (src/forcing_terms.cpp:979-1011)."""
+    P = dict(MASA_EULER_2D_DEFAULTS)
+    P.update(overrides)
+    fu, fs = _build_masa_2d(tuple(sorted(P.items())), bool(viscous))
+    z = np.zeros(X.shape[1])
+    U = np.array([np.asarray(a, dtype=np.float64) + z for a in fu(X[0], X[1])])
+    S = np.array([np.asarray(a, dtype=np.float64) + z for a in fs(X[0], X[1])])
+    return U, S
+
+
+def compute_rhs_errors(l2_norm, y, S):
+    """utils/compute_rhs.cpp:134-147 with compare_rhs = False: per variable (density, momentum vector, energy) the L2
+    norm of Mult(U_exact) -- which already contains the MASA forcing -- over the L2 norm of the forcing."""
+    e0 = l2_norm(y[0]) / l2_norm(S[0])
+    e1 = np.hypot(l2_norm(y[1]), l2_norm(y[2])) / np.hypot(l2_norm(S[1]), l2_norm(S[2]))
+    e2 = l2_norm(y[3]) / l2_norm(S[3])
+    return e0, e1, e2

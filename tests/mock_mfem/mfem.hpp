@@ -3,7 +3,7 @@
 // MFEM).  It mimics the SIGNATURES of the few MFEM classes / methods the adapter uses ([MFEM] >= 4.4: Vector,
 // Array, DenseMatrix, ElementTransformation::GetPointMat, Device::IsEnabled, TimeDependentOperator, and the
 // ParMesh queries GetElementVertices, GetBdrElementVertices, GetBdrAttribute, GetGlobalVertexIndices,
-// GetNFaceNeighbors, GetFaceNbrGroup, GetFaceNbrRank, GroupNQuadrilaterals / GroupQuadrilateral, GroupNEdges /
+// GetElementSize, GetNFaceNeighbors, GetFaceNbrGroup, GetFaceNbrRank, GroupNQuadrilaterals / GroupQuadrilateral, GroupNEdges /
 // GroupEdge, GetFaceVertices, GetEdgeVertices) over plain arrays.  It computes nothing and is no part of the product.
 #ifndef TPSRHS_MOCK_MFEM_HPP_
 #define TPSRHS_MOCK_MFEM_HPP_
@@ -100,6 +100,7 @@ class ParMesh {
   std::vector<int> bdr_vertices;     // [nbe][2^(dim-1)]
   std::vector<int> bdr_attributes;
   std::vector<long long> global_vertex;  // [nv]
+  std::vector<double> elem_size;     // [ne] what GetElementSize(e, 1) returns (the test supplies it; nothing is computed)
   struct Nbr {
     int rank;
     std::vector<std::vector<int>> faces;  // local vertices of each shared face
@@ -128,6 +129,7 @@ class ParMesh {
     for (int k = 0; k < n; k++) v[k] = bdr_vertices[static_cast<size_t>(b) * n + k];
   }
   int GetBdrAttribute(int b) const { return bdr_attributes[b]; }
+  double GetElementSize(int e, int /*type*/ = 0) const { return elem_size.at(e); }
   void GetGlobalVertexIndices(Array<HYPRE_BigInt> &g) const {
     g.SetSize(nv);
     for (int i = 0; i < nv; i++) g[i] = global_vertex.empty() ? i : global_vertex[i];

@@ -30,23 +30,34 @@ def build_driver(tmp_path):
     return exe
 
 
-def write_case(path, c, U, order):
+def write_case(path, c, U, order, sgs=0):
+    from oracle_lib import Oracle
+
     m = c.mesh
+    if m.elem_size is None:  # what MFEM's GetElementSize(e, 1) returns for this mesh (the oracle's elSize is / order)
+        esize = Oracle(m, c.disc, c.physics, c.bcs).element_sizes() * order
+    else:
+        esize = m.elem_size
     ev = np.ascontiguousarray(m.elem_vertices, dtype=np.int32)
     ex = np.ascontiguousarray(m.elem_coords, dtype=np.float64)
     bv = np.ascontiguousarray(m.bdr_vertices, dtype=np.int32)
     ba = np.ascontiguousarray(m.bdr_attributes, dtype=np.int32)
     with open(path, "wb") as f:
-        f.write(struct.pack("<6i", m.dim, m.num_vertices, m.num_elements, len(ba), U.shape[0], order))
-        for a in (ev, ex, bv, ba, np.ascontiguousarray(U, dtype=np.float64)):
+        f.write(struct.pack("<8i", m.dim, m.num_vertices, m.num_elements, len(ba), U.shape[0], order, sgs, 0))
+        for a in (ev, ex, bv, ba, np.ascontiguousarray(esize, dtype=np.float64), np.ascontiguousarray(U, dtype=np.float64)):
             f.write(a.tobytes())
 
 
-def make_case():
+def make_case(sgs=0):
     order = 2
     c = cases.cyl3d(4, 12, 3, order, capi.NS, capi.VISC_ISOTH)
     c.physics.dry_air.visc_mult = 2000.0  # the driver's dry-air block
-    return c, c.state(seed=31), order
+    c.physics.sgs.model_type = sgs
+    if sgs:  # sizes the library could not have recomputed from the corners: the adapter must pass MFEM's through
+        from oracle_lib import Oracle
+
+        c.mesh.elem_size = 1.25 * order * Oracle(c.mesh, c.disc, c.physics, c.bcs).element_sizes()
+    return c, c.state(seed=31, amp=0.1 if sgs else 0.05), order
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
@@ -64,12 +75,14 @@ def test_adapter_compiles_links_and_fails_loudly_without_a_device(tmp_path):
 
 
 @pytest.mark.gpu
-def test_adapter_mult_from_cpp_matches_oracle(tmp_path):
+@pytest.mark.parametrize("sgs", [0, capi.SGS_SMAGORINSKY])
+def test_adapter_mult_from_cpp_matches_oracle(tmp_path, sgs):
+    """sgs: the Smagorinsky model reads tpsrhs_mesh::elem_size, which the adapter fills from Mesh::GetElementSize"""
     from parity_util import RHS_RTOL, oracle_mult, rel_maxnorm
 
     exe = build_driver(tmp_path)
-    c, U, order = make_case()
-    write_case(tmp_path / "case.bin", c, U, order)
+    c, U, order = make_case(sgs)
+    write_case(tmp_path / "case.bin", c, U, order, sgs)
     r = subprocess.run([exe, str(tmp_path / "case.bin"), str(tmp_path / "y.bin")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     raw = np.fromfile(tmp_path / "y.bin", dtype=np.float64)

@@ -64,7 +64,8 @@ def test_sgs_cylinder_walls(wall):
 
 @pytest.mark.parametrize("dim,order", [(3, 3), (2, 3), (2, 2)])
 def test_viscous_sponge(dim, order):
-    """[viscosityMultiplierFunction]: tanh ramp of the viscosity along a plane normal (normal not normalised)"""
+    """[viscosityMultiplierFunction]: tanh ramp of the viscosity along a plane normal; the normal given here has
+    length 2.06 and is normalised by the library and the oracle like the reference's host constructor does"""
     if dim == 3:
         c = cases.cyl3d(4, 12, 3, order, capi.NS, capi.VISC_ISOTH)
     else:

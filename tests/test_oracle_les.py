@@ -94,11 +94,11 @@ def test_viscous_sponge_weight():
     g = _grad([[10.0, 300.0, 0], [0, -5.0, 0], [0, 0, 2.0]])
     g[4 + 0 * 5] = 1500.0  # dT/dx: the conductivity is weighted too
     for x in ((-3.0, 0.2, 0.1), (0.5, 0.0, 0.0), (0.9, 0.3, 0.3), (4.0, 0.0, 0.0)):
-        dist = (x[0] - 0.5) * 2.0
+        dist = (x[0] - 0.5) * 1.0  # the normal (2, 0, 0) is normalised first: the host constructor, src/fluxes.cpp:77-90
         w = 1.0 + 8.0 * 0.5 * (np.tanh(dist / 0.25 - 2.0) + 1.0)
         a, b = o.viscous_flux_at(STATE, g, x, 0.1), o0.viscous_flux_at(STATE, g, x, 0.1)
         assert np.abs(a - w * b).max() < 1e-13 * np.abs(a).max()
-    assert abs(o.viscous_flux_at(STATE, g, (-3.0, 0, 0), 0.1) - o0.viscous_flux_at(STATE, g, (-3.0, 0, 0), 0.1)).max() < 1e-12
+    assert abs(o.viscous_flux_at(STATE, g, (-8.0, 0, 0), 0.1) - o0.viscous_flux_at(STATE, g, (-8.0, 0, 0), 0.1)).max() < 1e-12
     # ratio below one is clipped to one (factor = max(ratio, 1)): no weighting at all
     o1, _ = _oracle(sponge=dict(sp, ratio=0.3))
     assert np.array_equal(o1.viscous_flux_at(STATE, g, (2.0, 0, 0), 0.1), o0.viscous_flux_at(STATE, g, (2.0, 0, 0), 0.1))

@@ -26,7 +26,9 @@ __device__ inline double fast_rcp(double x) {
   return r;
 }
 __device__ inline double fast_sqrt(double x) {
-  if (x <= 0.0) return 0.0;
+  // x < 0 -> NaN (rsq of a negative number), as sqrt: a non-physical state (negative pressure or temperature) must
+  // reach the reference's a-posteriori Check_NAN (src/M2ulPhyS.cpp:2463), not become a zero wave speed
+  if (x == 0.0) return 0.0;
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   double r = fma(-h, g, 0.5);

@@ -1864,13 +1864,15 @@ __global__ __launch_bounds__(256) void k_bc_mean(int nfaces, const int2 *__restr
 
 // One block per face of a non-reflecting patch, one lane per face quadrature point.
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK) void k_bc_nr(MeshDev m, typename PH::Params prm, const int2 *__restrict__ faces,
+__global__ __launch_bounds__(C::BLOCK) void k_bc_nr(MeshDev m, const typename PH::Params prm, const int2 *__restrict__ faces,
                                               const double *__restrict__ sums, const double *__restrict__ U,
                                               const double *__restrict__ Up, const double *__restrict__ gradUp,
                                               double *__restrict__ state_old, double *__restrict__ state_new, int first,
                                               const double *__restrict__ dt_dev) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
-  if (dt_dev) prm.nr_dt = *dt_dev;  // tpsrhs_advance keeps dt in device memory
+  // tpsrhs_advance keeps dt in device memory.  (Not written into `prm`: a kernel that modifies its by-value
+  // parameter block gets a private copy of all of it -- 1.9 KB of scratch per lane in round 2.)
+  const double nr_dt = dt_dev ? *dt_dev : prm.nr_dt;
   static_assert(C::NQ <= C::BLOCK, "one lane per face quadrature point");
   const Tables1D &ct = c_tab[C::NC][DIM - 2][C::P];
   __shared__ Tab<C> tab;
@@ -1923,7 +1925,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_bc_nr(MeshDev m, typename PH::Para
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) s2[eq] = state_old[rec + eq];
   }
-  PH::nr_update(prm, prm.bc[b], meanUp, nrm, Uq, g, s2, newU);
+  PH::nr_update(prm, prm.bc[b], nr_dt, meanUp, nrm, Uq, g, s2, newU);
 #pragma unroll
   for (int eq = 0; eq < NEQ; eq++) state_new[rec + eq] = newU[eq];
 }
@@ -1969,6 +1971,8 @@ __global__ void k_mixed_out_finish(typename PH::Params prm, ForcingDev *fd, int 
   double mean[NEQ], tgt[NEQ];
 #pragma unroll
   for (int eq = 0; eq < NEQ; eq++) mean[eq] = sz.msum[eq] / sz.msum[NEQ];
+  // no node of ANY rank lies within tol of the plane: 0 / 0 as in the reference (src/forcing_terms.cpp:737-739); the
+  // NaN target is left to Check_NAN (k_rk4_stage's census) rather than silently replaced
   PH::state_from_mean_flux(prm, mean, sz.normal, tgt);
 #pragma unroll
   for (int eq = 0; eq < NEQ; eq++) sz.target[eq] = tgt[eq];

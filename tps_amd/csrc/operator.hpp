@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -36,10 +37,19 @@ struct Unsupported : std::runtime_error {
       throw DeviceError(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
   } while (0)
 
+// TPSRHS_POISON=1 (debug / tests/test_gpu_poison.py): every device allocation of the library starts as all-ones bytes
+// (a NaN as a double, -1 as an index), so that a read of memory no kernel has written shows up as a NaN in the
+// residual instead of depending on what the allocator happened to return.  Read at every call: cheap next to hipMalloc.
+inline bool poison_allocations() {
+  const char *e = std::getenv("TPSRHS_POISON");
+  return e && e[0] == '1';
+}
 template <class T>
 T *dev_alloc(size_t n) {
   T *p = nullptr;
-  HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(T)));
+  const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), bytes));
+  if (poison_allocations()) HIP_CHECK(hipMemset(p, 0xFF, bytes));
   return p;
 }
 template <class T>
@@ -67,6 +77,7 @@ struct tpsrhs_operator {
   alignas(16) unsigned char params[4096];  // PH::Params of the selected physics, passed by value
   void *d_chem = nullptr;                   // ChemDev block + table storage (plasma)
   std::vector<void *> d_extra;
+  std::vector<void *> d_mixed_out;  // plane-node lists / sum buffers of the current forcing's mixed-out sponge zones
   // device data
   double *d_verts = nullptr;
   int2 *d_face_info = nullptr;
@@ -162,6 +173,7 @@ struct tpsrhs_operator {
       if (e) (void)hipEventDestroy(e);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
     for (void *p : d_extra) (void)hipFree(p);
+    for (void *p : d_mixed_out) (void)hipFree(p);
     for (auto &set : evs)
       for (auto &e : set)
         if (e) (void)hipEventDestroy(e);

@@ -555,7 +555,7 @@ struct DryAirPhys {
   // ---- non-reflecting inlet (src/inletBC.cpp:576-727) and outlets (src/outletBC.cpp:573-728, 739-892,
   // 894-1027): characteristic estimate of dU/dt at a boundary point from the patch mean of the primitives, the
   // normal gradient and the target; `state2` (the boundary state the Riemann solver sees) advanced by dt -> newU.
-  __device__ static inline void nr_update(const Params &p, const BcDev &bc, const double *meanUp, const double *n,
+  __device__ static inline void nr_update(const Params &p, const BcDev &bc, double dt, const double *meanUp, const double *n,
                                           const double *U, const double *g, const double *state2, double *newU) {
     const bool inlet = bc.category == TPSRHS_INLET;
     double un[DIM], t1[DIM], t2[3] = {0.0, 0.0, 0.0};
@@ -678,7 +678,7 @@ struct DryAirPhys {
       if constexpr (DIM == 3) sn[3] += state2[1 + d] * t2[d];
     }
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) newU[eq] = sn[eq] - p.nr_dt * f[eq];
+    for (int eq = 0; eq < NEQ; eq++) newU[eq] = sn[eq] - dt * f[eq];
     if constexpr (DIM == 2) {
       const double det = un[0] * t1[1] - un[1] * t1[0];
       const double m0 = newU[1], m1 = newU[2];

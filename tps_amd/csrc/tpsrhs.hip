@@ -530,8 +530,15 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
                                                 : (d.sgs_type == TPSRHS_SGS_SMAGORINSKY ? 0.12 : (d.sgs_type == TPSRHS_SGS_SIGMA ? 0.135 : 0.0));
       d.sgs_floor = phys->sgs.model_floor;
       d.vs_enabled = phys->visc_sponge.enabled ? 1 : 0;
+      // "ensure normal is actually a unit normal": the constructor every CPU build of the reference uses, and its host
+      // fluxClass, normalise vsd_.n (src/fluxes.cpp:77-90, src/M2ulPhyS.cpp:612-616); the device constructor
+      // (:98-125) copies it as given.  The CPU path is this library's referent.
+      double nmag = 0.0;
+      for (int k = 0; k < op->dim; k++) nmag += phys->visc_sponge.normal[k] * phys->visc_sponge.normal[k];
+      nmag = std::sqrt(nmag);
+      if (phys->visc_sponge.enabled && !(nmag > 0.0)) throw std::invalid_argument("visc_sponge.normal is zero");
       for (int k = 0; k < 3; k++) {
-        d.vs_n[k] = (k < op->dim) ? phys->visc_sponge.normal[k] : 0.0;  // vsd.n / vsd.p: dim entries, the rest 0 (:590-596)
+        d.vs_n[k] = (k < op->dim && nmag > 0.0) ? phys->visc_sponge.normal[k] / nmag : 0.0;  // vsd.n / vsd.p: dim entries, the rest 0
         d.vs_p[k] = (k < op->dim) ? phys->visc_sponge.point[k] : 0.0;
       }
       d.vs_width = phys->visc_sponge.enabled ? phys->visc_sponge.width : 1.0;
@@ -866,6 +873,17 @@ int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *in) {
   return guarded([&] {
     ForcingDev f = {};
     f.joule = h->forcing.joule;
+    // plane-node lists and sum buffers of the mixed-out zones of THIS call; they replace the previous call's, which
+    // are freed once the new block is in place (or these, if the call fails: the old forcing then stays as it was)
+    std::vector<void *> fresh;
+    struct Guard {
+      std::vector<void *> &v;
+      bool keep = false;
+      ~Guard() {
+        if (!keep)
+          for (void *q : v) (void)hipFree(q);
+      }
+    } guard{fresh};
     if (in) {
       if (in->num_heat_sources < 0 || in->num_heat_sources > TPSRHS_MAXHEATSOURCES || in->num_sponge_zones < 0 ||
           in->num_sponge_zones > TPSRHS_MAXSPONGEZONES)
@@ -946,12 +964,16 @@ int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *in) {
           }
           if (nodes.empty() && h->topo.num_shared == 0)
             throw std::invalid_argument("tpsrhs_set_forcing: no node within tol of the mix-out plane");
+          // the plane sums are added over the ranks (MPI_Allreduce of src/forcing_terms.cpp:732-735): without the hook a
+          // partitioned run would use rank-local means, and a rank without plane nodes 0 / 0
+          if (h->topo.num_shared > 0 && !h->reduce)
+            throw std::invalid_argument("tpsrhs_set_forcing: a mixed-out sponge zone on a partitioned mesh needs runtime.reduce");
           d.mixed_out = 1;
           d.n_plane = static_cast<int>(nodes.size());
           int *dn = dev_upload(nodes);
           double *ds = dev_alloc<double>(TPSRHS_MAXEQUATIONS + 1);
-          h->d_extra.push_back(dn);
-          h->d_extra.push_back(ds);
+          fresh.push_back(dn);
+          fresh.push_back(ds);
           d.plane_nodes = dn;
           d.msum = ds;
           for (int eq = 0; eq < TPSRHS_MAXEQUATIONS; eq++) d.target[eq] = 0.0;
@@ -963,8 +985,14 @@ int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *in) {
       }
     }
     h->forcing = f;
+    std::vector<void *> old;
+    old.swap(h->d_mixed_out);
+    h->d_mixed_out = fresh;
+    guard.keep = true;
     h->config_epoch++;
-    upload_forcing(h);
+    upload_forcing(h);  // synchronises the stream before it overwrites the device block
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (void *q : old) (void)hipFree(q);
   });
 }
 

@@ -38,6 +38,17 @@ class HaloExchange:
         self.skip = False  # timing experiments only: return without exchanging (the halo then holds stale traces)
         self._plans = {}
 
+    def _torch_stream(self, ptr):
+        """The torch stream object of a raw ``hipStream_t``.  A NULL pointer is the legacy default stream and must be
+        mapped to ``torch.cuda.default_stream``: ``torch.cuda.ExternalStream(0)`` does NOT wrap it -- with a zero
+        pointer torch's stream constructor takes a fresh NON-BLOCKING stream from its pool (checked on the GPU box,
+        ``tools/probe_external_stream.py``), and copies issued there are not ordered with the operator's kernels on the
+        NULL stream.  That was the cause of the intermittent 3-rank failure of round 2."""
+        ptr = int(ptr or 0)
+        if ptr == 0:
+            return torch.cuda.default_stream(self.device)
+        return torch.cuda.ExternalStream(ptr, device=self.device)
+
     def _view(self, ptr, n):
         if self.host_buffers:
             arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,))
@@ -54,7 +65,7 @@ class HaloExchange:
             # a failing exchange is an error (TPSRHS_ERR_HALO), never a silent change of transport: the ranks of a
             # job cannot switch backends one by one, and a degraded run must not be reported as an RCCL number
             if not self.host_buffers and torch.cuda.is_available():
-                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0), device=self.device)):
+                with torch.cuda.stream(self._torch_stream(stream)):
                     return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
             return self._exchange(send, recv, nnbr, ranks, send_off, recv_off)
         except Exception as exc:  # never let an exception cross the C boundary
@@ -74,7 +85,7 @@ class HaloExchange:
                 t = self._view(values, count)
                 dist.all_reduce(t, op=rop, group=self.group)
                 return 0
-            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0), device=self.device)):
+            with torch.cuda.stream(self._torch_stream(stream)):
                 t = self._view(values, count)
                 if self.backend == "nccl":
                     dist.all_reduce(t, op=rop, group=self.group)
