@@ -70,7 +70,9 @@ def test_halo_hook_is_ordered_on_the_null_stream(monkeypatch):
         return []
 
     monkeypatch.setattr(dist, "batch_isend_irecv", fake_batch)
-    monkeypatch.setattr(dist, "P2POp", lambda op, tensor, peer, group=None: type("Op", (), {"op": op, "tensor": tensor})())
+    from types import SimpleNamespace
+
+    monkeypatch.setattr(dist, "P2POp", lambda op, tensor, peer, group=None: SimpleNamespace(op=op, tensor=tensor))
     h = HaloExchange(device=dev)
     send = torch.zeros(32, dtype=torch.float64, device=dev)
     recv = torch.zeros(32, dtype=torch.float64, device=dev)

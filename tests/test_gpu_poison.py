@@ -32,14 +32,14 @@ def test_poisoned_dry_air_cylinder():
 
 def test_poisoned_partial_blocks_p1_p2():
     """orders whose blocks hold several elements, with element counts that leave the last block partly empty"""
-    for order, dims in ((1, (5, 8, 2)), (2, (3, 9, 3))):  # 80 elements in blocks of 3, 81 in blocks of 2
+    for order, dims in ((1, (5, 8, 4)), (2, (3, 9, 3))):  # 160 elements in blocks of 3, 81 in blocks of 2
         c = cases.cyl3d(*dims, order, capi.NS, capi.VISC_ADIAB)
         c.physics.dry_air.visc_mult = 2000.0
         _check(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=4), RHS_RTOL)
 
 
 def test_poisoned_gll_pair():
-    mesh = meshgen.scramble_orientations(meshgen.box_hex(3, 3, 2, lengths=(1.0, 0.8, 1.2), warp=0.1), 3)
+    mesh = meshgen.scramble_orientations(meshgen.box_hex(3, 3, 3, lengths=(1.0, 0.8, 1.2), warp=0.1), 3)
     disc = capi.Disc(3, 1, 1, 0, 0)
     ph = capi.dry_air_physics(capi.NS, visc_mult=500.0)
     _check(mesh, disc, ph, [], cases.dry_air_state(node_coordinates(mesh, 3, 1), seed=6), 5 * RHS_RTOL)

@@ -1,0 +1,58 @@
+"""Register-spill hygiene of the shipped kernels (tools/spill_lib.py reads the code-object metadata of every kernel in
+tps_amd/csrc/_obj): the set of kernels that spill VGPRs or use scratch must equal the committed allow-list
+(tests/golden/spill_allowlist.txt), so that a new spiller fails the CPU suite and the build, and none of the kernels a
+bench workload or a BASELINE.json configuration launches may be on it.
+
+Why: round 2 met two heavily spilling instantiations with deterministically wrong results (DESIGN.md section 5,
+"Spilled instantiations"); correctness of a spilling kernel rests on the parity suite and the randomised sweeps only.
+Regenerate the list with `python tools/spill_report.py --write-allowlist` after a deliberate change."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+ALLOW = os.path.join(ROOT, "tests", "golden", "spill_allowlist.txt")
+
+# (Cfg, physics) of every kernel the bench workloads and the BASELINE.json configurations launch
+BENCH_INSTANTIATIONS = {
+    "argon_p3 (the metric's workload)": "Cfg<3,3,0>,PlasmaPhys<3,3,3,true,false,1>",
+    "cfg3 = configs[2]": "Cfg<3,2,0>,PlasmaPhys<3,3,3,true,false,1>",
+    "cfg2 / cfg4 = configs[1], configs[3]": "Cfg<3,3,0>,DryAirPhys<3,false,false>",
+    "cfg1 = configs[0]": "Cfg<3,1,0>,DryAirPhys<3,false,false>",
+    "cfg5 = configs[4]": "Cfg<2,3,0>,PlasmaPhys<2,3,3,true,true,0>",
+    "torch6": "Cfg<2,3,0>,PlasmaPhys<2,3,6,false,true,0>",
+    "gll_dry (Gauss-Lobatto pair, dry air p=3)": "Cfg<3,3,1>,DryAirPhys<3,false,false>",
+}
+
+
+@pytest.fixture(scope="module")
+def census():
+    import spill_lib
+
+    if not os.path.isdir(spill_lib.OBJ) or not any(f.endswith(".o") for f in os.listdir(spill_lib.OBJ)):
+        pytest.skip("no object files (tps_amd/csrc/_obj): the census runs where the library was built")
+    return spill_lib.census()
+
+
+def spillers(census):
+    return sorted({k["kernel"] for k in census if k["vgpr_spill"] > 0 or k["scratch"] > 0})
+
+
+def test_spilling_kernels_equal_the_allow_list(census):
+    allowed = [l.strip() for l in open(ALLOW) if l.strip() and not l.startswith("#")]
+    got = spillers(census)
+    new = sorted(set(got) - set(allowed))
+    gone = sorted(set(allowed) - set(got))
+    assert not new, f"{len(new)} kernels spill VGPRs / use scratch and are not on the allow-list, e.g. {new[:5]}"
+    assert not gone, f"{len(gone)} kernels of the allow-list no longer spill: regenerate it, e.g. {gone[:5]}"
+
+
+def test_bench_and_baseline_kernels_do_not_spill(census):
+    bad = []
+    for what, inst in BENCH_INSTANTIATIONS.items():
+        ks = [k for k in census if ("<" + inst + ">") in k["kernel"]]
+        assert any(k["kernel"].startswith("k_flux<") for k in ks), f"no kernel of {what} ({inst}) in the build"
+        bad += [(what, k["kernel"], k["vgpr_spill"], k["scratch"]) for k in ks if k["vgpr_spill"] > 0 or k["scratch"] > 0]
+    assert not bad, bad

@@ -109,6 +109,19 @@ struct Stamper {
 // (first index: 0 the collocated Gauss-Legendre pair, 1 the non-collocated Gauss-Lobatto pair)
 static __constant__ Tables1D c_tab[2][2][TPSRHS_MAXORDER + 1];
 
+// A fresh view of a __constant__ table: loads through the result cannot be moved above this point (nor merged with
+// earlier ones), so a stage placed after it fetches its coefficients with scalar loads where it uses them.  Without
+// it the loop-invariant code motion keeps all 1-D operators (~70 SGPRs at p = 3) live across the point physics of
+// the heavy kernels, where they are spilled to VGPR lanes and come back through v_readlane (VALU issue).
+__device__ inline const Tables1D &fresh_table(const Tables1D &ct) {
+  typedef const Tables1D __attribute__((address_space(4))) *CP;
+  const unsigned long long a = reinterpret_cast<unsigned long long>(&ct);
+  unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a));
+  unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return *(const Tables1D *)reinterpret_cast<CP>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 // LDS read of one double (a hook: a volatile-typed variant that stops hipcc from fusing neighbouring
 // 8-byte reads into ds_read2_b64 was measured and dropped -- volatile LDS accesses are followed by a
 // full s_waitcnt, which serialises the line stages; see DESIGN.md "What was tried").
@@ -656,8 +669,9 @@ __device__ inline void traces_dir(const MeshDev &m, int e0, const double *sF, do
 }
 
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
+__global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::KArg prm_k, const double *__restrict__ U,
                                                      double *__restrict__ TA) {
+  typename PH::PRef prm = PH::pref(prm_k);
   constexpr int NEQ = PH::NEQ;
   const Tables1D &ct = c_tab[C::NC][C::DIM - 2][C::P];
   __shared__ double sF[2 * NEQ * C::NODES];
@@ -993,7 +1007,7 @@ __device__ inline void nc_apply_minv(const double *__restrict__ minv, double *sR
 // src/faceGradientIntegration.cpp:40-140): g[eq + d*NEQ] += sum_q w_q phi_j(q) 1/2 (Up2 - Up1)(q) n_d(q) over the two
 // faces of direction D.  sT: own | neighbour traces of Up at the face nodes, [2*NEQ][TN]; scr: >= 2*NEQ*TW + NEQ*TQ.
 template <class C, class PH, int D>
-__device__ inline void nc_grad_jump(const int2 *sFI, const typename PH::Params &prm, double *sT, double *scr, const double *sV,
+__device__ inline void nc_grad_jump(const int2 *sFI, typename PH::PRef prm, double *sT, double *scr, const double *sV,
                                     const Tab<C> &tab, const Tables1D &ct, bool node_on, int le_n, const int *idx, int tid,
                                     double *g) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
@@ -1107,7 +1121,7 @@ __device__ inline void face_normal_rt(int d, const double *V, int s, double ta, 
 // `D` is a run-time value and the face loop is not unrolled: one face's operands are live at a time
 // (with the six faces unrolled the kernel needs > 256 VGPRs)
 template <class C, class PH>
-__device__ inline void grad_jump_nodal(int D, const int2 *sFI, const typename PH::Params &prm, const double *Town,
+__device__ inline void grad_jump_nodal(int D, const int2 *sFI, typename PH::PRef prm, const double *Town,
                                        const double *Tnb, const double *sV, const Tab<C> &tab, int le_n, const int *idx,
                                        double inv_mass, double *g) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
@@ -1217,7 +1231,7 @@ struct FaceDist {
   double d[ROUNDS] = {};
 };
 template <class C, class PH, bool BOTH = false>
-__device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0, int d,
+__device__ inline void visc_points(const MeshDev &m, const int2 *sFI, typename PH::PRef prm0, int e0, int d,
                                    double (&v)[BOTH ? C::Q2_ROUNDS : C::Q_ROUNDS][GradLds<C, PH>::NVF], const double *sV,
                                    const Tab<C> &tab, double *__restrict__ TB, int tid,
                                    const FaceDist<BOTH ? C::Q2_ROUNDS : C::Q_ROUNDS> &dq = FaceDist<BOTH ? C::Q2_ROUNDS : C::Q_ROUNDS>()) {
@@ -1237,6 +1251,7 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const type
     if (e >= m.ne) continue;
     const int slot = e * C::NFACES + 2 * d + s;
     const int nb = sFI[le * C::NFACES + 2 * d + s].x;
+    typename PH::PRef prm = PH::relaunder(prm0);
     double fn[NEQ];
     PH::clamp_species(v[rd]);
     double n[DIM], wq, Xq[DIM];
@@ -1274,9 +1289,10 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, const type
 // normal derivative sum_d n_d d(.)/dx_d is accumulated -- heat and diffusion fluxes are linear in it.  12-15
 // interpolated values per point instead of 24, and none of them live across the closure.
 template <class C, class PH, int D>
-__device__ inline void visc_state_dir(const double *sU, double *Tb, double *Wb, const Tab<C> &tab, const Tables1D &ct,
+__device__ inline void visc_state_dir(const double *sU, double *Tb, double *Wb, const Tab<C> &tab, const Tables1D &ct0,
                                       double *u, int tid) {
   constexpr int NEQ = PH::NEQ;
+  const Tables1D &ct = fresh_table(ct0);
   trace_lines<C, D, NEQ>(sU, Tb, ct, tid);
   block_sync<C::BLOCK>();
   interp1_lines<C, NEQ>(Tb, Wb, ct, tid);
@@ -1293,13 +1309,14 @@ __device__ inline void visc_state_dir(const double *sU, double *Tb, double *Wb, 
 }
 // sG: the nodal gradient [d][eq][NODES]; gv[i + j*DIM] = d u_i / d x_j; gn[eq] = normal derivative (scalar rows)
 template <class C, class PH, int D>
-__device__ inline void visc_grad_dir(const double *sG, double *Tb, double *Wb, const Tab<C> &tab, const Tables1D &ct,
+__device__ inline void visc_grad_dir(const double *sG, double *Tb, double *Wb, const Tab<C> &tab, const Tables1D &ct0,
                                      const double *n, double *gv, double *gn, int tid) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM, NVEL = PH::NVEL;
 #pragma unroll
   for (int eq = 0; eq < NEQ; eq++) gn[eq] = 0.0;
 #pragma unroll
   for (int c = 0; c < DIM; c++) {
+    const Tables1D &ct = fresh_table(ct0);
     trace_lines<C, D, NEQ>(sG + c * NEQ * C::NODES, Tb, ct, tid);
     block_sync<C::BLOCK>();
     interp1_lines<C, NEQ>(Tb, Wb, ct, tid);
@@ -1322,13 +1339,14 @@ __device__ inline void visc_grad_dir(const double *sG, double *Tb, double *Wb, c
   }
 }
 template <class C, class PH>
-__device__ inline void visc_phase_heavy3d(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
+__device__ inline void visc_phase_heavy3d(const MeshDev &m, const int2 *sFI, typename PH::PRef prm0, int e0,
                                           const double *sU, const double *sG, double *Tb, double *Wb, const double *sV,
                                           const Tab<C> &tab, const Tables1D &ct, double *__restrict__ TB, int tid0 STAMP_PARAM) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   static_assert(DIM == 3 && C::Q_ROUNDS == 1 && PH::NVEL == 3, "3-D, one round of face points per direction pair");
 #pragma clang loop unroll(disable)
   for (int d = 0; d < DIM; d++) {
+    typename PH::PRef prm = PH::relaunder(prm0);  // the parameter loads of this direction stay inside it
     const int tid = tid0;
     const int pf = tid / C::NQ, q = tid - pf * C::NQ;
     const int le = pf >> 1, s = pf & 1;
@@ -1370,8 +1388,9 @@ __device__ inline void visc_phase_heavy3d(const MeshDev &m, const int2 *sFI, con
       typename PH::WallFlux w;
       typename PH::ViscCoef cf;
       if (pass < np_lane) {
-        PH::visc_pass_state(prm, nb, pass, u, n, Us, w);
-        PH::visc_point_coeffs(prm, Us, !w.species, cf);
+        typename PH::PRef pq = PH::relaunder(prm);
+        PH::visc_pass_state(pq, nb, pass, u, n, Us, w);
+        PH::visc_point_coeffs(pq, Us, !w.species, cf);
       }
       STAMP(6);
       double gv[DIM * DIM], gn[NEQ];
@@ -1384,7 +1403,7 @@ __device__ inline void visc_phase_heavy3d(const MeshDev &m, const int2 *sFI, con
       STAMP(7);
       if (pass < np_lane) {
         double f[NEQ];
-        PH::visc_normal_flux_n(prm, Us, cf, gv, gn, n, w, f);
+        PH::visc_normal_flux_n(PH::relaunder(prm), Us, cf, gv, gn, n, w, f);
         if (nb >= 0) {
 #pragma unroll
           for (int eq = 0; eq < NEQ; eq++) fn[eq] = f[eq];
@@ -1405,7 +1424,7 @@ __device__ inline void visc_phase_heavy3d(const MeshDev &m, const int2 *sFI, con
 }
 // 2-D viscous phase: both direction pairs at once (see Cfg::TQ2)
 template <class C, class PH>
-__device__ inline void visc_phase_2d(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
+__device__ inline void visc_phase_2d(const MeshDev &m, const int2 *sFI, typename PH::PRef prm, int e0,
                                      const double *sU, const double *g, bool node_on, double *sJ, double *Tb,
                                      const double *sV, const Tab<C> &tab, const Tables1D &ct, double *__restrict__ TB,
                                      int tid, const double *sDist = nullptr) {
@@ -1483,7 +1502,7 @@ __device__ inline void visc_phase_2d(const MeshDev &m, const int2 *sFI, const ty
   visc_points<C, PH, true>(m, sFI, prm, e0, 0, v, sV, tab, TB, tid, dq);
 }
 template <class C, class PH, int D>
-__device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const typename PH::Params &prm, int e0,
+__device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, typename PH::PRef prm, int e0,
                                        const double *sU, const double *g, bool node_on, double *sJ, double *Tb, double *Wb,
                                        const double *sV, const Tab<C> &tab, const Tables1D &ct, double *__restrict__ TB,
                                        int tid) {
@@ -1493,10 +1512,11 @@ __device__ inline void visc_traces_dir(const MeshDev &m, const int2 *sFI, const 
 }
 
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(C::DIM, C::P, C::NC)) void k_gradient(MeshDev m, typename PH::Params prm,
+__global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(C::DIM, C::P, C::NC)) void k_gradient(MeshDev m, typename PH::KArg prm_k,
                                                        const double *__restrict__ U, const double *__restrict__ TA,
                                                        double *__restrict__ Upout, double *__restrict__ gradUp,
                                                        double *__restrict__ TB) {
+  typename PH::PRef prm = PH::pref(prm_k);
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   typedef GradLds<C, PH> L;
   const Tables1D &ct = c_tab[C::NC][DIM - 2][C::P];
@@ -1691,7 +1711,7 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
 // The optional forcing terms at one node (added to y after the inverse mass, src/rhs_operator.cpp:451-461).
 //   X: node position; u, st: conserved state and its closure; gr: gradUp[eq + d*NEQ]
 template <class C, class PH>
-__device__ inline void apply_forcing(const ForcingDev &f, const typename PH::Params &prm, int64_t node, const double *X,
+__device__ inline void apply_forcing(const ForcingDev &f, typename PH::PRef prm, int64_t node, const double *X,
                                      const double *u, const typename PH::State &st, const double *gr, double *src) {
   constexpr int NEQ = PH::NEQ, DIM = C::DIM, NVEL = PH::NVEL;
   // ConstantPressureGradient::updateTerms, src/forcing_terms.cpp:150-170 (dim, not nvel: no pressure
@@ -1804,7 +1824,7 @@ __device__ inline void apply_forcing(const ForcingDev &f, const typename PH::Par
 // flux of one point use the state before the update); the host swaps the two buffers after the Mult.
 // =============================================================================================
 template <class C, class PH>
-__device__ inline const double *nr_state(const typename PH::Params &prm, int nb, int slot, int q) {
+__device__ inline const double *nr_state(typename PH::PRef prm, int nb, int slot, int q) {
   if constexpr (PH::HAS_NR_BC) {
     const auto &bc = prm.bc[-nb - 1];
     if (is_non_reflecting(bc.category, bc.type))
@@ -1864,11 +1884,12 @@ __global__ __launch_bounds__(256) void k_bc_mean(int nfaces, const int2 *__restr
 
 // One block per face of a non-reflecting patch, one lane per face quadrature point.
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK) void k_bc_nr(MeshDev m, const typename PH::Params prm, const int2 *__restrict__ faces,
+__global__ __launch_bounds__(C::BLOCK) void k_bc_nr(MeshDev m, typename PH::KArg prm_k, const int2 *__restrict__ faces,
                                               const double *__restrict__ sums, const double *__restrict__ U,
                                               const double *__restrict__ Up, const double *__restrict__ gradUp,
                                               double *__restrict__ state_old, double *__restrict__ state_new, int first,
                                               const double *__restrict__ dt_dev) {
+  typename PH::PRef prm = PH::pref(prm_k);
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   // tpsrhs_advance keeps dt in device memory.  (Not written into `prm`: a kernel that modifies its by-value
   // parameter block gets a private copy of all of it -- 1.9 KB of scratch per lane in round 2.)
@@ -1934,8 +1955,9 @@ __global__ __launch_bounds__(C::BLOCK) void k_bc_nr(MeshDev m, const typename PH
 // nodes of the mix-out plane -- one block, fixed summation order -- then (after the sum over the ranks) the
 // mixed-out state of the mean flux becomes the zone's target.
 template <class C, class PH>
-__global__ __launch_bounds__(256) void k_mixed_out_sum(int64_t ndofs, typename PH::Params prm, const ForcingDev *fd, int z,
+__global__ __launch_bounds__(256) void k_mixed_out_sum(int64_t ndofs, typename PH::KArg prm_k, const ForcingDev *fd, int z,
                                                        const double *__restrict__ U) {
+  typename PH::PRef prm = PH::pref(prm_k);
   constexpr int NEQ = PH::NEQ;
   const ForcingDev::Sponge &sz = fd->sponge[z];
   __shared__ double red[256];
@@ -1965,7 +1987,8 @@ __global__ __launch_bounds__(256) void k_mixed_out_sum(int64_t ndofs, typename P
   if (tid == 0) sz.msum[NEQ] = static_cast<double>(sz.n_plane);
 }
 template <class C, class PH>
-__global__ void k_mixed_out_finish(typename PH::Params prm, ForcingDev *fd, int z) {
+__global__ void k_mixed_out_finish(typename PH::KArg prm_k, ForcingDev *fd, int z) {
+  typename PH::PRef prm = PH::pref(prm_k);
   constexpr int NEQ = PH::NEQ;
   ForcingDev::Sponge &sz = fd->sponge[z];
   double mean[NEQ], tgt[NEQ];
@@ -1981,9 +2004,10 @@ __global__ void k_mixed_out_finish(typename PH::Params prm, ForcingDev *fd, int 
 // y += optional forcing terms: a streaming pass of its own (one lane per node), launched after k_flux
 // only when such a term is configured -- the hot sweeps carry neither its registers nor a branch.
 template <class C, class PH>
-__global__ __launch_bounds__(256) void k_forcing(MeshDev m, typename PH::Params prm, const ForcingDev *__restrict__ fd,
+__global__ __launch_bounds__(256) void k_forcing(MeshDev m, typename PH::KArg prm_k, const ForcingDev *__restrict__ fd,
                                                  const double *__restrict__ U, const double *__restrict__ gradUp,
                                                  double *__restrict__ Y) {
+  typename PH::PRef prm = PH::pref(prm_k);
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   const Tables1D &ct = c_tab[C::NC][DIM - 2][C::P];
   const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -2031,7 +2055,7 @@ struct FluxLds {
 };
 
 template <class C, class PH, int D>
-__device__ inline void face_flux_dir(const MeshDev &m, const typename PH::Params &prm, int e0, const double *sU,
+__device__ inline void face_flux_dir(const MeshDev &m, typename PH::PRef prm, int e0, const double *sU,
                                      double *X, double *Yb, const double *sV, const Tab<C> &tab, const Tables1D &ct,
                                      const NbTraces<C, PH::NEQ> &ta, const NbFlux<C, PH::NEQ> &tb, bool node_on,
                                      int le_n, const int *idx, double *z, int tid) {
@@ -2143,7 +2167,7 @@ __device__ inline void issue_visc_traces_2d(const int2 *sFI, int e0, const doubl
   }
 }
 template <class C, class PH>
-__device__ inline void face_flux_2d(const MeshDev &m, const typename PH::Params &prm, int e0, const double *sU, double *X,
+__device__ inline void face_flux_2d(const MeshDev &m, typename PH::PRef prm, int e0, const double *sU, double *X,
                                     double *Yb, const double *sV, const Tab<C> &tab, const Tables1D &ct,
                                     const NbTraces<C, PH::NEQ> &ta0, const NbTraces<C, PH::NEQ> &ta1,
                                     const NbFlux2<C, PH::NEQ> &tb, bool node_on, int le_n, const int *idx, double *z,
@@ -2222,10 +2246,11 @@ __device__ inline void face_flux_2d(const MeshDev &m, const typename PH::Params 
 }
 
 template <class C, class PH>
-__global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2)) ? (PH::HEAVY ? 1 : 2) : PH::MINW_FLUX) void k_flux(MeshDev m, typename PH::Params prm, const double *__restrict__ U,
+__global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2)) ? (PH::HEAVY ? 1 : 2) : PH::MINW_FLUX) void k_flux(MeshDev m, typename PH::KArg prm_k, const double *__restrict__ U,
                                                    const double *__restrict__ gradUp, const double *__restrict__ TA,
                                                    const double *__restrict__ TB, double *__restrict__ Y,
                                                    double *__restrict__ block_speed) {
+  typename PH::PRef prm = PH::pref(prm_k);
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   typedef FluxLds<C, PH> L;
   const Tables1D &ct = c_tab[C::NC][DIM - 2][C::P];
@@ -2470,8 +2495,9 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
 // Point-wise closures of the gas model for n states U[eq + ...]: U is [NEQ][n] (byNODES), one lane per state
 // (tpsrhs_eval_pointwise).  quantity: 0 primitives -> out[NEQ][n], 1 pressure, 2 speed of sound, 3 |u| + c -> out[n]
 template <class PH>
-__global__ __launch_bounds__(256) void k_point_eval(typename PH::Params prm, int quantity, int64_t n,
+__global__ __launch_bounds__(256) void k_point_eval(typename PH::KArg prm_k, int quantity, int64_t n,
                                                     const double *__restrict__ U, double *__restrict__ out) {
+  typename PH::PRef prm = PH::pref(prm_k);
   constexpr int NEQ = PH::NEQ;
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;

@@ -76,6 +76,7 @@ struct tpsrhs_operator {
   tpsrhs_physics phys;
   alignas(16) unsigned char params[4096];  // PH::Params of the selected physics, passed by value
   void *d_chem = nullptr;                   // ChemDev block + table storage (plasma)
+  void *d_params = nullptr;                 // device image of `params` for the physics that read it through a pointer (plasma)
   std::vector<void *> d_extra;
   std::vector<void *> d_mixed_out;  // plane-node lists / sum buffers of the current forcing's mixed-out sponge zones
   // device data
@@ -159,6 +160,7 @@ struct tpsrhs_operator {
                     static_cast<void *>(d_shared_orient), static_cast<void *>(d_send)})
       if (p) (void)hipFree(p);
     if (d_chem) (void)hipFree(d_chem);
+    if (d_params) (void)hipFree(d_params);
     if (d_minv) (void)hipFree(d_minv);
     if (d_rk) (void)hipFree(d_rk);
     if (d_nan) (void)hipFree(d_nan);
@@ -181,6 +183,22 @@ struct tpsrhs_operator {
 };
 
 namespace {
+
+// The parameter block as the kernels of physics PH take it: by value (dry air) or as a pointer to its device image
+// (plasma: PlasmaPhys::KArg), uploaded once -- the block is complete when the first kernel is launched and nothing
+// changes it afterwards (the dry-air block, which the non-reflecting conditions update per Mult, travels by value).
+template <class PH>
+typename PH::KArg kernel_params(tpsrhs_operator *op) {
+  if constexpr (std::is_pointer<typename PH::KArg>::value) {
+    if (!op->d_params) {
+      op->d_params = dev_alloc<unsigned char>(sizeof(op->params));
+      HIP_CHECK(hipMemcpy(op->d_params, op->params, sizeof(op->params), hipMemcpyHostToDevice));
+    }
+    return reinterpret_cast<typename PH::KArg>(op->d_params);
+  } else {
+    return *reinterpret_cast<const typename PH::Params *>(op->params);
+  }
+}
 
 inline void exchange(tpsrhs_operator *op, int phase, double *T, int nfld, int per, hipStream_t stream) {
   const Topology &tp = op->topo;
@@ -205,7 +223,7 @@ template <int DIM, int P, class PH, int NC = 0>
 void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_only) {
   typedef Cfg<DIM, P, NC> C;
   static_assert(sizeof(typename PH::Params) <= sizeof(op->params), "parameter block too large");
-  const typename PH::Params &prm = *reinterpret_cast<const typename PH::Params *>(op->params);
+  const typename PH::Params &prm = *reinterpret_cast<const typename PH::Params *>(op->params);  // host copy
   const int nblocks = (op->ne + C::EPB - 1) / C::EPB;
   hipStream_t s = op->stream;
   if constexpr (PH::HAS_NR_BC) {  // this Mult's view of the non-reflecting boundary state
@@ -214,21 +232,22 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     w.nr_ordinal = op->d_nr_ordinal;
     w.nr_dt = op->nr_dt;
   }
+  const typename PH::KArg prm_k = kernel_params<PH>(op);  // after the update above: what the kernels of this Mult get
   if (!op->d_block_speed && !gradients_only) {
     op->d_block_speed = dev_alloc<double>(nblocks);
     op->flux_grid = nblocks;
   }
   auto traces = [&](const MeshDev &m, int grid) {
-    hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_TA);
+    hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_TA);
     HIP_CHECK(hipGetLastError());
   };
   auto gradient = [&](const MeshDev &m, int grid) {
-    hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_TA, op->d_Up, op->d_gradUp,
+    hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_TA, op->d_Up, op->d_gradUp,
                        op->d_TB);
     HIP_CHECK(hipGetLastError());
   };
   auto flux = [&](const MeshDev &m, int grid) {
-    hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm, x, op->d_gradUp, op->d_TA, op->d_TB, y,
+    hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_gradUp, op->d_TA, op->d_TB, y,
                        op->d_block_speed);
     HIP_CHECK(hipGetLastError());
   };
@@ -246,7 +265,7 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
         if (st != 0) throw std::runtime_error("halo: reduce callback failed");
       }
       if (op->n_nr_faces > 0) {
-        hipLaunchKernelGGL((k_bc_nr<C, PH>), dim3(op->n_nr_faces), dim3(C::BLOCK), 0, s, m, prm, op->d_nr_faces, op->d_bc_sums, x,
+        hipLaunchKernelGGL((k_bc_nr<C, PH>), dim3(op->n_nr_faces), dim3(C::BLOCK), 0, s, m, prm_k, op->d_nr_faces, op->d_bc_sums, x,
                            op->d_Up, op->d_gradUp, op->d_bstate[op->bstate_cur], op->d_bstate[1 - op->bstate_cur],
                            op->bstate_init ? 0 : 1, op->nr_dt_dev);
         HIP_CHECK(hipGetLastError());
@@ -259,18 +278,18 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     if constexpr (PH::HAS_MIXED_OUT) {  // SpongeZone::updateTerms: computeMixedOutValues first (src/forcing_terms.cpp:631-635)
       for (int z = 0; z < op->forcing.nsponge; z++) {
         if (!op->forcing.sponge[z].mixed_out) continue;
-        hipLaunchKernelGGL((k_mixed_out_sum<C, PH>), dim3(1), dim3(256), 0, s, op->ndofs, prm, op->d_forcing, z, x);
+        hipLaunchKernelGGL((k_mixed_out_sum<C, PH>), dim3(1), dim3(256), 0, s, op->ndofs, prm_k, op->d_forcing, z, x);
         HIP_CHECK(hipGetLastError());
         if (op->reduce && op->topo.num_shared > 0) {  // MPI_Allreduce of meanNormalFluxes, :732-735
           const int st = op->reduce(op->reduce_ctx, op->forcing.sponge[z].msum, PH::NEQ + 1, TPSRHS_REDUCE_SUM, s);
           if (st != 0) throw std::runtime_error("mixed-out sponge: reduce callback failed");
         }
-        hipLaunchKernelGGL((k_mixed_out_finish<C, PH>), dim3(1), dim3(1), 0, s, prm, op->d_forcing, z);
+        hipLaunchKernelGGL((k_mixed_out_finish<C, PH>), dim3(1), dim3(1), 0, s, prm_k, op->d_forcing, z);
         HIP_CHECK(hipGetLastError());
       }
     }
     const int grid = static_cast<int>((op->ndofs + 255) / 256);
-    hipLaunchKernelGGL((k_forcing<C, PH>), dim3(grid), dim3(256), 0, s, m, prm, op->d_forcing, x, op->d_gradUp, y);
+    hipLaunchKernelGGL((k_forcing<C, PH>), dim3(grid), dim3(256), 0, s, m, prm_k, op->d_forcing, x, op->d_gradUp, y);
     HIP_CHECK(hipGetLastError());
   };
   if (op->timing) {
@@ -346,10 +365,9 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
 
 template <class PH>
 void launch_point_eval(tpsrhs_operator *op, int quantity, int64_t n, const double *U, double *out) {
-  const typename PH::Params &prm = *reinterpret_cast<const typename PH::Params *>(op->params);
   const int grid = static_cast<int>((n + 255) / 256);
   if (grid == 0) return;
-  hipLaunchKernelGGL((k_point_eval<PH>), dim3(grid), dim3(256), 0, op->stream, prm, quantity, n, U, out);
+  hipLaunchKernelGGL((k_point_eval<PH>), dim3(grid), dim3(256), 0, op->stream, kernel_params<PH>(op), quantity, n, U, out);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -139,6 +139,13 @@ __host__ __device__ inline bool is_non_reflecting(int category, int type) {
 template <int DIM_, bool NR_ = false, bool LES_ = false>
 struct DryAirPhys {
   static constexpr bool LES = LES_;
+  // the parameter block of the dry-air kernels travels by value in the kernel-argument segment (the non-reflecting
+  // flavour changes it per Mult); see PlasmaPhys::KArg for the other arrangement
+  typedef DryAirParams KArg;
+  typedef const DryAirParams &PRef;
+  typedef const BcDev &BcRef;
+  __device__ static inline PRef pref(const KArg &k) { return k; }
+  __device__ static inline PRef relaunder(PRef p) { return p; }
   static constexpr int DIM = DIM_;
   static constexpr int NVEL = DIM_;
   static constexpr int NEQ = DIM_ + 2;

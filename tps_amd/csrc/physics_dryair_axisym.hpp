@@ -26,6 +26,11 @@ struct DryAirAxiPhys {
   static constexpr bool LES = false;  // sub-grid scale models / viscous sponge: dry air, planar and 3-D
   static constexpr bool HAS_MIXED_OUT = false;  // mixed-out sponge target: dry air, planar / 3-D
   typedef DryAirParams Params;
+  typedef DryAirParams KArg;
+  typedef const DryAirParams &PRef;
+  typedef const BcDev &BcRef;
+  __device__ static inline PRef pref(const KArg &k) { return k; }
+  __device__ static inline PRef relaunder(PRef p) { return p; }
   struct State {
     double ir, k, p;
     double vel[NVEL];

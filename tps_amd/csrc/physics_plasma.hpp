@@ -219,6 +219,26 @@ struct PlasmaPhys {
   // round-2 sweep of the randomised parity driver ran in, and 20 % faster at torch6)
   static constexpr int MINW_FLUX = (NSP_ > 6 || (NSP_ > 3 && DIM_ == 3)) ? 1 : TPSRHS_PLASMA_MINW_FLUX;
   typedef PlasmaParams<NSP_> Params;
+  // How the kernels see the parameter block.  It lives in a device buffer and is read through the CONSTANT address
+  // space: every access is a scalar load (s_load) of a wave-uniform address.  Passed by value in the kernel-argument
+  // segment (round 1-2) the same loads were hoisted to the top of the kernel by the loop-invariant code motion -- some
+  // 70 SGPRs of masses, charges, reduced-mass factors ... live across every loop -- and came back lane by lane from
+  // spill VGPRs: 972 v_readlane / v_writelane of 4 581 VALU instructions in the reacting k_gradient.  `relaunder`
+  // passes the pointer through an empty asm statement: loads through the result cannot be moved above it, so a
+  // closure placed after it loads what it needs where it needs it, with SMEM instructions that cost no VALU issue.
+  typedef const Params *KArg;
+  typedef const Params __attribute__((address_space(4))) &PRef;
+  typedef const BcDev __attribute__((address_space(4))) &BcRef;
+  __device__ static inline PRef pref(KArg k) { return *(const Params __attribute__((address_space(4))) *)k; }
+  __device__ static inline PRef relaunder(PRef p) {
+    // (inside divergent control flow the compiler may hold the -- uniform -- address in VGPRs: readfirstlane brings
+    // it back to scalar registers, and folds away when it already is there)
+    const unsigned long long a = reinterpret_cast<unsigned long long>(&p);
+    unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a));
+    unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return *reinterpret_cast<const Params __attribute__((address_space(4))) *>((static_cast<unsigned long long>(hi) << 32) | lo);
+  }
   struct Transport {};
 
   // everything the closures need from one conserved state
@@ -228,7 +248,7 @@ struct PlasmaPhys {
     double n[NSP];
   };
 
-  __device__ static inline void number_densities(const Params &p, const double *U, double *n) {  // :947-961
+  __device__ static inline void number_densities(PRef p, const double *U, double *n) {  // :947-961
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++) n[sp] = 0.0;
 #pragma unroll
@@ -246,7 +266,7 @@ struct PlasmaPhys {
     }
     n[IB] = rhoB * p.imw[IB];
   }
-  __device__ static inline double heavies_cv(const Params &p, const double *n) {  // :576-584
+  __device__ static inline double heavies_cv(PRef p, const double *n) {  // :576-584
     double c = 0.0;
 #pragma unroll
     for (int sp = 0; sp < NACTIVE; sp++)
@@ -260,7 +280,7 @@ struct PlasmaPhys {
       if (sp != IE) nh += n[sp];
     return nh + n[IB];
   }
-  __device__ static inline State make_state(const Params &p, const double *U) {
+  __device__ static inline State make_state(PRef p, const double *U) {
     State s;
     number_densities(p, U, s.n);
     s.ir = fast_rcp(U[0]);
@@ -291,10 +311,10 @@ struct PlasmaPhys {
     s.c = fast_sqrt(gamma * s.p * s.ir);
     return s;
   }
-  __device__ static inline double pressure(const Params &p, const double *U) { return make_state(p, U).p; }
+  __device__ static inline double pressure(PRef p, const double *U) { return make_state(p, U).p; }
 
   // GetPrimitivesFromConservatives, :679-700
-  __device__ static inline void prim(const Params &p, const double *U, double *Up) {
+  __device__ static inline void prim(PRef p, const double *U, double *Up) {
     const State s = make_state(p, U);
     Up[0] = U[0];
 #pragma unroll
@@ -309,18 +329,18 @@ struct PlasmaPhys {
 #pragma unroll
     for (int sp = 0; sp < NACTIVE; sp++) U[NVEL + 2 + sp] = fmax(U[NVEL + 2 + sp], 0.0);
   }
-  __device__ static inline double max_char_speed(const Params &, const double *, const State &s) {  // :1359-1373
+  __device__ static inline double max_char_speed(PRef, const double *, const State &s) {  // :1359-1373
     return fast_sqrt(s.k * s.ir) + s.c;
   }
-  __device__ static inline double max_char_speed(const Params &p, const double *U) {
+  __device__ static inline double max_char_speed(PRef p, const double *U) {
     return max_char_speed(p, U, make_state(p, U));
   }
-  __device__ static inline double sound_speed(const Params &p, const double *U) {  // :1405-1432
+  __device__ static inline double sound_speed(PRef p, const double *U) {  // :1405-1432
     return make_state(p, U).c;
   }
 
   // F(U).n, src/fluxes.cpp:135-170
-  __device__ static inline void conv_flux_n(const Params &p, const double *U, const State &s, const double *n,
+  __device__ static inline void conv_flux_n(PRef p, const double *U, const State &s, const double *n,
                                             double *Fn) {
     double un = 0.0;
 #pragma unroll
@@ -333,7 +353,7 @@ struct PlasmaPhys {
     for (int sp = 0; sp < NACTIVE; sp++) Fn[NVEL + 2 + sp] = U[NVEL + 2 + sp] * un;
     if (TWOT) Fn[ITE] = (U[ITE] + s.pe) * un;
   }
-  __device__ static inline void lax_friedrichs(const Params &p, const double *U1, const double *U2, const double *n,
+  __device__ static inline void lax_friedrichs(PRef p, const double *U1, const double *U2, const double *n,
                                                double *F) {
     const State s1 = make_state(p, U1), s2 = make_state(p, U2);
     const double lam = fmax(max_char_speed(p, U1, s1), max_char_speed(p, U2, s2));
@@ -349,10 +369,10 @@ struct PlasmaPhys {
   }
 
   // RiemannSolverTPS::Eval: Lax-Friedrichs only here (Eval_Roe is 2-D single-species, not axisymmetric)
-  __device__ static inline void riemann(const Params &p, const double *U1, const double *U2, const double *n, double *F) {
+  __device__ static inline void riemann(PRef p, const double *U1, const double *U2, const double *n, double *F) {
     lax_friedrichs(p, U1, U2, n, F);
   }
-  __device__ static inline void riemann_bc(const Params &p, const BcDev &, const double *U1, const double *Ug,
+  __device__ static inline void riemann_bc(PRef p, BcRef, const double *U1, const double *Ug,
                                            const double *n, double *F) {
     lax_friedrichs(p, U1, Ug, n, F);
   }
@@ -362,7 +382,7 @@ struct PlasmaPhys {
   };
   // computeSpeciesPrimitives (:882-927): its own number densities (electrons not clamped, background
   // from the mass-fraction remainder), kept apart from computeNumberDensities as in the reference
-  __device__ static inline Species species(const Params &p, const double *U) {
+  __device__ static inline Species species(PRef p, const double *U) {
     Species q;
     const double ir = fast_rcp(U[0]);
     double n = 0.0, ne = 0.0, Yb = 1.0;
@@ -466,7 +486,7 @@ struct PlasmaPhys {
     double circle, Th, lnTe, lnTh;
     coll::Arg e, h;
   };
-  __device__ static inline MixColl mix_inputs(const Params &p, const double *n, double Th, double Te) {
+  __device__ static inline MixColl mix_inputs(PRef p, const double *n, double Th, double Te) {
     const double dfac = kBoltz * kEps0 / kQe / kQe;
     double nOverT = 0.0;
     const double iTe = fast_rcp(Te);
@@ -488,7 +508,7 @@ struct PlasmaPhys {
   // species are compile-time after unrolling; the pair's collision type is a uniform run-time value.
   // tpsrhs_create has checked that every (pair, l, r) the transport asks for exists.
   template <int L, int R>
-  __device__ static inline double collision(const Params &p, int i, int j, const MixColl &c) {
+  __device__ static inline double collision(PRef p, int i, int j, const MixColl &c) {
     const int a = i < j ? i : j, b = i < j ? j : i;
     const int type = p.coll[a + b * NSP];
     const bool with_e = (a == IE) || (b == IE);
@@ -511,7 +531,7 @@ struct PlasmaPhys {
   //   1 / D_ij = n Q_ij sqrt(mu_ij) / (d_fc sqrt(T)) directly (CurtissHirschfelder only ever divides by D_ij);
   //   one reciprocal each of T_e, T_h, n, X_sp + eps, shared by everything that divides by them.
   // Results differ from the reference's order by rounding (a few ulp).
-  __device__ static inline void transport_coeffs(const Params &p, const double *U, double Th, double Te, bool diffusion,
+  __device__ static inline void transport_coeffs(PRef p, const double *U, double Th, double Te, bool diffusion,
                                                  TCoef &t) {
     const Species q = species(p, U);
 #pragma unroll
@@ -660,7 +680,7 @@ struct PlasmaPhys {
   // (src/transport_properties.cpp:59-136).  gs[eq] = derivative of the primitives in that direction -- a
   // Cartesian direction, or the normal derivative sum_d n_d dUp/dx_d (the map is linear and the same for every
   // direction, so V . n comes out of one application).  Only the density and species rows are read.
-  __device__ static inline void diffusion_velocity(const Params &p, const TCoef &t, const double *gs, double *V) {
+  __device__ static inline void diffusion_velocity(PRef p, const TCoef &t, const double *gs, double *V) {
     // ComputeMoleFractionGradient, src/equation_of_state.cpp:1534-1592
     double ne = 0.0, nb = gs[0], nt = 0.0;
 #pragma unroll
@@ -697,7 +717,7 @@ struct PlasmaPhys {
     for (int sp = 0; sp < NSP; sp++) V[sp] -= Vc;
   }
   // ComputeFluxTransportProperties: coefficients + the diffusion velocities of every direction
-  __device__ static inline void transport(const Params &p, const double *U, double Th, double Te, const double *g,
+  __device__ static inline void transport(PRef p, const double *U, double Th, double Te, const double *g,
                                           bool diffusion, Trans &t) {
     TCoef c;
     transport_coeffs(p, U, Th, Te, diffusion, c);
@@ -724,7 +744,7 @@ struct PlasmaPhys {
   // src/transport_properties.cpp:392-449): the number densities of computeSpeciesPrimitives and the
   // electron momentum-transfer frequencies.  (The reference also evaluates the diffusion velocities and
   // the electric conductivity there; no term of the hot path reads them.)
-  __device__ static inline void source_props(const Params &p, const double *U, double Th, double Te, double *n,
+  __device__ static inline void source_props(PRef p, const double *U, double Th, double Te, double *n,
                                              double *mtfreq) {
     const Species q = species(p, U);
 #pragma unroll
@@ -759,14 +779,14 @@ struct PlasmaPhys {
       }
     }
   }
-  __device__ static inline void enthalpies(const Params &p, const State &s, double *h) {  // :1192-1207
+  __device__ static inline void enthalpies(PRef p, const State &s, double *h) {  // :1192-1207
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++) h[sp] = s.n[sp] * (p.cp[sp] * ((sp == IE) ? s.Te : s.Th) + p.eform[sp]);
   }
 
   // ComputeViscousFluxes, src/fluxes.cpp:178-335 (3-D / planar 2-D part); Fv[eq + d*NEQ]
   // (the state-only closure `c` -- transport_coeffs -- is evaluated by the caller, before it touches the gradient)
-  __device__ static inline void visc_flux(const Params &p, const double *U, const State &s, const TCoef &c,
+  __device__ static inline void visc_flux(PRef p, const double *U, const State &s, const TCoef &c,
                                           const double *g, double radius, double *Fv, const EddyCtx &ec = eddy_off()) {
 #pragma unroll
     for (int i = 0; i < NEQ * DIM; i++) Fv[i] = 0.0;
@@ -837,11 +857,11 @@ struct PlasmaPhys {
   }
   // closure of the nodal flux: everything of ComputeFluxTransportProperties that depends on the state alone
   typedef TCoef FluxCoef;
-  __device__ static inline void flux_coeffs(const Params &p, const double *U, const State &s, FluxCoef &c) {
+  __device__ static inline void flux_coeffs(PRef p, const double *U, const State &s, FluxCoef &c) {
     if (p.eq_system == TPSRHS_EULER) return;
     transport_coeffs(p, U, s.Th, s.Te, true, c);
   }
-  __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const FluxCoef &c,
+  __device__ static inline void total_flux(PRef p, const double *U, const State &s, const FluxCoef &c,
                                            const double *g, double radius, double *F, const EddyCtx &ec = eddy_off()) {
     double Fv[NEQ * DIM];
     visc_flux(p, U, s, c, g, radius, Fv, ec);
@@ -878,7 +898,7 @@ struct PlasmaPhys {
     w.nm = 1.0;
     return w;
   }
-  __device__ static inline void visc_normal_flux(const Params &p, const double *U, const double *g, const double *n,
+  __device__ static inline void visc_normal_flux(PRef p, const double *U, const double *g, const double *n,
                                                  double radius, const WallFlux &w, double *Fn, const EddyCtx &ec = eddy_off()) {
     const State s = make_state(p, U);
     Trans t;
@@ -947,7 +967,7 @@ struct PlasmaPhys {
     if (TWOT) Fn[ITE] = -EF;
   }
   // GetConservativesFromPrimitives, src/equation_of_state.cpp:744-783
-  __device__ static inline void cons(const Params &p, const double *Up, double *U) {
+  __device__ static inline void cons(PRef p, const double *Up, double *U) {
     U[0] = Up[0];
     double ke = 0.0;
 #pragma unroll
@@ -985,7 +1005,7 @@ struct PlasmaPhys {
   }
   // VISC_GNRL wall state: modifyStateFromPrimitive with no slip and the prescribed temperatures
   // (src/wallBC.cpp:112-148, src/equation_of_state.cpp:131-140); data = {T_h, T_e, heavy cond, electron cond}
-  __device__ static inline void general_wall_state(const Params &p, const BcDev &bc, const double *U, double *Uw) {
+  __device__ static inline void general_wall_state(PRef p, BcRef bc, const double *U, double *Uw) {
     double up[NEQ];
     prim(p, U, up);
 #pragma unroll
@@ -996,7 +1016,7 @@ struct PlasmaPhys {
   }
   // computeSheathBdrFlux, src/equation_of_state.cpp:1909-1942: Bohm velocities of the positive ions,
   // the electron and background fluxes that balance them, the electron energy flux through the sheath
-  __device__ static inline void sheath(const Params &p, const double *Uw, WallFlux &w) {
+  __device__ static inline void sheath(PRef p, const double *Uw, WallFlux &w) {
     const State s = make_state(p, Uw);
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++) w.Vn[sp] = 0.0;
@@ -1022,7 +1042,7 @@ struct PlasmaPhys {
   }
 
   // ---- boundary conditions ------------------------------------------------------------------
-  __device__ static inline void stagnant_with_temp(const Params &p, const double *U, double T, double *Uw) {  // :1596-1620
+  __device__ static inline void stagnant_with_temp(PRef p, const double *U, double T, double *Uw) {  // :1596-1620
     double n[NSP];
     number_densities(p, U, n);
 #pragma unroll
@@ -1036,7 +1056,7 @@ struct PlasmaPhys {
     for (int sp = 0; sp < NSP - 2; sp++) e += n[sp] * p.eform[sp];
     Uw[ITH] = e;
   }
-  __device__ static inline void energy_for_pressure(const Params &p, const double *Uin, double pres, bool modE,
+  __device__ static inline void energy_for_pressure(PRef p, const double *Uin, double pres, bool modE,
                                                     double *Uo) {  // :1698-1742
     double n[NSP];
     number_densities(p, Uin, n);
@@ -1064,7 +1084,7 @@ struct PlasmaPhys {
     if (TWOT) Uo[ITE] = ee;
     Uo[ITH] = rE;
   }
-  __device__ static inline void bc_ghost(const Params &p, const BcDev &bc, const double *U, const double *n,
+  __device__ static inline void bc_ghost(PRef p, BcRef bc, const double *U, const double *n,
                                          double *Ug, const double * = nullptr) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) Ug[eq] = U[eq];
@@ -1113,13 +1133,13 @@ struct PlasmaPhys {
   }
   // State and wall prescriptions of pass `pass` of the viscous trace of a face point: pass 0 = the interior
   // state, pass 1 (wall faces) = the wall-side state of the wall type (src/wallBC.cpp:277-543)
-  __device__ static inline void visc_pass_state(const Params &p, int nb, int pass, const double *U, const double *n,
+  __device__ static inline void visc_pass_state(PRef p, int nb, int pass, const double *U, const double *n,
                                                 double *Us, WallFlux &w) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) Us[eq] = U[eq];
     w = no_prescription();
     if (pass == 1) {  // the wall-side state
-      const BcDev &wbc = p.bc[-nb - 1];
+      BcRef wbc = p.bc[-nb - 1];
       const int type = wbc.type;
       const double twall = wbc.data[0];
       double ke = 0.0;
@@ -1143,7 +1163,7 @@ struct PlasmaPhys {
         stagnant_with_temp(p, U, twall, Us);
         w.species = true;
       } else {  // VISC_GNRL, src/wallBC.cpp:512-543
-        const BcDev &bc = p.bc[-nb - 1];
+        BcRef bc = p.bc[-nb - 1];
         general_wall_state(p, bc, U, Us);
         const int hc = static_cast<int>(bc.data[2]), ec = static_cast<int>(bc.data[3]);
         w.species = true;
@@ -1159,10 +1179,10 @@ struct PlasmaPhys {
   }
   // passes of the viscous trace of a face point: 0 = no viscous term (Euler; inlets, outlets and slip walls add
   // the Riemann flux only), 1 = interior face, 2 = wall face (interior state, then wall-side state)
-  __device__ static inline int visc_passes(const Params &p, int nb) {
+  __device__ static inline int visc_passes(PRef p, int nb) {
     if (p.eq_system == TPSRHS_EULER) return 0;
     if (nb >= 0) return 1;
-    const BcDev &bc = p.bc[-nb - 1];
+    BcRef bc = p.bc[-nb - 1];
     return (bc.category != TPSRHS_WALL || bc.type == TPSRHS_SLIP) ? 0 : 2;
   }
   // ---- the same trace in two steps (3-D face kernel): the state-only closure first -- the transcendental-heavy
@@ -1173,7 +1193,7 @@ struct PlasmaPhys {
     TCoef t;
     double vel[NVEL], h[NSP];
   };
-  __device__ static inline void visc_point_coeffs(const Params &p, const double *U, bool diffusion, ViscCoef &c) {
+  __device__ static inline void visc_point_coeffs(PRef p, const double *U, bool diffusion, ViscCoef &c) {
     const State s = make_state(p, U);
     transport_coeffs(p, U, s.Th, s.Te, diffusion, c.t);
     enthalpies(p, s, c.h);
@@ -1182,7 +1202,7 @@ struct PlasmaPhys {
   }
   // gv[i + j*DIM] = d u_i / d x_j; gn[eq] = sum_d n_d dUp_eq/dx_d (read for the scalar rows only).
   // Same terms as visc_normal_flux (ComputeViscousFluxes . n / ComputeBdrViscousFluxes, src/fluxes.cpp:178-505).
-  __device__ static inline void visc_normal_flux_n(const Params &p, const double *U, const ViscCoef &c, const double *gv,
+  __device__ static inline void visc_normal_flux_n(PRef p, const double *U, const ViscCoef &c, const double *gv,
                                                    const double *gn, const double *n, const WallFlux &w, double *Fn) {
     static_assert(!AXISYM, "planar / 3-D form");
     double Vn[NSP];
@@ -1241,7 +1261,7 @@ struct PlasmaPhys {
   // the closures split into a state-only part (collision integrals) and terms linear in the gradient: the kernels
   // evaluate the first before they bring the gradient into registers (flux_coeffs / visc_point_coeffs)
   static constexpr bool TWO_STEP = true;
-  __device__ static inline void visc_trace(const Params &p, int nb, const double *U, const double *g, const double *n,
+  __device__ static inline void visc_trace(PRef p, int nb, const double *U, const double *g, const double *n,
                                            double radius, double *fn, const EddyCtx &ec = eddy_off()) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) fn[eq] = 0.0;
@@ -1252,11 +1272,12 @@ struct PlasmaPhys {
     if (DIM == 2 && nb < 0 && p.bc[nb < 0 ? -nb - 1 : 0].type != TPSRHS_INV) wec.dist = 0.0;
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < npass; pass++) {
+      PRef q = relaunder(p);  // the parameter loads of the closure stay inside the pass
       double Us[NEQ];
       WallFlux w;
-      visc_pass_state(p, nb, pass, U, n, Us, w);
+      visc_pass_state(q, nb, pass, U, n, Us, w);
       double f[NEQ];
-      visc_normal_flux(p, Us, g, n, radius, w, f, wec);
+      visc_normal_flux(q, Us, g, n, radius, w, f, wec);
       if (nb >= 0) {
 #pragma unroll
         for (int eq = 0; eq < NEQ; eq++) fn[eq] = f[eq];
@@ -1266,7 +1287,7 @@ struct PlasmaPhys {
       }
     }
   }
-  __device__ static inline void bc_grad_prim(const Params &p, const BcDev &bc, const double *Up, double *UpB) {
+  __device__ static inline void bc_grad_prim(PRef p, BcRef bc, const double *Up, double *UpB) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) UpB[eq] = Up[eq];
     if (p.use_bc_in_grad && bc.category == TPSRHS_WALL && bc.type == TPSRHS_VISC_ISOTH) {
@@ -1278,7 +1299,7 @@ struct PlasmaPhys {
 
   // GetViscosities of the selected transport (src/transport_properties.cpp:440-449,
   // src/gas_transport.cpp:775-822): shear and bulk viscosity only
-  __device__ static inline void viscosities(const Params &p, const double *U, double Th, double Te, double &visc,
+  __device__ static inline void viscosities(PRef p, const double *U, double Th, double Te, double &visc,
                                             double &bulk) {
     if (TRANSPORT == TRANSPORT_CONSTANT) {
       visc = p.c_visc;
@@ -1313,7 +1334,7 @@ struct PlasmaPhys {
   }
   // AxisymmetricSource::updateTerms at one node (src/forcing_terms.cpp:293-380): the 1/r terms of the
   // radial and azimuthal momentum equations
-  __device__ static inline void axisym_source(const Params &p, const double *Uin, const double *Upin, const double *g,
+  __device__ static inline void axisym_source(PRef p, const double *Uin, const double *Upin, const double *g,
                                               double radius, double *src) {
     double U[NEQ], Up[NEQ];
 #pragma unroll
@@ -1366,7 +1387,7 @@ struct PlasmaPhys {
   }
 
   // ---- SourceTerm::updateTerms at one node, src/source_term.cpp:107-251 ------------------------
-  __device__ static inline void source(const Params &p, const double *Uin, const double *Upin, const double *g,
+  __device__ static inline void source(PRef p, const double *Uin, const double *Upin, const double *g,
                                        double *src) {
     double U[NEQ], Up[NEQ];
 #pragma unroll
