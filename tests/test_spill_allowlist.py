@@ -54,5 +54,24 @@ def test_bench_and_baseline_kernels_do_not_spill(census):
     for what, inst in BENCH_INSTANTIATIONS.items():
         ks = [k for k in census if ("<" + inst + ">") in k["kernel"]]
         assert any(k["kernel"].startswith("k_flux<") for k in ks), f"no kernel of {what} ({inst}) in the build"
-        bad += [(what, k["kernel"], k["vgpr_spill"], k["scratch"]) for k in ks if k["vgpr_spill"] > 0 or k["scratch"] > 0]
+        for k in ks:
+            if k["vgpr_spill"] > 0:
+                bad.append((what, k["kernel"], "vgpr_spill", k["vgpr_spill"]))
+            elif k["scratch"] > 0:
+                # a private segment in the metadata without a single scratch instruction (frame slots of SGPR spills that
+                # all ended up in VGPR lanes): tolerated; any scratch access is not
+                import kernel_isa
+
+                n = sum(kernel_isa.summary(kernel_isa.mix(body))["scratch"]
+                        for _, body in kernel_isa.kernels(os.path.join(ROOT, "tps_amd", "csrc", "_obj", k["unit"]), "")
+                        if _norm(_) == k["kernel"])
+                if n > 0:
+                    bad.append((what, k["kernel"], "scratch instructions", n))
     assert not bad, bad
+
+
+def _norm(demangled):
+    import re
+
+    d = re.sub(r"\(.*", "", demangled).replace("tpsrhs::", "").replace("void ", "")
+    return re.sub(r"\s+", "", d)

@@ -112,6 +112,87 @@ __device__ inline double flog_pos(double x) {
   const double dk = static_cast<double>(e);
   return fma(dk, fm::kLn2Hi, fma(dk, fm::kLn2Lo, lm));
 }
+// N independent evaluations in lock step: the same operations per element as fexp<false> / flog_pos (bit-identical
+// results), written so that the N dependent chains are interleaved in program order.  A dependent FP64 instruction
+// issues ~8 cycles after its producer, an independent one after 4 (tools/microbench/fp64_issue.hip): one Horner chain
+// alone keeps a SIMD half idle whenever the other resident wave is not in a VALU phase, and the heavy kernels run two
+// waves per SIMD.  (Round 2 evaluated the collision fits one after the other: 11 + 7 dependent FMAs per exp / log.)
+// the scheduler otherwise un-interleaves the rows again to save registers (seen in the ISA): nothing crosses a row
+#define TPSRHS_ROW_BARRIER() __builtin_amdgcn_sched_barrier(0)
+template <int N>
+__device__ inline void fexp_n(const double (&x)[N], double (&e)[N]) {
+  double k[N], r[N], p[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) k[i] = __builtin_rint(x[i] * fm::kLog2e);
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = fma(k[i], -fm::kLn2Hi, x[i]);
+  TPSRHS_ROW_BARRIER();
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = fma(k[i], -fm::kLn2Lo, r[i]);
+  TPSRHS_ROW_BARRIER();
+  constexpr double c[12] = {2.5110037605963777e-08, 2.763263963904103e-07, 2.755724091857897e-06, 2.4801485482328494e-05,
+                            0.00019841269890047113, 0.0013888888952314775, 0.008333333333319601, 0.0416666666664881,
+                            0.1666666666666668,     0.5000000000000019,    1.0,                  1.0};
+#pragma unroll
+  for (int i = 0; i < N; i++) p[i] = c[0];
+#pragma unroll
+  for (int j = 1; j < 12; j++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) p[i] = fma(p[i], r[i], c[j]);
+    TPSRHS_ROW_BARRIER();
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) e[i] = __builtin_amdgcn_ldexp(p[i], static_cast<int>(k[i]));
+}
+template <int N>
+__device__ inline void flog_pos_n(const double (&x)[N], double (&l)[N]) {
+  double m[N], f[N], d[N], r[N], s[N], z[N], h[N];
+  int e[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    m[i] = __builtin_amdgcn_frexp_mant(x[i]);
+    e[i] = __builtin_amdgcn_frexp_exp(x[i]);
+    const bool low = m[i] < 0.70710678118654752;
+    m[i] = __builtin_amdgcn_ldexp(m[i], low ? 1 : 0);
+    e[i] -= low ? 1 : 0;
+    f[i] = m[i] - 1.0;
+    d[i] = m[i] + 1.0;
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = __builtin_amdgcn_rcp(d[i]);
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = fma(fma(-d[i], r[i], 1.0), r[i], r[i]);
+    TPSRHS_ROW_BARRIER();
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) s[i] = f[i] * r[i];
+  TPSRHS_ROW_BARRIER();
+#pragma unroll
+  for (int i = 0; i < N; i++) s[i] = fma(fma(-d[i], s[i], f[i]), r[i], s[i]);
+  TPSRHS_ROW_BARRIER();
+#pragma unroll
+  for (int i = 0; i < N; i++) z[i] = s[i] * s[i];
+  TPSRHS_ROW_BARRIER();
+  constexpr double c[7] = {0.14616449685043406, 0.15331721600556042, 0.18182889125261723, 0.2222221113479508,
+                           0.28571428625975487, 0.39999999999899505, 0.666666666666667};
+#pragma unroll
+  for (int i = 0; i < N; i++) h[i] = c[0];
+#pragma unroll
+  for (int j = 1; j < 7; j++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) h[i] = fma(h[i], z[i], c[j]);
+    TPSRHS_ROW_BARRIER();
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const double lm = s[i] * fma(h[i], z[i], 2.0);
+    const double dk = static_cast<double>(e[i]);
+    l[i] = fma(dk, fm::kLn2Hi, fma(dk, fm::kLn2Lo, lm));
+  }
+}
+
 // log(x), any x: log(0) = -inf, log(x < 0) = NaN, log(inf) = inf, NaN -> NaN.  The special values come
 // from the single-precision hardware logarithm of the same argument (identical IEEE special cases).
 __device__ inline double flog(double x) {

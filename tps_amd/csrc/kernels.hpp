@@ -2286,8 +2286,14 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   FSTAMP(0);
   NbTraces<C, NEQ> ta0;
   NbFlux<C, NEQ> tb0;
-  issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta0, tid);
-  if (!L::BOTH_2D) issue_visc_traces<C, 0, NEQ>(sFI, e0, TB, tb0, tid);
+  // the neighbour records of the first direction pair go out before the nodal physics (their latency hides behind it)
+  // -- except in the wide 2-D kernels (more than 8 equations): 3 x NEQ values held across the closure there are 66
+  // VGPRs of a kernel that otherwise spills 90 (torch6, round 2); those issue them where the face term starts
+  constexpr bool EARLY = !(DIM == 2 && NEQ > 8);
+  if (EARLY) {
+    issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta0, tid);
+    if (!L::BOTH_2D) issue_visc_traces<C, 0, NEQ>(sFI, e0, TB, tb0, tid);
+  }
   if (node_on) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) sU[eq * C::NODES + tid] = u[eq];
@@ -2457,6 +2463,10 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
     // (not in 2-D with more than 8 equations: the prefetched pair costs 60+ registers of a kernel that already
     // spills -- torch6 k_flux 1.41 -> 1.28 ms without it)
     constexpr bool PIPE = !(DIM == 2 && NEQ > 8);
+    if (!EARLY) {
+      issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta0, tid);
+      issue_visc_traces<C, 0, NEQ>(sFI, e0, TB, tb0, tid);
+    }
     if (PIPE) {
       issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta1, tid);
       issue_visc_traces<C, 1, NEQ>(sFI, e0, TB, tb1, tid);

@@ -141,6 +141,26 @@ __device__ inline double cfit(double c0, double c1, double c2, double c3, const 
   const double v = c0 * fexp<false>(c3 * flog_pos(L)) * a.inv2;
   return (L > 0.0) ? v : ((L == 0.0) ? 0.0 : v);
 }
+// N fits of one argument in lock step (fexp_n / flog_pos_n): the same operations per fit as cfit, interleaved
+template <int N>
+__device__ inline void cfit_n(const double (&c)[N][4], const Arg &a, double (&out)[N]) {
+  double t[N], E[N], w[N], L[N], lL[N], u[N], P[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = c[i][2] * a.ln;
+  fexp_n<N>(t, E);
+#pragma unroll
+  for (int i = 0; i < N; i++) w[i] = 1.0 + c[i][1] * E[i];
+  flog_pos_n<N>(w, L);
+  flog_pos_n<N>(L, lL);
+#pragma unroll
+  for (int i = 0; i < N; i++) u[i] = c[i][3] * lL[i];
+  fexp_n<N>(u, P);
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const double v = c[i][0] * P[i] * a.inv2;
+    out[i] = (L[i] > 0.0) ? v : ((L[i] == 0.0) ? 0.0 : v);
+  }
+}
 __device__ inline double att11(const Arg &a) { return cfit(0.2150, 5.2194, 1.0472, 1.2435, a); }
 __device__ inline double att12(const Arg &a) { return cfit(0.0991, 7.4684, 1.0155, 1.1536, a); }
 __device__ inline double att13(const Arg &a) { return cfit(0.0616, 7.8271, 0.9452, 1.1105, a); }
@@ -184,6 +204,32 @@ __device__ inline double eAr1r(int r, double logT) {
     pw *= logT;
   }
   return fit;
+}
+// eAr1r(r, logT) for r = 1 .. NR in lock step: per r the reference's summation order, the NR sums interleaved
+template <int NR>
+__device__ inline void eAr1r_n(double logT, double (&fit)[NR]) {
+  static_assert(NR <= 5, "five fits");
+  constexpr double C[5][9] = {
+      {6.36254140e-18, 1.84835040e-18, -5.87727093e-18, 3.20023027e-18, -8.50509054e-19, 1.28163820e-19,
+       -1.11712910e-20, 5.25649382e-22, -1.03296658e-23},
+      {1.91338172e-17, 5.45418129e-18, -1.78361685e-17, 9.75657946e-18, -2.61115722e-18, 3.98310268e-19,
+       -3.53503678e-20, 1.70375066e-21, -3.45211955e-23},
+      {3.04685398e-17, 8.39750994e-18, -2.88132528e-17, 1.60147037e-17, -4.34837891e-18, 6.73136845e-19,
+       -6.06704580e-20, 2.97216168e-21, -6.12760944e-23},
+      {3.90777949e-17, 1.04696956e-17, -3.73774204e-17, 2.10610498e-17, -5.79029566e-18, 9.07573157e-19,
+       -8.28466766e-20, 4.11188110e-21, -8.59225098e-23},
+      {4.41333290e-17, 1.15696010e-17, -4.25651305e-17, 2.42442440e-17, -6.73359258e-18, 1.06641697e-18,
+       -9.83933863e-20, 4.93775812e-21, -1.04362372e-22}};
+  const double il = fast_rcp(logT);
+#pragma unroll
+  for (int r = 0; r < NR; r++) fit[r] = C[r][0] * il;
+  double pw = 1.0;
+#pragma unroll
+  for (int k = 1; k < 9; k++) {
+#pragma unroll
+    for (int r = 0; r < NR; r++) fit[r] += C[r][k] * pw;
+    pw *= logT;
+  }
 }
 }  // namespace coll
 
@@ -445,9 +491,9 @@ struct PlasmaPhys {
     d.h = TWOT ? coll::arg(f * Th) : d.e;
     return d;
   }
-  // sTe = sqrt(T_e), c_ke = v_f k_f sqrt(2 / m_e)
-  __device__ static inline double third_order_ke(const double *X, const Debye &d, double sTe, double lnTe, double att11c,
-                                                 double c_ke) {  // :400-489
+  // sTe = sqrt(T_e), c_ke = v_f k_f sqrt(2 / m_e); Q2 = Q_ee^(2,2..4), QI = Q_ei^(1,1..5), QN = Q_en^(1,1..5)
+  __device__ static inline double third_order_ke(const double *X, const double *Q2, const double *QI, const double *QN,
+                                                 double sTe, double c_ke) {  // :400-489
     auto L11ea = [](const double *Q) { return 6.25 * Q[0] - 15. * Q[1] + 12. * Q[2]; };
     auto L12ea = [](const double *Q) { return 10.9375 * Q[0] - 39.375 * Q[1] + 57. * Q[2] - 30. * Q[3]; };
     auto L22ea = [](const double *Q) {
@@ -455,28 +501,15 @@ struct PlasmaPhys {
     };
     constexpr double s2 = 1.4142135623730951;  // sqrt(2)
     // one collision partner at a time (electron, ion, neutral), each group reduced to its three sums
-    double L11, L12, L22;
-    {
-      const double Q2[3] = {d.circle * coll::rep22(d.e), d.circle * coll::rep23(d.e), d.circle * coll::rep24(d.e)};
-      L11 = s2 * X[I_E] * Q2[0];
-      L12 = s2 * X[I_E] * (1.75 * Q2[0] - 2.0 * Q2[1]);
-      L22 = s2 * X[I_E] * (4.8125 * Q2[0] - 7.0 * Q2[1] + 5. * Q2[2]);
-    }
-    {
-      const double QI[5] = {att11c, d.circle * coll::att12(d.e), d.circle * coll::att13(d.e), d.circle * coll::att14(d.e),
-                            d.circle * coll::att15(d.e)};
-      L11 += X[I_ION] * L11ea(QI);
-      L12 += X[I_ION] * L12ea(QI);
-      L22 += X[I_ION] * L22ea(QI);
-    }
-    {
-      double QN[5];
-#pragma unroll
-      for (int r = 1; r <= 5; r++) QN[r - 1] = coll::eAr1r(r, lnTe);
-      L11 += X[I_N] * L11ea(QN);
-      L12 += X[I_N] * L12ea(QN);
-      L22 += X[I_N] * L22ea(QN);
-    }
+    double L11 = s2 * X[I_E] * Q2[0];
+    double L12 = s2 * X[I_E] * (1.75 * Q2[0] - 2.0 * Q2[1]);
+    double L22 = s2 * X[I_E] * (4.8125 * Q2[0] - 7.0 * Q2[1] + 5. * Q2[2]);
+    L11 += X[I_ION] * L11ea(QI);
+    L12 += X[I_ION] * L12ea(QI);
+    L22 += X[I_ION] * L22ea(QI);
+    L11 += X[I_N] * L11ea(QN);
+    L12 += X[I_N] * L12ea(QN);
+    L22 += X[I_N] * L22ea(QN);
     return c_ke * sTe * X[I_E] * fast_rcp(L11 - L12 * L12 * fast_rcp(L22));
   }
 
@@ -623,17 +656,39 @@ struct PlasmaPhys {
       const double sTe = fast_sqrt(Te), sTh = TWOT ? fast_sqrt(Th) : sTe;
       const Debye d = debye(q.n, Th, Te, iTh, iTe);
       const double lnTe = flog(Te), lnTh = TWOT ? flog(Th) : lnTe;
-      const double QeAr = coll::eAr1r(1, lnTe), Qatt = coll::att11(d.e) * d.circle;
-      const double rep22h = coll::rep22(d.h) * d.circle;
+      double QeAr, Qatt, rep22h;
+      if (p.third_order) {
+        // the eight Coulomb fits of the electron temperature and the five e-Ar polynomials, four / five at a time in
+        // lock step (cfit_n, eAr1r_n: the same operations per fit, interleaved -- independent chains for the VALU)
+        constexpr double cA[4][4] = {{0.2150, 5.2194, 1.0472, 1.2435},   // att11
+                                     {0.4128, 1.2436, 1.1830, 1.0123},   // rep22
+                                     {0.2203, 1.8832, 1.2059, 0.9851},   // rep23
+                                     {0.1323, 2.7248, 1.2129, 0.9847}};  // rep24
+        constexpr double cB[4][4] = {{0.0991, 7.4684, 1.0155, 1.1536},    // att12
+                                     {0.0616, 7.8271, 0.9452, 1.1105},    // att13
+                                     {0.0308, 13.9567, 0.9511, 1.1803},   // att14
+                                     {0.0232, 13.7888, 0.9148, 1.1532}};  // att15
+        double A[4], B[4], QN[5];
+        coll::cfit_n<4>(cA, d.e, A);
+        coll::cfit_n<4>(cB, d.e, B);
+        coll::eAr1r_n<5>(lnTe, QN);
+        Qatt = A[0] * d.circle;
+        QeAr = QN[0];
+        const double Q2[3] = {d.circle * A[1], d.circle * A[2], d.circle * A[3]};
+        const double QI[5] = {Qatt, d.circle * B[0], d.circle * B[1], d.circle * B[2], d.circle * B[3]};
+        rep22h = TWOT ? coll::rep22(d.h) * d.circle : Q2[0];
+        t.ke = third_order_ke(q.X, Q2, QI, QN, sTe, p.ke_fac3);
+      } else {
+        QeAr = coll::eAr1r(1, lnTe);
+        Qatt = coll::att11(d.e) * d.circle;
+        rep22h = coll::rep22(d.h) * d.circle;
+        t.ke = p.ke_fac * sTe * q.X[I_E] * fast_rcp(TWOT ? coll::rep22(d.e) * d.circle : rep22h);
+      }
       const double sv_ion = p.vf_sq_mwp[I_ION] * sTh * fast_rcp(rep22h);
       const double sv_n = p.vf_sq_mwp[I_N] * sTh * coll::iArAr22(sTh);
       t.bulk = 0.0;
       t.visc = q.X[I_ION] * sv_ion + q.X[I_N] * sv_n;
       t.k = q.X[I_ION] * (sv_ion * p.kf_imwp[I_ION]) + q.X[I_N] * (sv_n * p.kf_imwp[I_N]);
-      if (p.third_order)
-        t.ke = third_order_ke(q.X, d, sTe, lnTe, Qatt, p.ke_fac3);
-      else
-        t.ke = p.ke_fac * sTe * q.X[I_E] * fast_rcp(TWOT ? coll::rep22(d.e) * d.circle : rep22h);
       __builtin_amdgcn_sched_barrier(0);  // the collision integrals of k_e are dead here: keep it that way
       if (diffusion) {
         const double nrsTe = q.ntot * (sTe * iTe), nrsTh = TWOT ? q.ntot * (sTh * iTh) : nrsTe;  // n / sqrt(T)
