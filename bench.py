@@ -14,6 +14,8 @@ configs[1]/[2] per GPU.  Workloads:
   cfg3            configs[2] itself: the same plasma at p=2
   cfg5            configs[4] on one GPU: axisymmetric 400x500 quads, p=3, two-temperature argon plasma with
                   constant transport, reactions and the NEC radiation source, 7 equations
+  gll_dry, gll_argon   cfg2 / argon_p3 on the reference's DEFAULT pair (Gauss-Lobatto basis + rules, src/M2ulPhyS.cpp:
+                  2671-2672): volume operators through the quadrature points, dense 32 KB inverse mass per hex
   torch6          the mixture of the reference's torch input (plasma.ini): six species, two temperatures, not
                   ambipolar, 11 equations, on the axisymmetric 400x500 mesh of cfg5
 At N = 1 the JSON line also carries the workloads that were not selected, under `other_workloads`.
@@ -46,10 +48,11 @@ HBM_COPY_GBS = 6290.0
 VALU_PEAK_GINST = 1024 * 2.4 / 4.0
 
 
-def algorithmic_bytes_per_node(neq, dim, p):
-    """bytes per node per Mult of the two mandatory sweeps (gradient, flux)."""
+def algorithmic_bytes_per_node(neq, dim, p, nc=0):
+    """bytes per node per Mult of the two mandatory sweeps (gradient, flux); nc = 1: the
+    Gauss-Lobatto rules have one more point per direction."""
     n1 = p + 1
-    qf = (((dim - 1) + 2 * p) // 2 + 1) ** (dim - 1)
+    qf = (((dim - 1) + 2 * p) // 2 + 1 + nc) ** (dim - 1)
     dof = n1**dim
     b_face = 8.0 * 2 * (dim + 1) * qf * dim / dof
     sweep1 = 8.0 * (neq + dim * neq + dim * dim + 1) + 0.5 * b_face
@@ -61,17 +64,20 @@ def workload(name):
     """-> order, physics, bcs(physics), state(X, physics), description, sample-case builder"""
     from tps_amd import capi, cases
 
-    if name in ("cfg2", "cfg4"):
+    if name in ("cfg2", "cfg4", "gll_dry"):
         return (3, capi.dry_air_physics(capi.NS), lambda ph: cases.cylinder_bcs(capi.VISC_ISOTH, 300.0),
                 lambda X, ph: cases.dry_air_state(X, seed=12345),
                 "perfect-gas Navier-Stokes (dry air, Sutherland), inlet SUB_DENS_VEL / outlet SUB_P / isothermal "
                 "wall (BASELINE.json " + ("configs[1])" if name == "cfg2" else
+                                          "configs[1] on the reference's DEFAULT basis / rule pair: Gauss-Lobatto basis, "
+                                          "Gauss-Lobatto rules, dense inverse mass)" if name == "gll_dry" else
                                           "configs[3]: 56x224x32 = 401 408 hexes in all, spanwise slabs)"),
                 lambda order: cases.cyl3d(7, 28, 4, order, capi.NS, capi.VISC_ISOTH))
-    if name in ("argon_p3", "cfg3"):
-        order = 3 if name == "argon_p3" else 2
+    if name in ("argon_p3", "cfg3", "gll_argon"):
+        order = 2 if name == "cfg3" else 3
         what = ("BASELINE.json metric: 3D p=3 reacting cylinder = configs[2] physics at configs[1] order"
-                if name == "argon_p3" else "BASELINE.json configs[2]")
+                if name == "argon_p3" else "the metric's workload on the Gauss-Lobatto basis / rule pair" if name == "gll_argon"
+                else "BASELINE.json configs[2]")
         return (order, capi.argon_ternary_physics(capi.NS, False, capi.ARGON_MINIMAL, "arrhenius"),
                 lambda ph: cases.plasma_cylinder_bcs(ph, capi.VISC_ISOTH, 3000.0),
                 lambda X, ph: cases.plasma_state(X, ph, nvel=3, seed=12345, amp=0.05),
@@ -99,6 +105,25 @@ def workload(name):
                 lambda order: cases.argon_axisym(40, 50, order, physics=capi.argon_six_species_physics(
                     capi.NS, capi.CONSTANT, True, "tabulated", radiation=True)))
     raise SystemExit(f"unknown workload {name}")
+
+
+_LIB_SHA = []
+
+
+def lib_sha16():
+    """first 16 hex digits of the SHA-256 of the kernel library this process loads: ties a counter profile
+    (profiles/hbm_traffic.json, tools/profile_summary.py) to the build it was taken from"""
+    if not _LIB_SHA:
+        import hashlib
+
+        from tps_amd import capi
+
+        h = hashlib.sha256()
+        with open(capi.LIB_PATH, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 22), b""):
+                h.update(chunk)
+        _LIB_SHA.append(h.hexdigest()[:16])
+    return _LIB_SHA[0]
 
 
 def cpu_baseline(neq, order, sample_case, budget_s=10.0):
@@ -145,7 +170,7 @@ def main():
     ap.add_argument("--ntheta", type=int, default=112)
     ap.add_argument("--nz", type=int, default=16)
     ap.add_argument("--order", type=int, default=0, help="override the workload's polynomial order")
-    ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3", "cfg4", "cfg5", "torch6"])
+    ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3", "cfg4", "cfg5", "torch6", "gll_dry", "gll_argon"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the multi-rank path on a one-GPU box (traces staged via host)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses device 0")
@@ -202,9 +227,10 @@ def main():
             mesh = meshgen.ogrid_cylinder_slab(56, 224, 32 // world, rank, world, span_local=4.0 / world)
         else:
             mesh = meshgen.ogrid_cylinder_slab(args.nr, args.ntheta, args.nz, rank, world)
-        disc = capi.Disc(order, 0, 0, 1 if axisym else 0, 0)
+        gll = wname.startswith("gll_")
+        disc = capi.Disc(order, 1 if gll else 0, 1 if gll else 0, 1 if axisym else 0, 0)
         bcs = make_bcs(physics)
-        X = node_coordinates(mesh, order)
+        X = node_coordinates(mesh, order, 1 if gll else 0)
         U = make_state(X, physics)
         del X
         op = RHSoperator(mesh, disc, physics, bcs, device=local_rank, halo=halo)
@@ -269,10 +295,12 @@ def main():
             if hasattr(halo, "stats"):
                 st = halo.stats()
                 calls, sent, peers = st["halo_calls"], st["bytes_sent"], st["peers_seen"]
+                nranks, reduce_comm = st["nranks"], st["reduce_comm"]  # ncclCommCount of the exchange communicator
             else:
                 calls, sent, peers = halo.calls, halo.bytes_sent, len({(rank - 1) % world, (rank + 1) % world})
+                nranks, reduce_comm = dist.get_world_size(), "torch.distributed (gloo)"
             comm = {"backend_used": halo.backend if hasattr(halo, "stats") else f"{halo.backend} (Python hook, staged through host)",
-                    "ranks_seen": peers, "halo_calls": calls,
+                    "nranks": nranks, "ranks_seen": peers, "reduce_comm": reduce_comm, "halo_calls": calls,
                     "halo_bytes_per_mult": 2.0 * sent / max(calls, 1)}  # two exchanges (TA, TB) per Mult
         op.close()
         del x, y
@@ -281,18 +309,27 @@ def main():
         ms_per_step = 1e3 * dt / steps
         evals_per_s = steps / dt
         value = world * ndofs * neq * evals_per_s / 1e6
-        alg = algorithmic_bytes_per_node(neq, mesh.dim, order)
+        alg = algorithmic_bytes_per_node(neq, mesh.dim, order, 1 if gll else 0)
+        if gll:  # the dense NPE x NPE inverse mass of every element is streamed by both sweeps
+            npe = (order + 1) ** mesh.dim
+            for k in ("k_gradient", "k_flux"):
+                alg[k] += 8.0 * npe
+            alg["mult"] += 16.0 * npe
         dom = max((k for k in ktimes if k in alg), key=lambda k: ktimes[k])
         achieved = alg[dom] * ndofs / (ktimes[dom] * 1e-3) / 1e9
         traffic = valu_insts = None
+        counters_from = "no counter profile of this workload in profiles/hbm_traffic.json"
         try:  # written by tools/profile_summary.py from the rocprofv3 --pmc passes of this workload
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(wname, {})
-            if tj.get("nodes") == ndofs and dom in tj.get("bytes_per_launch", {}):
-                traffic = tj["bytes_per_launch"][dom]
-            if tj.get("nodes") == ndofs:
+            if tj and tj.get("lib_sha16") != lib_sha16():
+                # the counters describe another build of the kernels: report none rather than stale ones
+                counters_from = f"profiles/hbm_traffic.json holds counters of build {tj.get('lib_sha16')}, this is {lib_sha16()}"
+            elif tj.get("nodes") == ndofs:
+                traffic = tj.get("bytes_per_launch", {}).get(dom)
                 valu_insts = tj.get("valu_insts_per_launch", {}).get(dom)
-        except Exception:
-            traffic = None
+                counters_from = f"profiles/hbm_traffic.json, build {tj.get('lib_sha16')} (the library loaded here)"
+        except Exception as exc:
+            counters_from = f"profiles/hbm_traffic.json unreadable: {exc}"
         # second roofline of a kernel that is not bandwidth-bound: FP64 vector issue.  achieved = VALU
         # wave-instructions per launch (SQ_INSTS_VALU of the committed PMC pass) / the live kernel time.
         valu = None
@@ -301,12 +338,16 @@ def main():
             valu = {"bound": "fp64-valu-issue", "kernel": dom, "achieved": ginst, "peak": VALU_PEAK_GINST,
                     "unit": "G wave-instructions/s", "frac": ginst / VALU_PEAK_GINST,
                     "valu_insts_per_launch": valu_insts}
+        else:
+            valu = {"bound": "fp64-valu-issue", "kernel": dom, "achieved": None, "peak": VALU_PEAK_GINST,
+                    "unit": "G wave-instructions/s", "frac": None, "valu_insts_per_launch": None}
+        valu["counters_from"] = counters_from
         res = {
             "value": value, "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
             "config": {"workload": (f"{wname}: " + ("" if axisym else
                                                     (f"cyl3d O-grid 56x224x{32 // world} hexes per GPU, " if strong else
                                                      f"cyl3d O-grid {args.nr}x{args.ntheta}x{args.nz} hexes per GPU, ")) +
-                                    f"p={order}, GL basis + GL rule, {description}"),
+                                    f"p={order}, " + ("Gauss-Lobatto basis + rules" if gll else "GL basis + GL rule") + f", {description}"),
                        "elements_per_gpu": mesh.num_elements, "nodes_per_gpu": ndofs, "num_equation": neq,
                        "partition": (f"{world} spanwise slabs; face traces of the shared planes exchanged by "
                                      f"{comm['backend_used']}") if world > 1 else "single GPU"},
@@ -324,14 +365,15 @@ def main():
     r = run(args.workload, args.steps, args.warmup)
     others = {}
     if world == 1 and not args.no_other_workloads:
-        for wname in ("argon_p3", "cfg2", "cfg3", "cfg5", "torch6"):
+        for wname in ("argon_p3", "cfg2", "cfg3", "cfg5", "torch6", "gll_dry"):
             if wname != args.workload:
-                o, _ = run(wname, max(args.steps // 2, 5), min(args.warmup, 3))
-                others[wname] = {k: o[k] for k in ("value", "ms_per_step", "rhs_evals_per_s", "kernel_ms", "finite")}
+                # the same K timed steps as the headline and at least 10 warm-ups: comparable round to round and
+                # with the profiles/ of the same command
+                o, _ = run(wname, args.steps, max(args.warmup, 10))
+                others[wname] = {k: o[k] for k in ("value", "ms_per_step", "steps", "warmup", "rhs_evals_per_s", "kernel_ms",
+                                                  "ms_per_mult_median_events", "finite", "roofline", "roofline_valu")}
                 others[wname]["unit"] = "MDOF/s"
                 others[wname]["workload"] = o["config"]["workload"]
-                others[wname]["roofline_frac"] = o["roofline"]["frac"]
-                others[wname]["roofline_kernel"] = o["roofline"]["kernel"]
     if rank == 0:
         res, (neq, order, sample_case) = r
         out = {
@@ -344,8 +386,8 @@ def main():
             "ms_per_mult_median_events": res["ms_per_mult_median_events"],
             "roofline": res["roofline"],
         }
-        if res.get("roofline_valu"):
-            out["roofline_valu"] = res["roofline_valu"]
+        out["roofline_valu"] = res["roofline_valu"]
+        out["lib_sha16"] = lib_sha16()
         if res.get("time_loop"):
             out["time_loop"] = res["time_loop"]
         if res.get("comm"):

@@ -42,6 +42,9 @@ int tpsrhs_rccl_reduce(void *ctx, double *values, int count, int op, void *strea
  * `skip` != 0 makes tpsrhs_rccl_halo return at once (timing experiments: exposed-communication measurement). */
 int tpsrhs_rccl_stats(const tpsrhs_rccl_ctx *ctx, int64_t *halo_calls, int64_t *bytes_sent, int *peers_seen);
 int tpsrhs_rccl_set_skip(tpsrhs_rccl_ctx *ctx, int skip);
+/* ncclCommCount of the exchange communicator (the number of ranks RCCL itself sees), and whether the scalar
+ * reductions run on a communicator of their own (ncclCommSplit at creation) or share the exchange's. */
+int tpsrhs_rccl_comm_info(const tpsrhs_rccl_ctx *ctx, int *nranks, int *reduce_comm_is_separate);
 const char *tpsrhs_rccl_last_error(void);
 
 #ifdef __cplusplus

@@ -83,3 +83,43 @@ def test_free_stream_preservation_at_full_size(kind):
     print("residual of the uniform state per equation:", resid, "bound", bound)
     assert (resid <= bound).all()
     assert np.abs(got["gradUp"]).max() <= 1e-10 * np.abs(got["Up"]).max() / h
+
+
+# ---- BASELINE.json configs[4] (cfg5 of bench.py) and torch6 at their full size: 400 x 500 axisymmetric quads, p = 3 ----
+def _bench_axisym(wname, nz, length):
+    """mesh, disc, physics, bcs and a state that depends on r only, built with bench.py's own workload definition"""
+    import bench
+
+    order, ph, make_bcs, make_state, _, _ = bench.workload(wname)
+    mesh = meshgen.annulus_quad(400, nz, r_in=0.0, r_out=0.05, length=length)
+    disc = capi.Disc(order, 0, 0, 1, 0)
+    X = node_coordinates(mesh, order)
+    X[1] = 0.0  # no dependence on z
+    return mesh, disc, ph, make_bcs(ph), make_state(X, ph), order
+
+
+@pytest.mark.parametrize("wname", ["cfg5", "torch6"])
+def test_full_size_axisymmetric_layers_reproduce_the_oracle_checked_strip(wname):
+    """Axial-translation invariance.  The tube is extruded along z between the inlet (z = 0) and the outlet (z = L);
+    for a state that depends on r only, every layer of elements whose stencil does not reach those two patches -- the
+    element, its neighbours and their neighbours (BR1 gradient): layers 2 ... 497 -- must reproduce, node for node, the
+    middle layer of a 7-layer strip with the same cells, and the two layers at either end the strip's end layers.
+    The strip is compared with the oracle."""
+    NZF, NZS, L = 500, 7, 0.25
+    mesh, disc, ph, bcs, U, order = _bench_axisym(wname, NZF, L)
+    full = hip_mult(mesh, disc, ph, bcs, U, want_grad=False)
+    smesh, sdisc, sph, sbcs, sU, _ = _bench_axisym(wname, NZS, L * NZS / NZF)
+    small = hip_mult(smesh, sdisc, sph, sbcs, sU, want_grad=False)
+    ref = oracle_mult(smesh, sdisc, sph, sbcs, sU)
+    scale = np.abs(ref["y"]).max(axis=1, keepdims=True)
+    err = (np.abs(small["y"] - ref["y"]) / scale).max(axis=1)
+    print(wname, "7-layer strip vs oracle:", err)
+    assert err.max() < 5 * RHS_RTOL  # 5 % perturbations of a plasma state: the tolerance of the plasma parity cases
+    per_layer = 400 * (order + 1) ** 2
+    lay = lambda y, k: y[:, k * per_layer:(k + 1) * per_layer]
+    assert (np.abs(lay(sU, 0) - lay(U, 0)) <= 1e-13 * np.abs(U).max(axis=1, keepdims=True)).all()
+    tol = 5 * RHS_RTOL * scale
+    for k in range(NZF):
+        ks = k if k < 2 else (NZS - (NZF - k) if k >= NZF - 2 else 3)
+        assert (np.abs(lay(full["y"], k) - lay(small["y"], ks)) <= tol).all(), (k, ks)
+    assert np.isfinite(full["y"]).all()

@@ -33,6 +33,13 @@ def _case(world, kind):
         ph = capi.dry_air_physics(capi.NS)
         Ug = cases.dry_air_state(node_coordinates(full, 2), seed=4, amp=0.1)
         return full, owner, 2, ph, [], Ug
+    if kind == "slab_thin":  # the shape of cfg4 at N = 8 (a few layers per rank: EVERY element touches a shared plane)
+        full = meshgen.ogrid_cylinder(4, 12, 2 * world, span=2.0 * world)
+        order = 3
+        ph = capi.dry_air_physics(capi.NS, visc_mult=2000.0)
+        bcs = cases.cylinder_bcs(capi.VISC_ISOTH)
+        Ug = cases.dry_air_state(node_coordinates(full, order), seed=5)
+        return full, "slab2", order, ph, bcs, Ug
     if kind == "slab":  # the weak-scaling partition of bench.py: spanwise slabs, both neighbours may be one rank
         full = meshgen.ogrid_cylinder(4, 12, 3 * world, span=2.0 * world)
         order = 3
@@ -88,6 +95,8 @@ def _worker(rank, world, port, q, kind, backend="gloo"):
         if isinstance(owner, str):
             if owner == "axislab":
                 part = meshgen.annulus_quad_slab(6, 3, rank, world, r_out=0.05, length_local=0.08)
+            elif owner == "slab2":
+                part = meshgen.ogrid_cylinder_slab(4, 12, 2, rank, world)
             else:
                 part = meshgen.ogrid_cylinder_slab(4, 12, 3, rank, world)
             gel = np.arange(part.num_elements) + rank * part.num_elements
@@ -136,7 +145,7 @@ ADV = (2.0e-5, 3, 0.1, 0.05)  # dt0, steps, CFL, hmin of the advance() leg
 
 
 @pytest.mark.parametrize("world,kind", [(2, "dry_air"), (3, "argon_2T"), (2, "slab"), (4, "slab"), (3, "axisym_2T"),
-                                        (3, "dry_air_nr"), (3, "axisym_slab"), (3, "mixedout")])
+                                        (3, "dry_air_nr"), (3, "axisym_slab"), (3, "mixedout"), (5, "slab_thin")])  # 5 ranks + the test process = the 6 processes a GPU box allows
 def test_ranks_match_serial_oracle(world, kind):
     _run_ranks(world, kind, "gloo")
 

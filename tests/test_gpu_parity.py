@@ -429,3 +429,18 @@ def test_plasma_orders_four_five(geo, order, nsp, two_t, transport):
     else:
         c = cases.argon_cyl3d(2, 8, 3, order, physics=ph)
     _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=23, amp=0.01), tol=_tol(0.01))
+
+
+@pytest.mark.parametrize("wname", ["cfg5", "torch6"])
+def test_bench_axisymmetric_workloads_exact_physics(wname):
+    """the physics, boundary conditions and state generator of bench.py's cfg5 (BASELINE.json configs[4]: ternary,
+    two temperatures, axisymmetric, constant transport, the reference's rate tables + NEC table) and torch6 (six
+    species, 14 tabulated reactions), taken from bench.workload itself, on a mesh the oracle can do"""
+    import bench
+
+    order, ph, make_bcs, make_state, _, _ = bench.workload(wname)
+    # (12 x 18 cells: on coarser ones the 5 % waves of bench.py's state extrapolate to negative densities at face points)
+    mesh = meshgen.scramble_orientations(meshgen.annulus_quad(12, 18, r_in=0.0, r_out=0.05, length=0.25), 4)
+    disc = capi.Disc(order, 0, 0, 1, 0)
+    U = make_state(node_coordinates(mesh, order), ph)
+    _compare(mesh, disc, ph, make_bcs(ph), U, tol=5 * RHS_RTOL)

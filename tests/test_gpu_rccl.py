@@ -47,7 +47,10 @@ def test_one_rank_communicator_moves_segments_and_reduces():
         side.synchronize()
         assert v.cpu().tolist() == [3.0, -1.5, 7.25]
         s = halo.stats()
-        assert s == {"halo_calls": 1, "bytes_sent": 8 * n, "peers_seen": 1}
+        assert {k: s[k] for k in ("halo_calls", "bytes_sent", "peers_seen", "nranks")} == {
+            "halo_calls": 1, "bytes_sent": 8 * n, "peers_seen": 1, "nranks": 1}  # nranks = ncclCommCount
+        # the reductions ran on a communicator of their own (ncclCommSplit), not on the exchange's
+        assert s["reduce_comm"].startswith("own communicator")
         halo.skip = True
         recv.zero_()
         assert halo.c_halo(halo.ctx, 1, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), 2, ranks, soff, roff,

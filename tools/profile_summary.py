@@ -79,6 +79,8 @@ for k, v in summary.items():
         ent["raw"][k] = {"FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"]}
         ent["bytes_per_launch"][k] = 1024.0 * (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"])
 ent["valu_insts_per_launch"] = {k: v["SQ_INSTS_VALU"] for k, v in summary.items() if "SQ_INSTS_VALU" in v}
+# the build the counters were taken from: bench.py reports them only for the same library (lib_sha16 of its line)
+ent["lib_sha16"] = bench.get("bench_plain.json", {}).get("lib_sha16")
 traffic[w] = ent
 json.dump(traffic, open(tp, "w"), indent=1)
 for k, v in summary.items():

@@ -14,7 +14,10 @@
 static_assert(sizeof(ncclUniqueId) == TPSRHS_RCCL_ID_BYTES, "ncclUniqueId size");
 
 struct tpsrhs_rccl_ctx {
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;         // neighbour exchange (grouped send / recv on the operator's communication stream)
+  ncclComm_t comm_reduce = nullptr;  // scalar reductions on the compute stream: a communicator of their own, so that RCCL
+                                     // does not order them with the exchange in flight on the other stream
+  bool own_reduce_comm = false;
   int nranks = 0, rank = 0, device = 0;
   int64_t halo_calls = 0, bytes_sent = 0;
   std::set<int> peers;
@@ -60,12 +63,33 @@ int tpsrhs_rccl_create(const void *id, int nranks, int rank, int device, tpsrhs_
     delete c;
     return fail("ncclCommInitRank", r);
   }
+  // Operations on ONE communicator are serialised by RCCL whatever stream they are enqueued on; the boundary-mean /
+  // dt reductions run on the compute stream while the trace exchange runs on the communication stream, so they get
+  // a communicator of their own (ncclCommSplit: same ranks, same order).  Should the split be refused the reductions
+  // share the exchange's communicator as in round 2 (correct, less overlap); tpsrhs_rccl_comm_info reports which.
+  c->comm_reduce = c->comm;
+  ncclComm_t second = nullptr;
+  if (ncclCommSplit(c->comm, 0, rank, &second, nullptr) == ncclSuccess && second) {
+    c->comm_reduce = second;
+    c->own_reduce_comm = true;
+  }
   *out = c;
+  return 0;
+}
+
+int tpsrhs_rccl_comm_info(const tpsrhs_rccl_ctx *c, int *nranks, int *reduce_comm_is_separate) {
+  if (!c || !c->comm) return 1;
+  int n = 0;
+  const ncclResult_t r = ncclCommCount(c->comm, &n);
+  if (r != ncclSuccess) return fail("ncclCommCount", r);
+  if (nranks) *nranks = n;
+  if (reduce_comm_is_separate) *reduce_comm_is_separate = c->own_reduce_comm ? 1 : 0;
   return 0;
 }
 
 int tpsrhs_rccl_destroy(tpsrhs_rccl_ctx *c) {
   if (!c) return 0;
+  if (c->own_reduce_comm && c->comm_reduce) ncclCommDestroy(c->comm_reduce);
   if (c->comm) ncclCommDestroy(c->comm);
   delete c;
   return 0;
@@ -116,7 +140,7 @@ int tpsrhs_rccl_reduce(void *ctx, double *values, int count, int op, void *strea
     return 1;
   }
   const ncclResult_t r = ncclAllReduce(values, values, static_cast<size_t>(count), ncclDouble, op == 1 ? ncclMin : ncclSum,
-                                       c->comm, static_cast<hipStream_t>(stream));
+                                       c->comm_reduce, static_cast<hipStream_t>(stream));
   if (r != ncclSuccess) return fail("ncclAllReduce", r);
   return 0;
 }

@@ -20,7 +20,8 @@ from . import capi
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtpsrhs_rccl.so")
 ID_BYTES = 128
 EXPORTED_SYMBOLS = ["tpsrhs_rccl_unique_id", "tpsrhs_rccl_create", "tpsrhs_rccl_destroy", "tpsrhs_rccl_halo",
-                    "tpsrhs_rccl_reduce", "tpsrhs_rccl_stats", "tpsrhs_rccl_set_skip", "tpsrhs_rccl_last_error"]
+                    "tpsrhs_rccl_reduce", "tpsrhs_rccl_stats", "tpsrhs_rccl_set_skip", "tpsrhs_rccl_last_error",
+                    "tpsrhs_rccl_comm_info"]
 _LIB = None
 
 
@@ -79,7 +80,12 @@ class RcclHalo:
     def stats(self):
         calls, sent, peers = C.c_int64(0), C.c_int64(0), C.c_int(0)
         self._lib.tpsrhs_rccl_stats(self.ctx, C.byref(calls), C.byref(sent), C.byref(peers))
-        return {"halo_calls": calls.value, "bytes_sent": sent.value, "peers_seen": peers.value}
+        n, sep = C.c_int(0), C.c_int(0)
+        self._lib.tpsrhs_rccl_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        if self._lib.tpsrhs_rccl_comm_info(self.ctx, C.byref(n), C.byref(sep)) != 0:
+            raise RuntimeError("tpsrhs_rccl_comm_info: " + self._lib.tpsrhs_rccl_last_error().decode())
+        return {"halo_calls": calls.value, "bytes_sent": sent.value, "peers_seen": peers.value, "nranks": n.value,
+                "reduce_comm": "own communicator (ncclCommSplit)" if sep.value else "shared with the exchange"}
 
     def close(self):
         if self.ctx:
