@@ -1,0 +1,56 @@
+/* libtpsrhs_io.so -- TPS restart files (HDF5) to and from the operator's byNODES state vector.
+ *
+ * Replaces, for the solution state, M2ulPhyS::restart_files_hdf5 / read_restart_files_hdf5 / write_restart_files_hdf5
+ * (src/io.cpp:43-193) with IOFamily::readPartitioned / writePartitioned (src/io.cpp:701-776): one file per rank,
+ * attributes "iteration" (int), "time", "dt" (double), "order", "dimension" (int) and optionally "dofs_global"
+ * on the root group, and the group "/solution" with one 1-D double dataset of NDofs entries per conserved variable:
+ * "density", "rho-u", "rho-v", ["rho-w"], "rho-E", "rho-Y_<species>" for every active species and "rhoE_e" for a
+ * two-temperature mixture (src/M2ulPhyS.cpp:1825-1852).  Dataset k holds entries [k*NDofs, (k+1)*NDofs) of the state
+ * vector: the reference's Ordering::byNODES layout, which is the layout of tpsrhs_mult's x.  A library of its own: the
+ * kernel library links no HDF5.  HOST buffers; nothing here touches the GPU.  [third party: HDF5 C library >= 1.10] */
+#ifndef TPSRHS_IO_H_
+#define TPSRHS_IO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tpsrhs_restart_info {
+  int iteration; /* attribute "iteration" */
+  double time;   /* "time" */
+  double dt;     /* "dt" */
+  int order;     /* "order": polynomial order of the stored solution */
+  int dimension; /* "dimension" */
+  int64_t dofs_global; /* "dofs_global" of partitioned files, -1 when absent */
+  int64_t ndofs;       /* entries of each dataset of this file */
+} tpsrhs_restart_info;
+
+/* Names of the /solution datasets in state-vector order (src/M2ulPhyS.cpp:1825-1852): nvel = 2 or 3 velocity
+ * components, the names of the ACTIVE species in mixture order, two_temperature != 0 adds "rhoE_e".  Writes up to
+ * `capacity` pointers into a static table of this library (valid until the next call from the same thread); returns
+ * the number of names = num_equation, or -1. */
+int tpsrhs_restart_variable_names(int nvel, int num_active_species, const char *const *species_names, int two_temperature,
+                                  int capacity, const char **names);
+
+/* Attributes and dataset size only (U may be sized from info->ndofs); 0 on success. */
+int tpsrhs_restart_info_read(const char *path, tpsrhs_restart_info *info);
+
+/* Reads dataset /solution/<names[k]> into U[k*ndofs ... ) for k < num_equation.  The file must hold datasets of
+ * exactly `ndofs` entries (the reference asserts numInSoln == local_ndofs, src/io.cpp:763) and `order` must equal
+ * info->order unless order < 0 (the reference's change of order on restart needs MFEM's interpolation: not here).
+ * 0 on success; tpsrhs_io_last_error() says what failed. */
+int tpsrhs_restart_read(const char *path, int num_equation, int64_t ndofs, const char *const *names, int order, double *U,
+                        tpsrhs_restart_info *info);
+
+/* The reference's partitioned write of one rank (src/io.cpp:43-103, 701-724): truncates `path`. */
+int tpsrhs_restart_write(const char *path, int num_equation, int64_t ndofs, const char *const *names, const double *U,
+                         const tpsrhs_restart_info *info);
+
+const char *tpsrhs_io_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,94 @@
+"""TPS restart files (src/io.cpp:43-193, 701-776): the layout written by libtpsrhs_io.so is
+checked with HDF5's own tools against what the reference writes (group, dataset names, attribute names and types),
+the reader against files of that layout -- including a file assembled by h5py-free means the way the reference does
+(one dataset per conserved variable, byNODES) -- and, on the GPU, a restart -> Mult round trip against the oracle."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from tps_amd import capi, cases, restart
+
+H5DUMP = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+
+
+def test_library_exports_the_declared_symbols():
+    lib = restart.load()
+    for s in restart.EXPORTED_SYMBOLS:
+        assert hasattr(lib, s), s
+
+
+def test_variable_names_follow_the_reference():
+    # src/M2ulPhyS.cpp:1825-1852
+    assert restart.variable_names(3) == ["density", "rho-u", "rho-v", "rho-w", "rho-E"]
+    assert restart.variable_names(2) == ["density", "rho-u", "rho-v", "rho-E"]
+    assert restart.variable_names(3, ["Ar.+1"], True) == ["density", "rho-u", "rho-v", "rho-w", "rho-E", "rho-Y_Ar.+1", "rhoE_e"]
+    assert restart.variable_names(3, ["Ar.+1", "Ar_m", "Ar_r", "Ar_p", "E"], True)[-2:] == ["rho-Y_E", "rhoE_e"]
+
+
+def test_round_trip_and_layout(tmp_path):
+    rng = np.random.default_rng(7)
+    names = restart.variable_names(3, ["Ar.+1"], True)
+    U = rng.standard_normal((len(names), 1234))
+    p = tmp_path / "restart_output.sol.h5"
+    restart.write(p, names, U, iteration=4200, time=0.125, dt=2.5e-6, order=3, dimension=3, dofs_global=9872)
+    info = restart.read_info(p)
+    assert (info.iteration, info.time, info.dt, info.order, info.dimension, info.dofs_global, info.ndofs) == (
+        4200, 0.125, 2.5e-6, 3, 3, 9872, 1234)
+    V, info2 = restart.read(p, names, 1234, order=3)
+    assert np.array_equal(U, V) and info2.iteration == 4200
+    # a subset / another order of variables reads the datasets by NAME (IOFamily::readPartitioned: group + "/" + varName)
+    W, _ = restart.read(p, ["rho-E", "density"], 1234)
+    assert np.array_equal(W[0], U[4]) and np.array_equal(W[1], U[0])
+    if os.path.exists(H5DUMP):  # the structure as HDF5's own tool sees it
+        hdr = subprocess.run([H5DUMP, "-H", str(p)], capture_output=True, text=True).stdout
+        assert 'GROUP "solution"' in hdr
+        for n in names:
+            assert f'DATASET "{n}"' in hdr
+        for a, t in (("iteration", "H5T_STD_I32LE"), ("order", "H5T_STD_I32LE"), ("dimension", "H5T_STD_I32LE"),
+                     ("time", "H5T_IEEE_F64LE"), ("dt", "H5T_IEEE_F64LE"), ("dofs_global", "H5T_STD_I32LE")):
+            i = hdr.index(f'ATTRIBUTE "{a}"')
+            assert t in hdr[i:i + 120], (a, hdr[i:i + 200])
+        assert hdr.count("DATASPACE  SIMPLE { ( 1234 ) / ( 1234 ) }") == len(names)
+
+
+def test_errors_are_reported_not_asserted(tmp_path):
+    names = restart.variable_names(2)
+    p = tmp_path / "r.h5"
+    restart.write(p, names, np.ones((4, 10)), order=2, dimension=2)
+    with pytest.raises(RuntimeError, match="10 entries per variable, the operator has 11"):
+        restart.read(p, names, 11)
+    with pytest.raises(RuntimeError, match="polynomial order 2, operator of order 3"):
+        restart.read(p, names, 10, order=3)
+    with pytest.raises(RuntimeError, match="rho-w"):
+        restart.read(p, restart.variable_names(3), 10)
+    with pytest.raises(RuntimeError, match="cannot open"):
+        restart.read(tmp_path / "absent.h5", names, 10)
+
+
+@pytest.mark.gpu
+def test_restart_to_mult_matches_the_oracle(tmp_path):
+    """write a state the way the reference's restart holds it, read it back, run Mult on the device"""
+    import torch
+
+    from parity_util import RHS_RTOL, oracle_mult, rel_maxnorm
+    from tps_amd.rhs_operator import RHSoperator
+
+    c = cases.argon_cyl3d(4, 12, 3, 2, two_temperature=True)
+    U = c.state(seed=3, amp=0.01)
+    names = restart.variable_names(3, ["Ar.+1"], True)
+    assert len(names) == U.shape[0]
+    p = tmp_path / "restart_argon.sol.h5"
+    restart.write(p, names, U, iteration=10, time=1e-3, dt=1e-6, order=2, dimension=3)
+    V, info = restart.read(p, names, U.shape[1], order=c.disc.order)
+    op = RHSoperator(c.mesh, c.disc, c.physics, c.bcs)
+    x = torch.tensor(V.ravel(), dtype=torch.float64, device=op.device)
+    y = torch.empty_like(x)
+    op.SetTime(info.time)
+    op.Mult(x, y)
+    torch.cuda.synchronize()
+    ref = oracle_mult(c.mesh, c.disc, c.physics, c.bcs, U)
+    assert rel_maxnorm(y.cpu().numpy().reshape(U.shape), ref["y"]).max() < 5 * RHS_RTOL
+    op.close()
