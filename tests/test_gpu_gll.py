@@ -158,6 +158,26 @@ def test_argon_ternary_gll(dim, order, two_t):
     _compare(mesh, disc, ph, bcs, U, tol=5e-11)
 
 
+@pytest.mark.parametrize("levels,ambi,dim,order,transport,two_t", [
+    (1, True, 2, 2, capi.ARGON_MIXTURE, True), (2, False, 3, 3, capi.CONSTANT, True), (3, False, 3, 2, capi.ARGON_MIXTURE, True),
+    (3, True, 2, 3, capi.CONSTANT, False), (4, False, 2, 3, capi.ARGON_MIXTURE, True), (5, True, 3, 1, capi.CONSTANT, True),
+    (5, False, 3, 2, capi.CONSTANT, True),
+])
+def test_argon_mixtures_gll(levels, ambi, dim, order, transport, two_t):
+    """the Gauss-Lobatto pair for every species count (4 ... 8 species; SURVEY 8a row a16 / the reference accepts any
+    basis / rule pair with any mixture, src/M2ulPhyS.cpp:557-572)"""
+    ph = capi.argon_levels_physics(levels, ambi, capi.NS, transport, two_t, True)
+    if dim == 3:
+        c = cases.argon_cyl3d(3, 8, 3, order, physics=ph)
+        mesh, bcs = c.mesh, c.bcs
+    else:
+        mesh = meshgen.scramble_orientations(meshgen.box_quad(5, 4, lengths=(1.0, 0.7), warp=0.08), 4)
+        bcs = []
+    disc = capi.Disc(order, 1, 1, 0, 0)
+    U = cases.plasma_state(node_coordinates(mesh, order, 1), ph, nvel=dim, seed=6, amp=0.005 if order == 1 else 0.01)
+    _compare(mesh, disc, ph, bcs, U, tol=1e-10)
+
+
 def test_mixed_pairs_are_refused():
     with pytest.raises(Exception) as ei:
         hip_mult(meshgen.box_quad(3, 3), capi.Disc(2, 0, 1, 0, 0), capi.dry_air_physics(capi.NS), [],

@@ -444,3 +444,29 @@ def test_bench_axisymmetric_workloads_exact_physics(wname):
     disc = capi.Disc(order, 0, 0, 1, 0)
     U = make_state(node_coordinates(mesh, order), ph)
     _compare(mesh, disc, ph, make_bcs(ph), U, tol=5 * RHS_RTOL)
+
+
+@pytest.mark.parametrize("levels,ambi,geo,order,transport,two_t", [
+    (1, False, "3d", 2, capi.ARGON_MIXTURE, True),   # four species with an electron equation (family n4, new in round 3)
+    (1, False, "axisym", 3, capi.CONSTANT, True),
+    (3, True, "2d", 3, capi.ARGON_MIXTURE, True),    # six species, ambipolar (family n6a, new in round 3)
+    (3, True, "3d", 1, capi.CONSTANT, False),
+    # polynomial orders 4 and 5 for the species counts round 2 left at p <= 3
+    (1, True, "3d", 4, capi.ARGON_MIXTURE, True), (2, False, "2d", 5, capi.CONSTANT, True), (2, True, "axisym", 4, capi.CONSTANT, True),
+    (4, True, "axisym", 4, capi.ARGON_MIXTURE, True), (4, False, "3d", 4, capi.CONSTANT, True), (5, False, "2d", 5, capi.CONSTANT, True),
+    (5, True, "3d", 4, capi.CONSTANT, False), (3, True, "axisym", 5, capi.CONSTANT, True),
+])
+def test_plasma_every_species_count_and_order(levels, ambi, geo, order, transport, two_t):
+    """3 ... 8 species, ambipolar or not, at every polynomial order 1 ... 5: the capacity limits of the reference's
+    device build (MAXSPECIES = 8, MAXEQUATIONS = 13, MAXDOFS = 216; src/dataStructures.hpp:41-65)"""
+    ph = capi.argon_levels_physics(levels, ambi, capi.NS, transport, two_t, True, radiation=(geo == "axisym"))
+    _boost_transport(ph, 30.0)
+    small = order >= 4
+    if geo == "axisym":
+        c = cases.argon_axisym(4 if small else 6, 5 if small else 8, order, physics=ph, r_in=0.0)
+    elif geo == "2d":
+        c = cases.Case("plasma_2d", meshgen.box_quad(4 if small else 5, 4, lengths=(0.2, 0.1), warp=0.08), capi.Disc(order, 0, 0, 0, 0), ph, [])
+    else:
+        c = cases.argon_cyl3d(2 if small else 4, 8 if small else 12, 3, order, physics=ph)
+    amp = 0.005 if order == 1 else 0.01
+    _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=29, amp=amp), tol=_tol(amp) * (max(order, 3) / 3.0) ** 2)

@@ -20,10 +20,10 @@ worst = 0.0
 t0 = time.time()
 for it in range(ncases):
     fluid = rng.choice(["dry", "argon3", "argon3n", "argon6", "argon4a", "argon5a", "argon5", "argon7", "argon7a", "argon8",
-                        "argon8a"], p=[0.22, 0.2, 0.08, 0.14, 0.06, 0.06, 0.06, 0.05, 0.04, 0.05, 0.04])
+                        "argon8a", "argon4", "argon6a"], p=[0.2, 0.18, 0.08, 0.12, 0.06, 0.06, 0.06, 0.05, 0.04, 0.05, 0.04, 0.03, 0.03])
     geo = rng.choice(["cyl3d", "box3d", "box2d", "axisym"])
-    # plasma: p = 1..3, and p = 4, 5 for the ternary and six-species families
-    pmax = (6 if geo != "axisym" else 5) if fluid == "dry" else (6 if fluid in ("argon3", "argon3n", "argon6") else 4)
+    # p = 1 .. 5 for every fluid since round 3 (dry air axisymmetric: 1 .. 4)
+    pmax = (6 if geo != "axisym" else 5) if fluid == "dry" else 6
     order = int(rng.integers(1, pmax))
     eq = capi.NS if rng.random() < 0.85 else capi.EULER
     wall = int(rng.choice([capi.INV, capi.SLIP, capi.VISC_ADIAB, capi.VISC_ISOTH]))
@@ -53,7 +53,8 @@ for it in range(ncases):
         two_t = bool(rng.random() < 0.5)
         if fluid not in ("argon3", "argon3n"):
             levels, ambi = {"argon6": (3, False), "argon4a": (1, True), "argon5a": (2, True), "argon5": (2, False),
-                            "argon7": (4, False), "argon7a": (4, True), "argon8": (5, False), "argon8a": (5, True)}[fluid]
+                            "argon7": (4, False), "argon7a": (4, True), "argon8": (5, False), "argon8a": (5, True),
+                            "argon4": (1, False), "argon6a": (3, True)}[fluid]
             trs = [capi.CONSTANT] if levels == 5 else [capi.CONSTANT, capi.ARGON_MIXTURE]  # mixture transport: <= 7 species
             ph = capi.argon_levels_physics(levels, ambi, eq, int(rng.choice(trs)), two_t,
                                            bool(rng.random() < 0.7), radiation=bool(rng.random() < 0.5),
@@ -92,7 +93,7 @@ for it in range(ncases):
             disc, bcs = capi.Disc(order, 0, 0, 0, 0), []
             c = None
         # the non-collocated Gauss-Lobatto pair: dry air and the ternary mixtures, planar 2-D / 3-D, p <= 3, no LES flavour
-        gll = (geo != "axisym" and order <= 3 and fluid in ("dry", "argon3", "argon3n") and rng.random() < 0.2
+        gll = (geo != "axisym" and order <= 3 and rng.random() < 0.2  # (every species count since round 3)
                and not (fluid == "dry" and (ph.sgs.model_type or ph.visc_sponge.enabled)))
         if gll:
             disc = capi.Disc(order, 1, 1, 0, 0)

@@ -215,6 +215,26 @@ struct ForcingDev {
   const double *joule;  // [ndofs] or NULL
 };
 
+// RK4 stage combination fused into the epilogue of k_flux inside tpsrhs_rk4_step / tpsrhs_advance (src/M2ulPhyS.cpp:
+// 2004-2008 around MFEM's RK4Solver::Step): the residual k of a node never goes to memory, the lane that owns the node
+// writes the next stage's state (or the new solution) instead.
+//   mode 0  plain Mult: Y = k
+//   mode 1  out = U + dt/2 k           (stage 1: the stage input is x itself, taken from LDS)
+//   mode 2  out = x0 + dt/2 k          mode 3  out = x0 + dt k
+//   mode 4  out = x0 + [(y2 - x0) + 2 (y3 - x0) + (y4 - x0)] / 3 + dt/6 k,  then the NaN census and the species clamp
+//           (Check_NAN, Check_Undershoot).  With y2 = x0 + dt/2 k1, y3 = x0 + dt/2 k2, y4 = x0 + dt k3 this is
+//           x0 + dt/6 (k1 + 2 k2 + 2 k3 + k4): the accumulator z of RK4Solver::Step is recovered from the stage states
+//           instead of being streamed through memory at every stage (6 vector passes per step instead of 14); the
+//           differences are exact, the result differs from the reference's order of operations by rounding only.
+struct RkDev {
+  int mode, sp_first, sp_last, pad;
+  double dt_host;
+  const double *dt_dev;  // tpsrhs_advance keeps dt in device memory
+  const double *x0, *y2, *y3, *y4;
+  double *out;
+  unsigned long long *nan_count;
+};
+
 struct MeshDev {
   const int *blocks;           // workgroup -> block of EPB consecutive elements (NULL: identity); lets one
                                // launch cover the interior and another the blocks that touch shared faces
@@ -2249,7 +2269,7 @@ template <class C, class PH>
 __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2)) ? (PH::HEAVY ? 1 : 2) : PH::MINW_FLUX) void k_flux(MeshDev m, typename PH::KArg prm_k, const double *__restrict__ U,
                                                    const double *__restrict__ gradUp, const double *__restrict__ TA,
                                                    const double *__restrict__ TB, double *__restrict__ Y,
-                                                   double *__restrict__ block_speed) {
+                                                   double *__restrict__ block_speed, RkDev rk) {
   typename PH::PRef prm = PH::pref(prm_k);
   constexpr int NEQ = PH::NEQ, DIM = C::DIM;
   typedef FluxLds<C, PH> L;
@@ -2495,8 +2515,34 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   }
   if (node_on) {
     const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
+    if (rk.mode == 0) {
 #pragma unroll
-    for (int eq = 0; eq < NEQ; eq++) field_ptr(Y, eq, m.ndofs)[n] = inv_mass * z[eq] + src[eq];
+      for (int eq = 0; eq < NEQ; eq++) field_ptr(Y, eq, m.ndofs)[n] = inv_mass * z[eq] + src[eq];
+    } else {  // RK4 stage combination (see RkDev); uniform branch
+      const double dt = rk.dt_dev ? *rk.dt_dev : rk.dt_host;
+      unsigned long long bad = 0;
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) {
+        const double k = inv_mass * z[eq] + src[eq];
+        double v;
+        if (rk.mode == 1) {
+          v = ldsr(&sU[eq * C::NODES + tid]) + (dt / 2) * k;
+        } else if (rk.mode == 2) {
+          v = field_ptr(rk.x0, eq, m.ndofs)[n] + (dt / 2) * k;
+        } else if (rk.mode == 3) {
+          v = field_ptr(rk.x0, eq, m.ndofs)[n] + dt * k;
+        } else {
+          const double x0 = field_ptr(rk.x0, eq, m.ndofs)[n];
+          const double d2 = field_ptr(rk.y2, eq, m.ndofs)[n] - x0, d3 = field_ptr(rk.y3, eq, m.ndofs)[n] - x0,
+                       d4 = field_ptr(rk.y4, eq, m.ndofs)[n] - x0;
+          v = x0 + ((d2 + 2.0 * d3 + d4) * (1.0 / 3.0) + (dt / 6) * k);
+          if (v != v) bad++;                                        // Check_NAN
+          if (eq >= rk.sp_first && eq < rk.sp_last) v = fmax(v, 0.0);  // Check_Undershoot
+        }
+        field_ptr(rk.out, eq, m.ndofs)[n] = v;
+      }
+      if (bad) atomicAdd(rk.nan_count, bad);
+    }
   }
   FSTAMP(7);
   FSTAMP_FLUSH();
@@ -2528,12 +2574,33 @@ __global__ __launch_bounds__(256) void k_point_eval(typename PH::KArg prm_k, int
   }
 }
 
+// One block reduces the 50 176 per-block maxima of cfg2: a lane's loads must not wait for each other (round 2: one
+// dependent load per iteration, 196 iterations of a full memory latency = 75 us per call of the time loop's k_step_end)
+template <int BLOCK>
+__device__ inline double strided_max(int n, const double *__restrict__ v) {
+  constexpr int UN = 8;
+  double m[UN];
+#pragma unroll
+  for (int u = 0; u < UN; u++) m[u] = 0.0;
+  int i = threadIdx.x;
+  for (; i + (UN - 1) * BLOCK < n; i += UN * BLOCK) {
+    double t[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) t[u] = v[i + u * BLOCK];  // UN independent loads in flight
+#pragma unroll
+    for (int u = 0; u < UN; u++) m[u] = fmax(m[u], t[u]);
+  }
+  for (; i < n; i += BLOCK) m[0] = fmax(m[0], v[i]);
+#pragma unroll
+  for (int u = 1; u < UN; u++) m[0] = fmax(m[0], m[u]);
+  return m[0];
+}
+
 // max over the per-block maxima written by k_flux (one block)
 template <int BLOCK>
 __global__ void k_reduce_max(int n, const double *__restrict__ v, double *__restrict__ out) {
   __shared__ double s[BLOCK];
-  double m = 0.0;
-  for (int i = threadIdx.x; i < n; i += BLOCK) m = fmax(m, v[i]);
+  const double m = strided_max<BLOCK>(n, v);
   s[threadIdx.x] = m;
   __syncthreads();
   for (int off = BLOCK / 2; off > 0; off >>= 1) {
@@ -2583,8 +2650,7 @@ template <int BLOCK>
 __global__ void k_step_end(int n, const double *__restrict__ block_speed, double *__restrict__ ctl, int constant_dt,
                            double cfl_hmin_over_dim) {
   __shared__ double s[BLOCK];
-  double m = 0.0;
-  for (int i = threadIdx.x; i < n; i += BLOCK) m = fmax(m, block_speed[i]);
+  const double m = strided_max<BLOCK>(n, block_speed);
   s[threadIdx.x] = m;
   __syncthreads();
   for (int off = BLOCK / 2; off > 0; off >>= 1) {

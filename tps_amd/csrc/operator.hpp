@@ -88,6 +88,7 @@ struct tpsrhs_operator {
   double *d_xh = nullptr, *d_yh = nullptr;  // staging for tpsrhs_mult_host
   double *d_rk = nullptr;                   // k | y | z of tpsrhs_rk4_step
   unsigned long long *d_nan = nullptr;
+  RkDev rk = {};  // mode 0 outside tpsrhs_rk4_step / tpsrhs_advance: k_flux writes the residual
   MixLenDev mixlen = {nullptr, 0.0, 1.0, 0.0};  // MixingLengthTransport (tpsrhs_set_mixing_length); distance NULL: off
   ForcingDev forcing = {};                  // host copy of the optional forcing terms (tpsrhs_set_forcing / _joule_heating)
   ForcingDev *d_forcing = nullptr;
@@ -248,7 +249,7 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
   };
   auto flux = [&](const MeshDev &m, int grid) {
     hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_gradUp, op->d_TA, op->d_TB, y,
-                       op->d_block_speed);
+                       op->d_block_speed, op->rk);
     HIP_CHECK(hipGetLastError());
   };
   // non-reflecting patches: mean of the primitives (+ sum over the ranks), then the boundary-state update;

@@ -1,0 +1,4 @@
+// Plasma kernel family: dim 3, 3 velocity components, 4 species, ambipolar = true; polynomial orders 4 and 5.
+#define TPSRHS_PLASMA_HIGH_ORDERS 1
+#include "plasma_family.hpp"
+TPSRHS_PLASMA_FAMILY(pick_plasma_3d_n4a_hi, 3, 3, 4, true)

@@ -1,0 +1,4 @@
+// Plasma kernel family: dim 2, 3 velocity components, 6 species, ambipolar = true; polynomial orders 4 and 5.
+#define TPSRHS_PLASMA_HIGH_ORDERS 1
+#include "plasma_family.hpp"
+TPSRHS_PLASMA_FAMILY(pick_plasma_axi_n6a_hi, 2, 3, 6, true)

@@ -11,16 +11,15 @@ template <int DIM, int NVEL, int NSP, bool AMBI, bool TWOT, int TR>
 static void pick_plasma_orders(tpsrhs_operator *op) {
   typedef PlasmaPhys<DIM, NVEL, NSP, AMBI, TWOT, TR> PH;
   if (op->nc) {
-    // the Gauss-Lobatto pair: the ternary mixtures (the species count of test/inputs/argonMinimal.ini, which runs
-    // on that pair), planar / 3-D
+    // the Gauss-Lobatto pair (orders 1..3, planar / 3-D): every species count
 #ifndef TPSRHS_PLASMA_HIGH_ORDERS
-    if constexpr (NSP == 3 && NVEL == DIM) {
+    if constexpr (NVEL == DIM) {
       pick_order_nc<DIM, PH>(op);
       return;
     } else
 #endif
     {
-      throw Unsupported("Gauss-Lobatto basis + rule: built for dry air and the ternary plasma (planar 2-D, 3-D)");
+      throw Unsupported("Gauss-Lobatto basis + rule: planar 2-D and 3-D, polynomial orders 1..3");
     }
   }
   upload_tables(DIM, op->order);
@@ -47,10 +46,14 @@ static void pick_plasma_family(tpsrhs_operator *op, bool two_temperature, int tr
     else
       pick_plasma_orders<DIM, NVEL, NSP, AMBI, false, TRANSPORT_CONSTANT>(op);
   } else if (transport == TRANSPORT_ARGON_MIXTURE) {
-    if (two_temperature)
-      pick_plasma_orders<DIM, NVEL, NSP, AMBI, true, TRANSPORT_ARGON_MIXTURE>(op);
-    else
-      pick_plasma_orders<DIM, NVEL, NSP, AMBI, false, TRANSPORT_ARGON_MIXTURE>(op);
+    if constexpr (NSP <= 7) {  // the reference's argon mixture transport asserts at most 7 species (src/gas_transport.cpp:905-911)
+      if (two_temperature)
+        pick_plasma_orders<DIM, NVEL, NSP, AMBI, true, TRANSPORT_ARGON_MIXTURE>(op);
+      else
+        pick_plasma_orders<DIM, NVEL, NSP, AMBI, false, TRANSPORT_ARGON_MIXTURE>(op);
+    } else {
+      throw Unsupported("argon_mixture transport supports at most 7 species");
+    }
   } else {
     if constexpr (NSP == 3) {
       if (two_temperature)

@@ -13,19 +13,13 @@
 
 // kernel families instantiated in their own translation units (plasma_family.hpp)
 #define DECL(name) void name(tpsrhs_operator *op, bool two_temperature, int transport)
-DECL(pick_plasma_3d_n3a); DECL(pick_plasma_3d_n3); DECL(pick_plasma_3d_n6);
-DECL(pick_plasma_2d_n3a); DECL(pick_plasma_2d_n3); DECL(pick_plasma_2d_n6);
-DECL(pick_plasma_axi_n3a); DECL(pick_plasma_axi_n3); DECL(pick_plasma_axi_n6);
-DECL(pick_plasma_3d_n4a); DECL(pick_plasma_3d_n5a); DECL(pick_plasma_3d_n5);
-DECL(pick_plasma_2d_n4a); DECL(pick_plasma_2d_n5a); DECL(pick_plasma_2d_n5);
-DECL(pick_plasma_axi_n4a); DECL(pick_plasma_axi_n5a); DECL(pick_plasma_axi_n5);
-DECL(pick_plasma_3d_n7a); DECL(pick_plasma_3d_n7); DECL(pick_plasma_3d_n8a); DECL(pick_plasma_3d_n8);
-DECL(pick_plasma_2d_n7a); DECL(pick_plasma_2d_n7); DECL(pick_plasma_2d_n8a); DECL(pick_plasma_2d_n8);
-DECL(pick_plasma_axi_n7a); DECL(pick_plasma_axi_n7); DECL(pick_plasma_axi_n8a); DECL(pick_plasma_axi_n8);
+DECL(pick_plasma_3d_n3a); DECL(pick_plasma_3d_n3); DECL(pick_plasma_3d_n4a); DECL(pick_plasma_3d_n4); DECL(pick_plasma_3d_n5a); DECL(pick_plasma_3d_n5); DECL(pick_plasma_3d_n6a); DECL(pick_plasma_3d_n6); DECL(pick_plasma_3d_n7a); DECL(pick_plasma_3d_n7); DECL(pick_plasma_3d_n8a); DECL(pick_plasma_3d_n8);
+DECL(pick_plasma_2d_n3a); DECL(pick_plasma_2d_n3); DECL(pick_plasma_2d_n4a); DECL(pick_plasma_2d_n4); DECL(pick_plasma_2d_n5a); DECL(pick_plasma_2d_n5); DECL(pick_plasma_2d_n6a); DECL(pick_plasma_2d_n6); DECL(pick_plasma_2d_n7a); DECL(pick_plasma_2d_n7); DECL(pick_plasma_2d_n8a); DECL(pick_plasma_2d_n8);
+DECL(pick_plasma_axi_n3a); DECL(pick_plasma_axi_n3); DECL(pick_plasma_axi_n4a); DECL(pick_plasma_axi_n4); DECL(pick_plasma_axi_n5a); DECL(pick_plasma_axi_n5); DECL(pick_plasma_axi_n6a); DECL(pick_plasma_axi_n6); DECL(pick_plasma_axi_n7a); DECL(pick_plasma_axi_n7); DECL(pick_plasma_axi_n8a); DECL(pick_plasma_axi_n8);
 // polynomial orders 4 and 5 (the `_hi` translation units)
-DECL(pick_plasma_3d_n3a_hi); DECL(pick_plasma_3d_n3_hi); DECL(pick_plasma_3d_n6_hi);
-DECL(pick_plasma_2d_n3a_hi); DECL(pick_plasma_2d_n3_hi); DECL(pick_plasma_2d_n6_hi);
-DECL(pick_plasma_axi_n3a_hi); DECL(pick_plasma_axi_n3_hi); DECL(pick_plasma_axi_n6_hi);
+DECL(pick_plasma_3d_n3a_hi); DECL(pick_plasma_3d_n3_hi); DECL(pick_plasma_3d_n4a_hi); DECL(pick_plasma_3d_n4_hi); DECL(pick_plasma_3d_n5a_hi); DECL(pick_plasma_3d_n5_hi); DECL(pick_plasma_3d_n6a_hi); DECL(pick_plasma_3d_n6_hi); DECL(pick_plasma_3d_n7a_hi); DECL(pick_plasma_3d_n7_hi); DECL(pick_plasma_3d_n8a_hi); DECL(pick_plasma_3d_n8_hi);
+DECL(pick_plasma_2d_n3a_hi); DECL(pick_plasma_2d_n3_hi); DECL(pick_plasma_2d_n4a_hi); DECL(pick_plasma_2d_n4_hi); DECL(pick_plasma_2d_n5a_hi); DECL(pick_plasma_2d_n5_hi); DECL(pick_plasma_2d_n6a_hi); DECL(pick_plasma_2d_n6_hi); DECL(pick_plasma_2d_n7a_hi); DECL(pick_plasma_2d_n7_hi); DECL(pick_plasma_2d_n8a_hi); DECL(pick_plasma_2d_n8_hi);
+DECL(pick_plasma_axi_n3a_hi); DECL(pick_plasma_axi_n3_hi); DECL(pick_plasma_axi_n4a_hi); DECL(pick_plasma_axi_n4_hi); DECL(pick_plasma_axi_n5a_hi); DECL(pick_plasma_axi_n5_hi); DECL(pick_plasma_axi_n6a_hi); DECL(pick_plasma_axi_n6_hi); DECL(pick_plasma_axi_n7a_hi); DECL(pick_plasma_axi_n7_hi); DECL(pick_plasma_axi_n8a_hi); DECL(pick_plasma_axi_n8_hi);
 #undef DECL
 void pick_dryair_axisym(tpsrhs_operator *op);
 void pick_dryair_les(tpsrhs_operator *op);
@@ -408,11 +402,8 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   if (plasma) {
     const tpsrhs_perfect_mixture &mx = phys->mixture;
     if (!mx.is_electron_included) throw Unsupported("USER_DEFINED fluids without electrons are not built");
-    const bool fam = (mx.num_species == 3) || (mx.num_species == 6 && !mx.ambipolar) || (mx.num_species == 4 && mx.ambipolar) ||
-                     (mx.num_species == 5) || (mx.num_species == 7) || (mx.num_species == 8);
-    if (!fam)
-      throw Unsupported("USER_DEFINED fluids: built species counts are 3, 5, 7 and 8 (ambipolar or not), 4 (ambipolar) and "
-                        "6 (not ambipolar)");
+    if (mx.num_species < 3 || mx.num_species > TPSRHS_MAXSPECIES)
+      throw Unsupported("USER_DEFINED fluids: 3 to 8 species (electron, background and 1 to 6 others)");
     if (mx.num_species > 7 && phys->transport_model == TPSRHS_ARGON_MIXTURE)  // the reference asserts, src/gas_transport.cpp:905-911
       throw Unsupported("argon_mixture transport supports at most 7 species (Ar, Ar.+1, Ar_m, Ar_r, Ar_p, Ar_h, E)");
     if (mx.num_species != 3 && phys->transport_model == TPSRHS_ARGON_MINIMAL)
@@ -467,29 +458,23 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
                        ? TRANSPORT_CONSTANT
                        : (phys->transport_model == TPSRHS_ARGON_MINIMAL ? TRANSPORT_ARGON_MINIMAL : TRANSPORT_ARGON_MIXTURE);
     typedef void (*pick_fn)(tpsrhs_operator *, bool, int);
-    // families: 3 species (ambipolar / not), 6 (not), and the other counts of the reference's M2ulPhyS inputs --
-    // 4 ambipolar (test/inputs/perfectGas.argon.ini), 5 ambipolar (perfectGas.air.ini), 5 not (input.malamas.test.ini)
-    // (7 and 8 species: up to MAXSPECIES = 8 / MAXEQUATIONS = 13 of src/dataStructures.hpp:41-65)
-    const pick_fn table[3][10] = {
-        {pick_plasma_3d_n3a, pick_plasma_3d_n3, pick_plasma_3d_n6, pick_plasma_3d_n4a, pick_plasma_3d_n5a, pick_plasma_3d_n5,
-         pick_plasma_3d_n7a, pick_plasma_3d_n7, pick_plasma_3d_n8a, pick_plasma_3d_n8},
-        {pick_plasma_2d_n3a, pick_plasma_2d_n3, pick_plasma_2d_n6, pick_plasma_2d_n4a, pick_plasma_2d_n5a, pick_plasma_2d_n5,
-         pick_plasma_2d_n7a, pick_plasma_2d_n7, pick_plasma_2d_n8a, pick_plasma_2d_n8},
-        {pick_plasma_axi_n3a, pick_plasma_axi_n3, pick_plasma_axi_n6, pick_plasma_axi_n4a, pick_plasma_axi_n5a,
-         pick_plasma_axi_n5, pick_plasma_axi_n7a, pick_plasma_axi_n7, pick_plasma_axi_n8a, pick_plasma_axi_n8}};
-    // orders 4 and 5: the ternary mixtures and the six-species torch mixture
-    const pick_fn table_hi[3][3] = {{pick_plasma_3d_n3a_hi, pick_plasma_3d_n3_hi, pick_plasma_3d_n6_hi},
-                                    {pick_plasma_2d_n3a_hi, pick_plasma_2d_n3_hi, pick_plasma_2d_n6_hi},
-                                    {pick_plasma_axi_n3a_hi, pick_plasma_axi_n3_hi, pick_plasma_axi_n6_hi}};
+    // one translation unit per (geometry, species count, ambipolar) family, and a second one for the polynomial orders
+    // 4 and 5: every species count up to MAXSPECIES = 8 (MAXEQUATIONS = 13) of the reference's device build
+    // (src/dataStructures.hpp:41-65), ambipolar or not
+    const pick_fn table[3][12] = {
+        {pick_plasma_3d_n3a, pick_plasma_3d_n3, pick_plasma_3d_n4a, pick_plasma_3d_n4, pick_plasma_3d_n5a, pick_plasma_3d_n5, pick_plasma_3d_n6a, pick_plasma_3d_n6, pick_plasma_3d_n7a, pick_plasma_3d_n7, pick_plasma_3d_n8a, pick_plasma_3d_n8},
+        {pick_plasma_2d_n3a, pick_plasma_2d_n3, pick_plasma_2d_n4a, pick_plasma_2d_n4, pick_plasma_2d_n5a, pick_plasma_2d_n5, pick_plasma_2d_n6a, pick_plasma_2d_n6, pick_plasma_2d_n7a, pick_plasma_2d_n7, pick_plasma_2d_n8a, pick_plasma_2d_n8},
+        {pick_plasma_axi_n3a, pick_plasma_axi_n3, pick_plasma_axi_n4a, pick_plasma_axi_n4, pick_plasma_axi_n5a, pick_plasma_axi_n5, pick_plasma_axi_n6a, pick_plasma_axi_n6, pick_plasma_axi_n7a, pick_plasma_axi_n7, pick_plasma_axi_n8a, pick_plasma_axi_n8}};
+    const pick_fn table_hi[3][12] = {
+        {pick_plasma_3d_n3a_hi, pick_plasma_3d_n3_hi, pick_plasma_3d_n4a_hi, pick_plasma_3d_n4_hi, pick_plasma_3d_n5a_hi, pick_plasma_3d_n5_hi, pick_plasma_3d_n6a_hi, pick_plasma_3d_n6_hi, pick_plasma_3d_n7a_hi, pick_plasma_3d_n7_hi, pick_plasma_3d_n8a_hi, pick_plasma_3d_n8_hi},
+        {pick_plasma_2d_n3a_hi, pick_plasma_2d_n3_hi, pick_plasma_2d_n4a_hi, pick_plasma_2d_n4_hi, pick_plasma_2d_n5a_hi, pick_plasma_2d_n5_hi, pick_plasma_2d_n6a_hi, pick_plasma_2d_n6_hi, pick_plasma_2d_n7a_hi, pick_plasma_2d_n7_hi, pick_plasma_2d_n8a_hi, pick_plasma_2d_n8_hi},
+        {pick_plasma_axi_n3a_hi, pick_plasma_axi_n3_hi, pick_plasma_axi_n4a_hi, pick_plasma_axi_n4_hi, pick_plasma_axi_n5a_hi, pick_plasma_axi_n5_hi, pick_plasma_axi_n6a_hi, pick_plasma_axi_n6_hi, pick_plasma_axi_n7a_hi, pick_plasma_axi_n7_hi, pick_plasma_axi_n8a_hi, pick_plasma_axi_n8_hi}};
     const int geo = (op->dim == 3) ? 0 : (disc->axisymmetric ? 2 : 1);
-    const int fam = (nsp == 6) ? 2 : (nsp == 4) ? 3 : (nsp == 5) ? (ambi ? 4 : 5) : (nsp == 7) ? (ambi ? 6 : 7)
-                    : (nsp == 8) ? (ambi ? 8 : 9) : (ambi ? 0 : 1);
-    if (op->order >= 4 && !op->nc) {
-      if (fam > 2) throw Unsupported("plasma kernels of polynomial orders 4 and 5: built for 3 species and for 6 (not ambipolar)");
+    const int fam = 2 * (nsp - 3) + (ambi ? 0 : 1);
+    if (op->order >= 4 && !op->nc)
       table_hi[geo][fam](op, two_t, tr);
-    } else {
+    else
       table[geo][fam](op, two_t, tr);
-    }
   } else {
     DryAirParams &d = *new (op->params) DryAirParams;
     std::memset(&d, 0, sizeof(d));
@@ -690,7 +675,7 @@ int tpsrhs_mult(tpsrhs_handle h, const double *x, double *y, double /*time*/, do
     HIP_CHECK(hipSetDevice(h->device));
     h->launch(h, x, y, false);
     if (max_char_speed) {
-      hipLaunchKernelGGL(k_reduce_max<256>, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_speed);
+      hipLaunchKernelGGL(k_reduce_max<1024>, dim3(1), dim3(1024), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_speed);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipMemcpyAsync(max_char_speed, h->d_speed, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -734,6 +719,37 @@ void rk4_stages(tpsrhs_operator *h, double *x, double dt, const double *dt_dev) 
                                                                        : h->phys.mixture.num_species - 1)
                               : sp_first;
   const int grid = static_cast<int>(std::min<int64_t>((n + 255) / 256, 8192));
+  if (!h->forcing_active) {
+    // The stage combinations in k_flux's epilogue (RkDev, kernels.hpp): k never goes to memory, the accumulator of
+    // RK4Solver::Step is recovered from the stage states at the end.  (The optional forcing terms add to the residual in
+    // a pass of their own after k_flux: with them the separate stage kernel below stays.)
+    double *y2 = k, *y3 = y, *y4 = z;  // the three stage states
+    const double *ins[4] = {x, y2, y3, y4};
+    double *outs[4] = {y2, y3, y4, x};
+    for (int stage = 1; stage <= 4; stage++) {
+      RkDev r = {};
+      r.mode = stage;
+      r.sp_first = sp_first;
+      r.sp_last = sp_last;
+      r.dt_host = dt;
+      r.dt_dev = dt_dev;
+      r.x0 = x;
+      r.y2 = y2;
+      r.y3 = y3;
+      r.y4 = y4;
+      r.out = outs[stage - 1];
+      r.nan_count = h->d_nan;
+      h->rk = r;
+      try {
+        h->launch(h, ins[stage - 1], outs[stage - 1], false);
+      } catch (...) {
+        h->rk = RkDev{};
+        throw;
+      }
+      h->rk = RkDev{};
+    }
+    return;
+  }
   const double *in = x;
   for (int stage = 1; stage <= 4; stage++) {
     h->launch(h, in, k, false);  // k_s = f(stage input); SetTime is a no-op for this operator
@@ -754,7 +770,7 @@ int tpsrhs_rk4_step(tpsrhs_handle h, double *x, double *time, double dt, double 
     rk4_stages(h, x, dt, nullptr);
     *time += dt;
     if (max_char_speed || nan_count) {
-      hipLaunchKernelGGL(k_reduce_max<256>, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_speed);
+      hipLaunchKernelGGL(k_reduce_max<1024>, dim3(1), dim3(1024), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_speed);
       HIP_CHECK(hipGetLastError());
       double speed = 0.0;
       unsigned long long bad = 0;
@@ -784,7 +800,7 @@ int tpsrhs_advance(tpsrhs_handle h, double *x, double *time, double *dt, int num
     h->nr_dt_dev = h->d_ctl;
     auto one_step = [&] {
       rk4_stages(h, x, 0.0, h->d_ctl);
-      hipLaunchKernelGGL(k_step_end<256>, dim3(1), dim3(256), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_ctl,
+      hipLaunchKernelGGL(k_step_end<1024>, dim3(1), dim3(1024), 0, h->stream, h->flux_grid, h->d_block_speed, h->d_ctl,
                          constant_dt ? 1 : 0, cfl * hmin / static_cast<double>(h->dim));
       HIP_CHECK(hipGetLastError());
       if (!constant_dt && h->reduce && h->topo.num_shared > 0) {  // MPI_Allreduce(MIN) of src/M2ulPhyS.cpp:2015
