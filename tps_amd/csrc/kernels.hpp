@@ -168,8 +168,12 @@ struct Cfg {
   static constexpr int BLOCK = (NPE <= 64) ? 64 : ((NPE <= 128) ? 128 : 256);
   // elements per block.  3-D p = 1: 3 elements = 54 face quadrature points per direction pair, one round of the
   // 64 lanes (4 elements needed a second round for 8 points, and with 11 equations that instantiation kept
-  // 2 x 3 sets of prefetched traces live: 259 spilled VGPRs); the non-collocated pair has 16 points per face
-  static constexpr int EPB = (DIM_ == 3 && P_ == 1) ? (NC_ ? 4 : 3) : BLOCK / NPE;
+  // 2 x 3 sets of prefetched traces live: 259 spilled VGPRs); the non-collocated pair has 16 points per face: 2
+  // elements = 64 points, one round.  Round 2 ran that pair with 4 elements -- two rounds of face points in one wave,
+  // the shape of round 2's failing 11-equation kernel -- and in round 3 the mixtures of 9+ equations with the argon
+  // mixture transport returned a wrong species residual in the lanes of the block's third and fourth element, one of
+  // them a memory fault (tools/probe_gll_p1.py): that shape is gone.
+  static constexpr int EPB = (DIM_ == 3 && P_ == 1) ? (NC_ ? 2 : 3) : BLOCK / NPE;
   static constexpr int NODES = EPB * NPE;
   // one direction pair (faces 2d, 2d+1) of a block
   static constexpr int PF = 2 * EPB;
