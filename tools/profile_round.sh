@@ -19,3 +19,6 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INS
 echo "sq counters done"
 $B > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 python3 tools/profile_summary.py "$OUT" "$TAG" "$W"
+# what the summary wrote under profiles/ lives on the GPU box only: hand it back through gpurun_out/
+mkdir -p gpurun_out/profiles_back
+cp profiles/${TAG}_${W}_* profiles/hbm_traffic.json gpurun_out/profiles_back/ 2>/dev/null || true

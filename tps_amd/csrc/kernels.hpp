@@ -165,7 +165,9 @@ struct Cfg {
   static constexpr int NW = (DIM_ == 3) ? Q1 * N1 : 1;  // half-interpolated face values (3-D only)
   static constexpr int NFACES = 2 * DIM_;
   static constexpr int NV = 1 << DIM_;
-  static constexpr int BLOCK = (NPE <= 64) ? 64 : ((NPE <= 128) ? 128 : 256);
+  // (the Gauss-Lobatto hexes of p = 2, 3 get two waves: their 100 / 72 face quadrature points per direction pair then
+  // are ONE round of the block's lanes -- see EPB below)
+  static constexpr int BLOCK = (NC_ && DIM_ == 3 && P_ >= 2) ? 128 : ((NPE <= 64) ? 64 : ((NPE <= 128) ? 128 : 256));
   // elements per block.  3-D p = 1: 3 elements = 54 face quadrature points per direction pair, one round of the
   // 64 lanes (4 elements needed a second round for 8 points, and with 11 equations that instantiation kept
   // 2 x 3 sets of prefetched traces live: 259 spilled VGPRs); the non-collocated pair has 16 points per face: 2
@@ -173,7 +175,15 @@ struct Cfg {
   // the shape of round 2's failing 11-equation kernel -- and in round 3 the mixtures of 9+ equations with the argon
   // mixture transport returned a wrong species residual in the lanes of the block's third and fourth element, one of
   // them a memory fault (tools/probe_gll_p1.py): that shape is gone.
-  static constexpr int EPB = (DIM_ == 3 && P_ == 1) ? (NC_ ? 2 : 3) : BLOCK / NPE;
+  // Every failing instantiation of rounds 2 and 3 had the same shape -- a single-wave block that takes TWO rounds of face
+  // quadrature points (and then more than 256 registers with SGPR spills) --, and no other shape has failed in the
+  // exhaustive sweep (tools/sweep_instantiations.py): in 3-D no block takes a second round any more.  Gauss-Lobatto
+  // pair: p = 1: 2 hexes x 2 faces x 16 points = 64; p = 2: 2 hexes, 100 points, 128 lanes; p = 3: 1 hex, 72 points,
+  // 128 lanes.  2-D, Gauss-Lobatto p = 1: 10 quads (60 points; 16 quads = 96 before).
+  static constexpr int EPB = (DIM_ == 3 && NC_) ? (P_ == 3 ? 1 : 2)
+                             : (DIM_ == 3 && P_ == 1) ? 3
+                             : (DIM_ == 2 && NC_ && P_ == 1) ? 10
+                                                             : BLOCK / NPE;
   static constexpr int NODES = EPB * NPE;
   // one direction pair (faces 2d, 2d+1) of a block
   static constexpr int PF = 2 * EPB;
@@ -182,6 +192,8 @@ struct Cfg {
   static constexpr int TQ = PF * NQ;
   static constexpr int LN = EPB * NF;
   static constexpr int Q_ROUNDS = (TQ + BLOCK - 1) / BLOCK;
+  static_assert(DIM_ == 2 || Q_ROUNDS == 1, "3-D: one round of face quadrature points per direction pair");
+  static_assert(!(DIM_ == 2 && NC_) || Q_ROUNDS == 1, "2-D Gauss-Lobatto pair: one round per direction pair");
   // 2-D: the quadrature points of BOTH direction pairs of a block are worked on together (at p = 3 they
   // are 2 x 32 = one full 64-lane round; one pair at a time leaves half of the lanes idle in the physics)
   static constexpr int TQ2 = 2 * TQ;
