@@ -36,6 +36,8 @@ def worker(geo, nsp, ambi):
                     ph.gas_transport.multiply = 1
                     for k in range(4):
                         ph.gas_transport.flux_trns_multiplier[k] = 30.0
+                    if ph.gas_transport.third_order_k_electron:  # ill-conditioned in double precision (tests/test_gpu_parity.py
+                        ph.gas_transport.flux_trns_multiplier[3] = 1.0  # ::_boost_transport): not amplified
                     ph.gas_transport.diff_mult = ph.gas_transport.mobil_mult = 30.0
                     small = order >= 4
                     if geo == "3d":
@@ -48,11 +50,16 @@ def worker(geo, nsp, ambi):
                     disc = capi.Disc(order, nc, nc, 1 if geo == "axi" else 0, 0)
                     amp = 0.005 if order == 1 else 0.01
                     nvel = 2 if geo == "2d" else 3
-                    U = cases.plasma_state(node_coordinates(c.mesh, order, nc), ph, nvel=nvel, seed=11, amp=amp,
-                                           vel0=(1.0, 20.0, 3.0) if geo == "axi" else (20.0, 0.0, 0.0))
-                    tag = f"{geo} nsp={nsp} ambi={int(ambi)} 2T={int(two_t)} tr={tr} p={order} nc={nc} neq={U.shape[0]}"
+                    tag = f"{geo} nsp={nsp} ambi={int(ambi)} 2T={int(two_t)} tr={tr} p={order} nc={nc}"
                     try:
-                        ref = oracle_mult(c.mesh, disc, ph, c.bcs, U)
+                        for attempt in range(3):  # a state the oracle accepts (coarse meshes extrapolate to negative densities)
+                            U = cases.plasma_state(node_coordinates(c.mesh, order, nc), ph, nvel=nvel, seed=11, amp=amp,
+                                                   vel0=(1.0, 20.0, 3.0) if geo == "axi" else (20.0, 0.0, 0.0))
+                            ref = oracle_mult(c.mesh, disc, ph, c.bcs, U)
+                            if np.isfinite(ref["y"]).all():
+                                break
+                            amp *= 0.3
+                        tag += f" neq={U.shape[0]}"
                         if not np.isfinite(ref["y"]).all():
                             print(f"{tag}: oracle not finite, skipped", flush=True)
                             continue

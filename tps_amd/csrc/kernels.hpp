@@ -262,6 +262,26 @@ struct MeshDev {
   MixLenDev ml;                // MixingLengthTransport (2-D kernels): wall-distance grid function, or distance = NULL
 };
 
+// XCD-aware block order.  The hardware hands workgroup b of a launch to XCD b % 8, each XCD with an L2 of its own: with
+// the identity order an element and its face neighbours (e +- 1, e +- nr, ...) sit on eight different L2s, and the trace
+// records that BOTH sides of a face read are never found in the L2 by the second reader.  Here the workgroups of one XCD
+// take one contiguous eighth of the block list, so that neighbours (all but those across the seven chunk borders) share
+// an L2.  A bijection of [0, n): XCD x runs the workgroups x, x + 8, ... -- q + (x < r) of them -- and owns the chunk
+// [x q + min(x, r), ...) of that length.
+#ifndef TPSRHS_XCD_ORDER
+#define TPSRHS_XCD_ORDER 1
+#endif
+__device__ inline int xcd_block(int b, int n) {
+#if TPSRHS_XCD_ORDER
+  constexpr int X = 8;
+  const int q = n / X, r = n - q * X;
+  const int x = b % X, k = b / X;
+  return x * q + (x < r ? x : r) + k;
+#else
+  return b;
+#endif
+}
+
 // Face records of the block's elements -> LDS, once, so that no later stage has a global load on the
 // path to a neighbour address (nb = INT32_MIN marks the faces of elements past the end of the mesh).
 template <class C>
@@ -713,7 +733,8 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::KAr
   __shared__ double sF[2 * NEQ * C::NODES];
   __shared__ double sT[(C::DIM == 2 ? 2 : 1) * 2 * NEQ * C::TN];
   const int tid = threadIdx.x;
-  const int bid = m.blocks ? m.blocks[blockIdx.x] : static_cast<int>(blockIdx.x);
+  const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int bid = m.blocks ? m.blocks[lin] : lin;
   const int e0 = bid * C::EPB;
   if (tid < C::NODES) {
     const int le = tid / C::NPE, nd = tid - le * C::NPE;
@@ -1565,7 +1586,8 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
   double *sW = pool + L::O_W;    // W chunk of the viscous phase
 
   const int tid = threadIdx.x;
-  const int bid = m.blocks ? m.blocks[blockIdx.x] : static_cast<int>(blockIdx.x);
+  const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int bid = m.blocks ? m.blocks[lin] : lin;
   const int e0 = bid * C::EPB;
   __shared__ int2 sFI[C::EPB * C::NFACES];
   STAMP_DECL;
@@ -2298,7 +2320,8 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   double *sX = sGf, *sY = sGf + L::X;
 
   const int tid = threadIdx.x;
-  const int bid = m.blocks ? m.blocks[blockIdx.x] : static_cast<int>(blockIdx.x);
+  const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int bid = m.blocks ? m.blocks[lin] : lin;
   const int e0 = bid * C::EPB;
   __shared__ int2 sFI[C::EPB * C::NFACES];
   FSTAMP_DECL;
