@@ -82,6 +82,13 @@ enum tpsrhs_inlet_type {
   TPSRHS_UNI_DENS_VEL = 0,
   TPSRHS_INTERPOLATE = 1,
   TPSRHS_SUB_DENS_VEL = 2,
+  /* density and velocity RELATIVE TO THE INLET FACE (src/inletBC.cpp:453-464, 758-864; "subsonicFaceBasedX/Y/Z"): data =
+   * {rho, U_normal (into the domain), U_tangent, unused, active species ...}; the face frame is the inward unit normal
+   * made orthogonal to the global x / y / z axis, the axis itself, and their cross product.  3-D only (the reference's
+   * frame has three components). */
+  TPSRHS_SUB_DENS_VEL_FACE_X = 3,
+  TPSRHS_SUB_DENS_VEL_FACE_Y = 4,
+  TPSRHS_SUB_DENS_VEL_FACE_Z = 5,
   TPSRHS_SUB_DENS_VEL_NR = 6,   /* non-reflecting, density and velocity (src/inletBC.cpp:576-727) */
   TPSRHS_SUB_VEL_CONST_ENT = 7  /* non-reflecting, velocity, constant entropy (same routine, L2 = 0) */
 };

@@ -901,7 +901,9 @@ class BoundaryCondition {
     } else if (category == TPSRHS_INLET) {
       if (type == TPSRHS_SUB_DENS_VEL_NR || type == TPSRHS_SUB_VEL_CONST_ENT)
         nonReflecting = true;
-      else if (type != TPSRHS_SUB_DENS_VEL)
+      else if (type >= TPSRHS_SUB_DENS_VEL_FACE_X && type <= TPSRHS_SUB_DENS_VEL_FACE_Z) {
+        if (dim != 3 || axisym) throw std::runtime_error("face-relative inlets: dim == 3");
+      } else if (type != TPSRHS_SUB_DENS_VEL)
         throw std::runtime_error("inlet type outside the hot-path scope");
     } else if (category == TPSRHS_OUTLET) {
       if (type == TPSRHS_SUB_P_NR || type == TPSRHS_SUB_MF_NR || type == TPSRHS_SUB_MF_NR_PW)
@@ -1079,6 +1081,49 @@ class BoundaryCondition {
     // the reference stores the unit normal in the member bcFlux_ (src/wallBC.cpp:448,492); the
     // oracle's face loop is threaded, so each call works on its own copy
     BoundaryViscousFluxData bcFlux = this->bcFlux;
+    if (category == TPSRHS_INLET && type >= TPSRHS_SUB_DENS_VEL_FACE_X && type <= TPSRHS_SUB_DENS_VEL_FACE_Z) {
+      // InletBC::subsonicReflectingDensityVelocityFace, src/inletBC.cpp:758-864 (tangentW = the global axis, :453-464)
+      const double p = mixture->ComputePressure(stateIn);
+      double state2[MAXEQ];
+      for (int eq = 0; eq < num_equation; eq++) state2[eq] = stateIn[eq];
+      const double wt = 1.0;  // the time ramp of the reference is overwritten by 1 (:770-773)
+      const double Un = wt * inputState[1], Ut = wt * inputState[2];
+      double unitNorm[3], tangent1[3], tangent2[3] = {0, 0, 0};
+      double mod = 0.;
+      for (int d = 0; d < dim; d++) mod += normal[d] * normal[d];
+      for (int d = 0; d < dim; d++) unitNorm[d] = normal[d] * (-1.0 / std::sqrt(mod));  // inward-facing normal
+      tangent2[type - TPSRHS_SUB_DENS_VEL_FACE_X] = 1.0;
+      {  // ensure normal is orthogonal to tangent-w
+        double tmag = 0.0, tn = 0.0;
+        for (int d = 0; d < dim; d++) tmag += tangent2[d] * tangent2[d];
+        for (int d = 0; d < dim; d++) tn += tangent2[d] * unitNorm[d];
+        for (int d = 0; d < dim; d++) unitNorm[d] -= (tn / tmag) * tangent2[d];
+      }
+      tangent1[0] = +(unitNorm[1] * tangent2[2] - unitNorm[2] * tangent2[1]);
+      tangent1[1] = -(unitNorm[0] * tangent2[2] - unitNorm[2] * tangent2[0]);
+      tangent1[2] = +(unitNorm[0] * tangent2[1] - unitNorm[1] * tangent2[0]);
+      state2[0] = inputState[0];
+      state2[1] = state2[0] * Un;
+      state2[2] = state2[0] * Ut;
+      state2[3] = state2[0] * 0.0;
+      {  // transform from face coords to global: M rows = unitNorm, tangent1, tangent2; momX = M^-1 momN [MFEM CalcInverse]
+        const double M[9] = {unitNorm[0], unitNorm[1], unitNorm[2], tangent1[0], tangent1[1], tangent1[2], tangent2[0], tangent2[1], tangent2[2]};
+        const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+        const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+        const double inv[9] = {c00, M[2] * M[7] - M[1] * M[8], M[1] * M[5] - M[2] * M[4],
+                               c01, M[0] * M[8] - M[2] * M[6], M[2] * M[3] - M[0] * M[5],
+                               c02, M[1] * M[6] - M[0] * M[7], M[0] * M[4] - M[1] * M[3]};
+        const double momN[3] = {state2[1], state2[2], state2[3]};
+        for (int i = 0; i < 3; i++) state2[1 + i] = (inv[3 * i] * momN[0] + inv[3 * i + 1] * momN[1] + inv[3 * i + 2] * momN[2]) / det;
+      }
+      for (int sp = 0; sp < numActiveSpecies; sp++) state2[nvel + 2 + sp] = inputState[4 + sp];
+      double tmpU[MAXEQ];
+      for (int eq = 0; eq < num_equation; eq++) tmpU[eq] = state2[eq];
+      for (int eq = 1; eq <= dim; eq++) tmpU[eq] = 2.0 * state2[eq] - stateIn[eq];
+      mixture->modifyEnergyForPressure(tmpU, tmpU, p, true);
+      rsolver->Eval(stateIn, tmpU, normal, bdrFlux, true);
+      return;
+    }
     if (category == TPSRHS_INLET) {  // src/inletBC.cpp:729-757
       const double p = mixture->ComputePressure(stateIn);
       double state2[MAXEQ];

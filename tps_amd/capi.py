@@ -28,6 +28,7 @@ SPECIES_MW, SPECIES_CHARGES, FORMATION_ENERGY, SPECIES_DEGENERACY = 0, 1, 2, 3
 CLMB_ATT, CLMB_REP, AR_AR1P, AR_E, AR_AR, NONE_ARGCOLL = 0, 1, 2, 3, 4, 5
 INLET, OUTLET, WALL = 0, 1, 2
 SUB_DENS_VEL, SUB_DENS_VEL_NR, SUB_VEL_CONST_ENT = 2, 6, 7
+SUB_DENS_VEL_FACE_X, SUB_DENS_VEL_FACE_Y, SUB_DENS_VEL_FACE_Z = 3, 4, 5
 SUB_P, SUB_P_NR, SUB_MF_NR, SUB_MF_NR_PW = 0, 2, 3, 4
 INV, SLIP, VISC_ADIAB, VISC_ISOTH, VISC_GNRL = 0, 1, 2, 3, 4
 ADIAB, ISOTH, SHTH, NONE_THMCND = 0, 1, 2, 3  # ThermalCondition of viscous_general walls

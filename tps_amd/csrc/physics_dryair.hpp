@@ -127,6 +127,34 @@ __device__ inline void slip_ghost_momentum_2d(const double *n, const double *U, 
   Ug[2] = U[0] * (-t[0] * a + u[0] * b) / det;
 }
 
+// Inlet "relative to the face" (SUB_DENS_VEL_FACE_X/Y/Z, src/inletBC.cpp:758-864): momentum of the prescribed state in
+// global coordinates.  Face frame: the inward unit normal minus its component along the global axis `axis` (NOT
+// renormalised, as in the reference), tangent1 = that x axis (with the reference's signs), tangent2 = the axis; the
+// prescribed momentum (rho Un, rho Ut, 0) is given in that frame and comes back through the inverse of M = rows
+// (normal, tangent1, tangent2) [MFEM CalcInverse of a 3 x 3: adjugate / determinant].
+__device__ inline void face_inlet_momentum(const double *n, int axis, double rho, double Un, double Ut, double *mom) {
+  double mod = 0.0;
+  for (int d = 0; d < 3; d++) mod += n[d] * n[d];
+  const double sc = -1.0 / sqrt(mod);
+  double un[3] = {n[0] * sc, n[1] * sc, n[2] * sc};
+  double t2[3] = {0.0, 0.0, 0.0};
+  t2[axis] = 1.0;
+  const double tn = un[axis];  // (t . n) / |t|^2 with |t| = 1
+  un[axis] -= tn;
+  const double t1[3] = {+(un[1] * t2[2] - un[2] * t2[1]), -(un[0] * t2[2] - un[2] * t2[0]), +(un[0] * t2[1] - un[1] * t2[0])};
+  const double M[9] = {un[0], un[1], un[2], t1[0], t1[1], t1[2], t2[0], t2[1], t2[2]};  // row-major
+  const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+  const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+  const double inv[9] = {c00, M[2] * M[7] - M[1] * M[8], M[1] * M[5] - M[2] * M[4],
+                         c01, M[0] * M[8] - M[2] * M[6], M[2] * M[3] - M[0] * M[5],
+                         c02, M[1] * M[6] - M[0] * M[7], M[0] * M[4] - M[1] * M[3]};
+  const double mn[3] = {rho * Un, rho * Ut, 0.0};
+  for (int i = 0; i < 3; i++) mom[i] = (inv[3 * i] * mn[0] + inv[3 * i + 1] * mn[1] + inv[3 * i + 2] * mn[2]) / det;
+}
+__host__ __device__ inline bool is_face_inlet(int category, int type) {
+  return category == TPSRHS_INLET && type >= TPSRHS_SUB_DENS_VEL_FACE_X && type <= TPSRHS_SUB_DENS_VEL_FACE_Z;
+}
+
 __host__ __device__ inline bool is_non_reflecting(int category, int type) {
   return (category == TPSRHS_INLET && (type == TPSRHS_SUB_DENS_VEL_NR || type == TPSRHS_SUB_VEL_CONST_ENT)) ||
          (category == TPSRHS_OUTLET && (type == TPSRHS_SUB_P_NR || type == TPSRHS_SUB_MF_NR || type == TPSRHS_SUB_MF_NR_PW));
@@ -756,6 +784,20 @@ struct DryAirPhys {
       const double pres = pressure(p, U);
       Ug[0] = bc.data[0];
       double k = 0.0;
+      if constexpr (DIM == 3) {
+        if (is_face_inlet(bc.category, bc.type)) {  // src/inletBC.cpp:758-864: tmpU = 2 state2 - stateIn in the momentum rows
+          double mom[3];
+          face_inlet_momentum(n, bc.type - TPSRHS_SUB_DENS_VEL_FACE_X, bc.data[0], bc.data[1], bc.data[2], mom);
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            Ug[1 + d] = 2.0 * mom[d] - U[1 + d];
+            k += Ug[1 + d] * Ug[1 + d];
+          }
+          k *= 0.5 / Ug[0];
+          Ug[1 + NVEL] = pres / (p.gamma - 1.0) + k;
+          return;
+        }
+      }
 #pragma unroll
       for (int d = 0; d < NVEL; d++) {
         Ug[1 + d] = bc.data[0] * bc.data[1 + d];

@@ -1151,6 +1151,14 @@ struct PlasmaPhys {
       s2[0] = bc.data[0];
 #pragma unroll
       for (int d = 0; d < NVEL; d++) s2[1 + d] = bc.data[0] * bc.data[1 + d];
+      if constexpr (DIM == 3) {
+        if (is_face_inlet(bc.category, bc.type)) {  // velocity relative to the face, mirrored momentum (src/inletBC.cpp:758-864)
+          double mom[3];
+          face_inlet_momentum(n, bc.type - TPSRHS_SUB_DENS_VEL_FACE_X, bc.data[0], bc.data[1], bc.data[2], mom);
+#pragma unroll
+          for (int d = 0; d < 3; d++) s2[1 + d] = 2.0 * mom[d] - U[1 + d];
+        }
+      }
 #pragma unroll
       for (int sp = 0; sp < NACTIVE; sp++) s2[NVEL + 2 + sp] = bc.data[4 + sp];
       energy_for_pressure(p, s2, pres, true, Ug);

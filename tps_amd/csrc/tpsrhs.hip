@@ -375,7 +375,10 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
                         "characteristic algebra (src/outletBC.cpp:573-1027)");
     if (nr && (b.type == TPSRHS_SUB_MF_NR || b.type == TPSRHS_SUB_MF_NR_PW) && !(b.data[7] > 0.0))
       throw std::invalid_argument("mass-flow outlet: data[7] must hold the total patch area");
-    const bool ok = nr || (b.category == TPSRHS_INLET && b.type == TPSRHS_SUB_DENS_VEL) ||
+    const bool face_inlet = is_face_inlet(b.category, b.type);
+    if (face_inlet && (op->dim != 3 || disc->axisymmetric))
+      throw Unsupported("face-relative inlets (subsonicFaceBasedX/Y/Z): 3-D (the reference's face frame has three components)");
+    const bool ok = nr || face_inlet || (b.category == TPSRHS_INLET && b.type == TPSRHS_SUB_DENS_VEL) ||
                     (b.category == TPSRHS_OUTLET && b.type == TPSRHS_SUB_P) ||
                     (b.category == TPSRHS_WALL &&
                      (b.type == TPSRHS_INV || b.type == TPSRHS_SLIP || b.type == TPSRHS_VISC_ADIAB || b.type == TPSRHS_VISC_ISOTH ||
