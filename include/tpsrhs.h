@@ -219,8 +219,11 @@ typedef struct tpsrhs_radiation { /* RadiationInput */
 
 /* Fluxes: sub-grid scale model ([flow] sgsModel / sgsModelConstant / sgsFloor, src/M2ulPhyS.cpp:2689-2699,
  * src/fluxes.cpp:513-665) and the planar viscous sponge ([viscosityMultiplierFunction], src/M2ulPhyS.cpp:2788-2808,
- * src/fluxes.cpp:669-688).  Built for dry air, planar 2-D (sponge only: the reference's strain tensor indexes three
- * directions) and 3-D, Gauss-Legendre pair; anything else: TPSRHS_ERR_UNSUPPORTED. */
+ * src/fluxes.cpp:669-688).  The sub-grid scale models: dry air, 3-D (the reference's strain tensor indexes three
+ * directions).  The viscous sponge: dry air planar 2-D and 3-D, and every 2-D formulation with the heavy kernel
+ * interface -- axisymmetric dry air and table gas, the mixtures planar and axisymmetric (there it also scales the
+ * diffusion velocities of the active species, src/fluxes.cpp:240-245).  Gauss-Legendre pair; anything else:
+ * TPSRHS_ERR_UNSUPPORTED. */
 enum tpsrhs_sgs_model { TPSRHS_SGS_NONE = 0, TPSRHS_SGS_SMAGORINSKY = 1, TPSRHS_SGS_SIGMA = 2 };
 typedef struct tpsrhs_sgs {
   int model_type;      /* tpsrhs_sgs_model */
@@ -234,6 +237,26 @@ typedef struct tpsrhs_visc_sponge { /* viscositySpongeData (src/M2ulPhyS.cpp:583
   double width, ratio;
 } tpsrhs_visc_sponge;
 
+/* WorkingFluid::LTE_FLUID: the local-thermodynamic-equilibrium table gas, LteMixture + LteTransport
+ * (src/lte_mixture.cpp, src/lte_transport_properties.cpp) with ONE-DIMENSIONAL tables in the temperature
+ * (`flow/lte/table_dim = 1`, the variant of the reference's device build, src/M2ulPhyS.cpp:164-255: the columns of its
+ * "T_energy_R_c" and "T_mu_kappa_sigma" datasets; linear scales).  One species, num_equation = nvel + 2; the inverse
+ * table T(e) is the energy table with abscissae and values swapped, as the reference builds it (:193-200), so the
+ * energies must increase with the temperature.  The two-dimensional (T, rho) tables of the reference's CPU build
+ * interpolate with GSL (third party, `flow/lte/table_dim = 2`) and are not built.  The radiation sink of SourceTerm
+ * (src/source_term.cpp:207-209) is tpsrhs_physics::radiation; the electric conductivity table is carried for the
+ * plasma-conductivity side output of SourceTerm (:196), which this library does not produce yet.
+ * Built for the axisymmetric formulation (the reference's LTE inputs, test/inputs/plasma.lte1d.ini), Gauss-Legendre
+ * pair; anything else: TPSRHS_ERR_UNSUPPORTED. */
+typedef struct tpsrhs_lte { /* LteMixtureInput + the TableInputs of src/M2ulPhyS.cpp:176-255 */
+  tpsrhs_table energy_table;                /* T -> specific internal energy e [J/kg] */
+  tpsrhs_table gas_constant_table;          /* T -> mixture gas constant R [J/(kg K)], p = rho R T */
+  tpsrhs_table sound_speed_table;           /* T -> c [m/s] */
+  tpsrhs_table viscosity_table;             /* T -> mu [Pa s] */
+  tpsrhs_table conductivity_table;          /* T -> kappa [W/(m K)] */
+  tpsrhs_table electric_conductivity_table; /* T -> sigma [S/m] */
+} tpsrhs_lte;
+
 typedef struct tpsrhs_physics {
   int eq_system;        /* tpsrhs_equations */
   int working_fluid;    /* tpsrhs_working_fluid */
@@ -246,6 +269,7 @@ typedef struct tpsrhs_physics {
   tpsrhs_radiation radiation;
   tpsrhs_sgs sgs;
   tpsrhs_visc_sponge visc_sponge;
+  tpsrhs_lte lte;       /* LTE_FLUID only */
 } tpsrhs_physics;
 
 /* ---- boundary conditions: [boundaryConditions/...] (src/M2ulPhyS.cpp:3480-3700) --------------- */

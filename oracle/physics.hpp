@@ -97,6 +97,9 @@ class GasMixture {
   virtual void computeSheathBdrFlux(const double *, BoundaryViscousFluxData &) const {
     throw std::runtime_error("sheath boundary flux needs a plasma mixture");
   }
+  virtual double ComputePressureFromPrimitives(const double *) const {
+    throw std::runtime_error("ComputePressureFromPrimitives: not restated for this mixture through the base class");
+  }
   virtual double GetGasConstant() const { return 0.0; }
   virtual double GetSpecificHeatRatio() const { return 0.0; }
   virtual double GetGasParams(int sp, int param) const { return 0.0; }

@@ -1116,6 +1116,8 @@ inline void axisym_source_point(GasMixture &mix, TransportProperties &trans, int
   double pressure;
   if (PerfectMixture *pm = dynamic_cast<PerfectMixture *>(&mix)) {
     pressure = pm->ComputePressureFromPrimitives(Up);
+  } else if (mix.GetGasConstant() == 0.0) {  // the table gas (oracle/lte.hpp): rho R(T) T, src/lte_mixture.cpp:138-147
+    pressure = mix.ComputePressureFromPrimitives(Up);
   } else {
     pressure = mix.GetGasConstant() * Up[0] * Up[mix.iTh];  // DryAir::ComputePressureFromPrimitives
   }

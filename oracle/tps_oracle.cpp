@@ -21,6 +21,7 @@
 #include "fe.hpp"
 #include "physics.hpp"
 #include "plasma.hpp"
+#include "lte.hpp"
 
 namespace tpsoracle {
 
@@ -38,6 +39,7 @@ struct Operator {
   std::unique_ptr<Fluxes> fluxes;
   std::unique_ptr<RiemannSolver> rsolver;
   std::unique_ptr<SourceTerm> source;
+  LinearTable lteNec;  // net emission table of the table gas' radiation sink
   std::map<int, std::unique_ptr<BoundaryCondition>> bcs;
   // ConstantPressureGradient / SpongeZone / HeatSource / JouleHeating (src/rhs_operator.cpp:101-166)
   bool has_forcing = false;
@@ -81,8 +83,12 @@ struct Operator {
       PerfectMixture *pm = new PerfectMixture(p->mixture, dim, nvel);
       mixture.reset(pm);
       transport.reset(make_transport(pm, *p));
+    } else if (p->working_fluid == TPSRHS_LTE_FLUID) {  // src/M2ulPhyS.cpp:164-255, table_dim == 1
+      mixture.reset(new LteMixture(p->lte, dim, nvel));
+      transport.reset(new LteTransport(mixture.get(), p->lte));
+      if (p->radiation.model == TPSRHS_NET_EMISSION) lteNec.init(p->radiation.nec_table);
     } else {
-      throw std::runtime_error("working fluid outside the hot-path scope");
+      throw std::runtime_error("unknown working fluid");
     }
     neq = mixture->num_equation;
     fluxes.reset(new Fluxes(mixture.get(), p->eq_system, transport.get(), neq, dim, axisym));
@@ -116,7 +122,7 @@ struct Operator {
     if (d->use_roe && (dim != 2 || axisym || p->working_fluid != TPSRHS_DRY_AIR))
       throw std::runtime_error("Eval_Roe: 2-D, single species, not axisymmetric (src/riemann_solver.cpp:117-206)");
     rsolver.reset(new RiemannSolver(neq, mixture.get(), fluxes.get(), d->use_roe != 0));
-    if (p->working_fluid != TPSRHS_DRY_AIR) {  // src/rhs_operator.cpp:125-129
+    if (p->working_fluid == TPSRHS_USER_DEFINED) {  // src/rhs_operator.cpp:125-129 (the table gas: lteSource below)
       source.reset(new SourceTerm(dim, neq, static_cast<PerfectMixture *>(mixture.get()), transport.get(), *p));
     }
     for (int i = 0; i < nbc; i++)
@@ -579,6 +585,7 @@ struct Operator {
       for (size_t hs = 0; hs < heatNodes.size(); hs++)  // HeatSource::updateTerms, src/forcing_terms.cpp:923-936
         for (int64_t node : heatNodes[hs]) y[node + (dim + 1) * N] += forcing_in.heat_sources[hs].value;
     if (source) source->updateTerms(x, Up.data(), gradUp.data(), ndofs, y);
+    if (phys.working_fluid == TPSRHS_LTE_FLUID) lteSource(y);
     if (axisym) axisymmetricSource(x, y);
     if (!joule.empty()) {  // JouleHeating::updateTerms, src/forcing_terms.cpp:443-471
       if (nvel != 3) throw std::runtime_error("JouleHeating asserts nvel == 3");
@@ -667,6 +674,13 @@ struct Operator {
   }
 
   // ConstantPressureGradient::updateTerms (CPU branch), src/forcing_terms.cpp:132-171
+  // SourceTerm::updateTerms (src/source_term.cpp:62-256) for the table gas (numSpecies == 1: no chemistry, not
+  // two-temperature): what is left is the radiation sink at the node's primitive temperature (:207-209)
+  void lteSource(double *y) {
+    if (phys.radiation.model != TPSRHS_NET_EMISSION) return;
+    const int64_t N = ndofs;
+    for (int64_t n = 0; n < N; n++) y[n + (1 + nvel) * N] += -4.0 * PI_ * lteNec.eval(Up[n + (1 + nvel) * N]);
+  }
   void constantPressureGradient(double *y) {
     const int64_t N = ndofs;
     const double *pressGrad = forcing_in.pressure_gradient;
@@ -676,6 +690,8 @@ struct Operator {
       double p;
       if (phys.working_fluid == TPSRHS_DRY_AIR)
         p = mixture->GetGasConstant() * primi[0] * primi[nvel + 1];  // DryAir::ComputePressureFromPrimitives :361
+      else if (phys.working_fluid == TPSRHS_LTE_FLUID)
+        p = static_cast<LteMixture *>(mixture.get())->ComputePressureFromPrimitives(primi);
       else
         p = static_cast<PerfectMixture *>(mixture.get())->ComputePressureFromPrimitives(primi);
       double grad_pV = 0.;
@@ -735,6 +751,8 @@ struct Operator {
     double speedSound;  // mixture->ComputeSpeedOfSound(Up, true)
     if (phys.working_fluid == TPSRHS_DRY_AIR)
       speedSound = std::sqrt(mixture->GetSpecificHeatRatio() * mixture->GetGasConstant() * Upt[nvel + 1]);  // :337-348
+    else if (phys.working_fluid == TPSRHS_LTE_FLUID)
+      speedSound = static_cast<LteMixture *>(mixture.get())->ComputeSpeedOfSound(Upt, true);
     else  // the primitive branch (:1406-1419) rebuilds exactly the quantities of the conserved one
       speedSound = static_cast<PerfectMixture *>(mixture.get())->ComputeSpeedOfSound(targetU);
     for (int64_t n = 0; n < N; n++) {

@@ -118,11 +118,16 @@ SGS_NONE, SGS_SMAGORINSKY, SGS_SIGMA = 0, 1, 2
 SPONGE_USERDEF, SPONGE_MIXEDOUT = 0, 1
 
 
+class Lte(C.Structure):  # LteMixtureInput + the TableInputs of src/M2ulPhyS.cpp:176-255 (flow/lte/table_dim = 1)
+    _fields_ = [("energy_table", Table), ("gas_constant_table", Table), ("sound_speed_table", Table),
+                ("viscosity_table", Table), ("conductivity_table", Table), ("electric_conductivity_table", Table)]
+
+
 class Physics(C.Structure):
     _fields_ = [("eq_system", C.c_int), ("working_fluid", C.c_int), ("dry_air", DryAir), ("mixture", PerfectMixture),
                 ("transport_model", C.c_int), ("constant_transport", ConstantTransport),
                 ("gas_transport", GasTransport), ("chemistry", Chemistry), ("radiation", Radiation),
-                ("sgs", Sgs), ("visc_sponge", ViscSponge)]
+                ("sgs", Sgs), ("visc_sponge", ViscSponge), ("lte", Lte)]
 
 
 class BC(C.Structure):
@@ -207,6 +212,47 @@ def dry_air_physics(eq_system=NS, visc_mult=1.0, bulk_visc_mult=0.0, gamma=1.4, 
 
 
 UNIVERSALGASCONSTANT = 8.3144598  # src/equation_of_state.hpp:55
+
+_LTE_TABLES = None
+
+
+def lte_tables():
+    """The reference's own LTE tables (test/test_lte_mixture.cpp:175-186) as one-dimensional temperature tables:
+    tests/golden/tables/lte_tables.npz, written by make_lte_tables.py next to it."""
+    global _LTE_TABLES
+    if _LTE_TABLES is None:
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "tables", "lte_tables.npz")
+        with np.load(path) as z:
+            _LTE_TABLES = {k: np.array(z[k]) for k in z.files}
+    return _LTE_TABLES
+
+
+def lte_physics(eq_system=NS, density="rho0p005", radiation=False) -> Physics:
+    """[flow] fluid = lte_table, lte/table_dim = 1 (test/inputs/plasma.lte1d.ini:30-34): argon thermodynamics at the
+    density slice `density` of test/inputs/argon_lte_thermo_table.dat and the transport columns of
+    test/inputs/air_simple_transport_table.dat -- the pair of files the reference's unit test combines ("inconsistent ...
+    ok here", test/test_lte_mixture.cpp:178-182).  radiation: the reference's net-emission sample table."""
+    t = lte_tables()
+    th, tr = t["thermo_" + density], t["transport"]
+    ph = Physics()
+    ph.eq_system = eq_system
+    ph.working_fluid = LTE_FLUID
+    ph.dry_air = DryAir(1.4, 287.058, 1.0, 0.0, 1.458e-6, 110.4, 0.71)  # unused by the table gas
+    keep = []
+    ph.lte.energy_table = make_table(th[:, 0], th[:, 1], keep=keep)
+    ph.lte.gas_constant_table = make_table(th[:, 0], th[:, 2], keep=keep)
+    ph.lte.sound_speed_table = make_table(th[:, 0], th[:, 3], keep=keep)
+    ph.lte.viscosity_table = make_table(tr[:, 0], tr[:, 1], keep=keep)
+    ph.lte.conductivity_table = make_table(tr[:, 0], tr[:, 2], keep=keep)
+    ph.lte.electric_conductivity_table = make_table(tr[:, 0], tr[:, 3], keep=keep)
+    if radiation:
+        nec = reference_table("nec_sample_0")
+        ph.radiation.model = NET_EMISSION
+        ph.radiation.nec_table = make_table(nec[:, 0], nec[:, 1], keep=keep)
+    ph._keep = keep
+    return ph
 
 
 def make_table(x, f, x_log=False, f_log=False, keep=None) -> Table:

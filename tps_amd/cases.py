@@ -26,6 +26,8 @@ class Case:
 
     def state(self, seed=12345, amp=0.05, coords=None):
         X = node_coordinates(self.mesh, self.disc.order) if coords is None else coords
+        if self.physics.working_fluid == capi.LTE_FLUID:
+            return lte_state(X, self.physics, seed=seed, amp=amp)
         if self.physics.working_fluid == capi.USER_DEFINED:
             if self.disc.axisymmetric:
                 return plasma_state(X, self.physics, nvel=3, seed=seed, amp=amp, vel0=(1.0, 20.0, 3.0))
@@ -227,6 +229,42 @@ def dry_air_axisym(nr, nz, order, eq_system=capi.NS, wall_type=capi.VISC_ISOTH, 
            capi.make_bc(4, capi.WALL, capi.INV)]
     return Case(name or f"dry_air_axisym_{nr}x{nz}_p{order}", mesh, capi.Disc(order, 0, 0, 1, 0),
                 capi.dry_air_physics(eq_system), bcs, "axisymmetric dry air")
+
+
+def lte_state(X, physics, seed=12345, amp=0.05, rho0=0.255, T0=7000.0, dT=4000.0, vel0=(1.0, 20.0, 3.0)):
+    """Conserved state (5, NDofs) of the table gas in the axisymmetric formulation: smooth density, velocity (r, z, theta)
+    and a temperature field T0 + dT * wave crossing many table intervals; rho e from the energy table (an INPUT state:
+    the kernels and the oracle each invert it themselves)."""
+    wave = _waves(X, seed)
+    t = physics.lte.energy_table
+    Tt = np.ctypeslib.as_array(t.x_data, shape=(t.n_data,))
+    et = np.ctypeslib.as_array(t.f_data, shape=(t.n_data,))
+    rho = rho0 * (1.0 + amp * wave())
+    vref = max(abs(v) for v in vel0) or 1.0
+    vel = [v + amp * vref * wave() for v in vel0]
+    T = T0 + dT * wave()
+    U = np.zeros((5, X.shape[1]))
+    U[0] = rho
+    ke = 0.0
+    for d in range(3):
+        U[1 + d] = rho * vel[d]
+        ke = ke + 0.5 * rho * vel[d] ** 2
+    U[4] = rho * np.interp(T, Tt, et) + ke
+    return U
+
+
+def lte_axisym(nr, nz, order, eq_system=capi.NS, wall_type=capi.VISC_ISOTH, r_in=0.0, r_out=0.05, length=0.25, warp=0.0,
+               radiation=False, density="rho0p255", name=None):
+    """Axisymmetric tube in the table gas (fluid = lte_table, the shape of the reference's test/inputs/plasma.lte1d.ini):
+    patch 1 inlet at z = 0 (density and velocity), 2 pressure outlet, 3 outer wall, 4 axis (inviscid wall)."""
+    attrs = {(0, 0): 4, (0, 1): 3, (1, 0): 1, (1, 1): 2}
+    mesh = meshgen.box_quad(nr, nz, lengths=(r_out - r_in, length), periodic=(False, False), bdr_attr=attrs, warp=warp,
+                            origin=(r_in, 0.0))
+    bcs = [capi.make_bc(1, capi.INLET, capi.SUB_DENS_VEL, [0.26, 0.0, 20.0, 2.0]),
+           capi.make_bc(2, capi.OUTLET, capi.SUB_P, [3.6e5]), capi.make_bc(3, capi.WALL, wall_type, [3000.0]),
+           capi.make_bc(4, capi.WALL, capi.INV)]
+    return Case(name or f"lte_axisym_{nr}x{nz}_p{order}", mesh, capi.Disc(order, 0, 0, 1, 0),
+                capi.lte_physics(eq_system, density, radiation), bcs, "axisymmetric table gas (LTE)")
 
 
 def cylinder_bcs(wall_type=capi.VISC_ISOTH, t_wall=300.0, dim=3):

@@ -260,7 +260,14 @@ struct MeshDev {
   const int2 *face_info;       // [ne*NFACES] {neighbour slot | -(bc+1), orientation code}
   const double *minv;          // non-collocated variant: [ne][NPE][NPE] inverse element mass matrices (symmetric)
   MixLenDev ml;                // MixingLengthTransport (2-D kernels): wall-distance grid function, or distance = NULL
+  VsDev vs;                    // viscous sponge of the 2-D kernels with the heavy interface (enabled = 0: none)
 };
+// what the closures of the 2-D heavy kernels take of the mixing-length model and the viscous sponge at one point
+__device__ inline EddyCtx closure_ctx(const MeshDev &m, bool dist_on, double dist, const double *X) {
+  EddyCtx ec = dist_on ? eddy_at(m.ml, dist) : eddy_off();
+  if (m.vs.enabled) ec.vsw = visc_sponge_weight_2d(m.vs, X);  // uniform over the grid
+  return ec;
+}
 
 // XCD-aware block order.  The hardware hands workgroup b of a launch to XCD b % 8, each XCD with an L2 of its own: with
 // the identity order an element and its face neighbours (e +- 1, e +- nr, ...) sit on eight different L2s, and the trace
@@ -1314,7 +1321,7 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, typename P
     double n[DIM], wq, Xq[DIM];
     face_geometry_rt<C>(d, &sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
     if constexpr (PH::HEAVY && DIM == 2) {  // dq: the wall distance at the points (mixing-length model) or NULL
-      PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, PH::AXISYM ? Xq[0] : -1.0, fn, dq.on ? eddy_at(m.ml, dq.d[rd]) : eddy_off());
+      PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, PH::AXISYM ? Xq[0] : -1.0, fn, closure_ctx(m, dq.on, dq.d[rd], Xq));
     } else if constexpr (PH::HEAVY) {
       PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, PH::AXISYM ? Xq[0] : -1.0, fn);
     } else if constexpr (PH::LES) {  // delta1 of src/face_integrator.cpp:253, transip of :333
@@ -2370,12 +2377,15 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   if (node_on) {
     double F[NEQ * DIM];
     double radius = 1.0;  // axisymmetric: r of the node (x-coordinate), weights the mass and the volume term
-    if constexpr (PH::AXISYM) {
-      double xi[DIM], Xn[DIM];
+    double Xn[DIM] = {};  // position of the node: the radius, the viscous sponge of the 2-D heavy kernels
+    if constexpr (PH::AXISYM || (PH::HEAVY && DIM == 2)) {
+      if (PH::AXISYM || m.vs.enabled) {
+        double xi[DIM];
 #pragma unroll
-      for (int d = 0; d < DIM; d++) xi[d] = tab.x[idx[d]];
-      position<DIM>(&sV[le_n * C::NV * DIM], xi, Xn);
-      radius = Xn[0];
+        for (int d = 0; d < DIM; d++) xi[d] = tab.x[idx[d]];
+        position<DIM>(&sV[le_n * C::NV * DIM], xi, Xn);
+      }
+      if (PH::AXISYM) radius = Xn[0];
     }
     {
       double uc[NEQ];
@@ -2399,7 +2409,7 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
       } else {
         if constexpr (PH::HEAVY && DIM == 2) {  // (+ the mixing-length eddy viscosity when a distance function is set)
           const bool ml_on = m.ml.distance != nullptr;
-          const EddyCtx ec = eddy_at(m.ml, ml_on ? m.ml.distance[static_cast<int64_t>(e0 + le_n) * C::NPE + nd] : 0.0);
+          const EddyCtx ec = closure_ctx(m, true, ml_on ? m.ml.distance[static_cast<int64_t>(e0 + le_n) * C::NPE + nd] : 0.0, Xn);
           if constexpr (PH::TWO_STEP)
             PH::total_flux(prm, uc, st, fc, gr, PH::AXISYM ? radius : -1.0, F, ec);
           else

@@ -140,6 +140,7 @@ struct tpsrhs_operator {
 
   void (*launch)(tpsrhs_operator *, const double *, double *, bool) = nullptr;
   void (*point_eval)(tpsrhs_operator *, int, int64_t, const double *, double *) = nullptr;
+  VsDev vs2d = {};  // viscous sponge of the 2-D heavy kernels (MeshDev::vs); enabled = 0: none
 
   MeshDev mesh_dev() const {
     MeshDev m;
@@ -150,6 +151,7 @@ struct tpsrhs_operator {
     m.face_info = d_face_info;
     m.minv = d_minv;
     m.ml = mixlen;
+    m.vs = vs2d;
     return m;
   }
   ~tpsrhs_operator() {

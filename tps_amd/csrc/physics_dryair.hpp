@@ -57,13 +57,29 @@ struct MixLenDev {
   const double *distance;  // [NDofs] device, owned by the caller
   double lmax, prt, bulk;
 };
-struct EddyCtx {  // what a closure needs of it at one point, by value: the constants and the (interpolated) distance
+// The viscous sponge of Fluxes ([viscosityMultiplierFunction], src/fluxes.cpp:232-246, 669-688) for the 2-D kernels with
+// the heavy interface (axisymmetric dry air / table gas, the mixtures planar and axisymmetric): the plane, by value in
+// MeshDev; the 3-D / planar dry-air kernels carry theirs in DryAirParams (the LES flavour).
+struct VsDev {
+  int enabled;
+  double n[2], p[2], width, ratio;
+};
+__device__ inline double visc_sponge_weight_2d(const VsDev &v, const double *X) {  // viscSpongePlanar
+  const double factor = fmax(v.ratio, 1.0);
+  const double dist = (X[0] - v.p[0]) * v.n[0] + (X[1] - v.p[1]) * v.n[1];
+  double wgt = 0.5 * (tanh(dist / v.width - 2.0) + 1.0);
+  wgt *= (factor - 1.0);
+  wgt += 1.0;
+  return wgt;
+}
+struct EddyCtx {  // what a closure needs of both at one point, by value: the constants, the (interpolated) distance, the sponge weight
   bool on;
   double dist, lmax, prt, bulk;
+  double vsw;  // weight of the viscous sponge at the point (1: none)
 };
-__device__ inline EddyCtx eddy_off() { return EddyCtx{false, 0.0, 0.0, 0.0, 0.0}; }
+__device__ inline EddyCtx eddy_off() { return EddyCtx{false, 0.0, 0.0, 0.0, 0.0, 1.0}; }
 __device__ inline EddyCtx eddy_at(const MixLenDev &ml, double dist) {
-  return EddyCtx{ml.distance != nullptr, dist, ml.lmax, ml.prt, ml.bulk};
+  return EddyCtx{ml.distance != nullptr, dist, ml.lmax, ml.prt, ml.bulk, 1.0};
 }
 // eddy viscosity rho l^2 |S| added to the molecular viscosity / raw bulk viscosity / heavy conductivity of a point
 // (g[eq + d*NEQ]: the primitive gradient; NVEL = 3 with DIM = 2: the axisymmetric strain terms)

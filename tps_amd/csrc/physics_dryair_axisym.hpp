@@ -10,11 +10,77 @@
 #ifndef TPSRHS_PHYSICS_DRYAIR_AXISYM_HPP_
 #define TPSRHS_PHYSICS_DRYAIR_AXISYM_HPP_
 
+#include <type_traits>
+
 #include "physics_dryair.hpp"
+#include "physics_plasma.hpp"  // TableDev, table_eval (LinearTable on the device)
 
 namespace tpsrhs {
 
-struct DryAirAxiPhys {
+// ---- WorkingFluid::LTE_FLUID with one-dimensional tables (flow/lte/table_dim = 1: the variant of the reference's
+// device build, src/M2ulPhyS.cpp:164-255): one species, the state (rho, rho u, rho E); thermodynamics and transport
+// are LinearTables in the temperature.
+//   LteMixture    src/lte_mixture.cpp:76-470          LteTransport  src/lte_transport_properties.cpp:60-140
+// The parameter block extends the dry-air one (boundary conditions, switches); the gas constants of the latter are unused.
+struct LteParams : DryAirParams {
+  TableDev tab_e, tab_R, tab_c, tab_T;    // e(T), R(T), c(T) and the inverse T(e) (the energy table swapped, src/M2ulPhyS.cpp:193-200)
+  TableDev tab_mu, tab_k, tab_sigma;      // mu(T), kappa(T), sigma(T)
+  TableDev tab_nec;                       // net emission coefficient (src/radiation.hpp:54-69), when `radiation`
+  int radiation;
+};
+// LinearTable::eval_x, src/table.cpp:103-113
+__device__ inline double table_eval_x(const TableDev &t, double xe) {
+  const int idx = table_interval(t, xe);
+  const double xt = t.x_log ? flog(xe) : xe;
+  double ft_x = t.b[idx] * (t.x_log ? 1.0 / xe : 1.0);
+  if (t.f_log) ft_x *= fexp(t.a[idx] + t.b[idx] * xt);
+  return ft_x;
+}
+// LteMixture::ComputeTemperatureInternal, src/lte_mixture.cpp:161-218: Newton on e(T) = energy from the inverse table
+// (the reference asserts convergence; a state that does not converge returns NaN here and is caught like any other)
+__device__ inline double lte_temperature(const LteParams &p, double energy) {
+  double T = table_eval(p.tab_T, energy);
+  double res = energy - table_eval(p.tab_e, T);
+  const double res0 = fabs(res);
+  const double atol = 1e-18, rtol = 1e-12, dT_atol = 1e-12, dT_rtol = 1e-8;
+  bool converged = (fabs(res) < atol) || (fabs(res) / fabs(res0) < rtol);
+  int niter = 0;
+  while (!converged && niter < 20) {
+    const double dedT = table_eval_x(p.tab_e, T);
+    const double dT = res / dedT;
+    T += dT;
+    res = energy - table_eval(p.tab_e, T);
+    converged = (fabs(res) < atol) || (fabs(res) / res0 < rtol) || (fabs(dT) < dT_atol) || (fabs(dT) / T < dT_rtol);
+    niter++;
+  }
+  return converged ? T : __builtin_nan("");
+}
+// LteMixture::ComputeTemperatureFromDensityPressure, src/lte_mixture.cpp:236-296: Newton on p = rho R(T) T
+// (the reference goes on with the last iterate when the iteration has not converged)
+__device__ inline double lte_temperature_rho_p(const LteParams &p, double rho, double pres) {
+  double T = pres / (rho * 208.);
+  double R = table_eval(p.tab_R, T);
+  double res = pres - rho * R * T;
+  const double res0 = fabs(res);
+  const double atol = 1e-18, rtol = 1e-12, dT_atol = 1e-12, dT_rtol = 1e-8;
+  bool converged = (fabs(res) < atol) || (fabs(res) / fabs(res0) < rtol);
+  int niter = 0;
+  while (!converged && niter < 20) {
+    const double R_T = table_eval_x(p.tab_R, T);
+    const double dpdT = rho * R + rho * R_T * T;
+    const double dT = res / dpdT;
+    T += dT;
+    R = table_eval(p.tab_R, T);
+    res = pres - rho * R * T;
+    converged = (fabs(res) < atol) || (fabs(res) / res0 < rtol) || (fabs(dT) < dT_atol) || (fabs(dT) / T < dT_rtol);
+    niter++;
+  }
+  return T;
+}
+
+// LTE_ = false: dry air (gamma law, Sutherland); true: the table gas
+template <bool LTE_>
+struct GasAxiPhys {
   static constexpr int DIM = 2, NVEL = 3, NEQ = 5, NACTIVE = 0, ITH = 4;
   static constexpr bool HAS_SOURCE = true, AXISYM = true, HEAVY = true, TWO_TEMPERATURE = false, HAS_NR_BC = false;
   static constexpr bool TWO_STEP = false;
@@ -25,15 +91,17 @@ struct DryAirAxiPhys {
   static constexpr int minw_grad(int, int, int) { return MINW_GRAD; }
   static constexpr bool LES = false;  // sub-grid scale models / viscous sponge: dry air, planar and 3-D
   static constexpr bool HAS_MIXED_OUT = false;  // mixed-out sponge target: dry air, planar / 3-D
-  typedef DryAirParams Params;
-  typedef DryAirParams KArg;
-  typedef const DryAirParams &PRef;
+  static constexpr bool LTE = LTE_;
+  typedef std::conditional_t<LTE_, LteParams, DryAirParams> Params;
+  typedef Params KArg;
+  typedef const Params &PRef;
   typedef const BcDev &BcRef;
   __device__ static inline PRef pref(const KArg &k) { return k; }
   __device__ static inline PRef relaunder(PRef p) { return p; }
   struct State {
     double ir, k, p;
     double vel[NVEL];
+    double T;  // table gas only
   };
   __device__ static inline State make_state(const Params &p, const double *U) {
     State s;
@@ -45,19 +113,58 @@ struct DryAirAxiPhys {
       s.vel[d] = U[1 + d] * s.ir;
     }
     s.k = m2 * s.ir;
-    s.p = (p.gamma - 1.0) * (U[ITH] - 0.5 * s.k);
+    if constexpr (LTE_) {  // LteMixture::ComputePressure, src/lte_mixture.cpp:119-131
+      s.T = lte_temperature(p, (U[ITH] - 0.5 * s.k) / U[0]);
+      s.p = U[0] * table_eval(p.tab_R, s.T) * s.T;
+    } else {
+      s.p = (p.gamma - 1.0) * (U[ITH] - 0.5 * s.k);
+    }
     return s;
+  }
+  // temperature of a state; rho e of a density at a pressure (modifyEnergyForPressure) / at a temperature
+  // (computeStagnantStateWithTemp); speed of sound
+  __device__ static inline double temperature(const Params &p, const State &s) {
+    if constexpr (LTE_)
+      return s.T;
+    else
+      return s.p * p.inv_Rg * s.ir;
+  }
+  __device__ static inline double rho_e_at_pressure(const Params &p, double rho, double pres) {
+    if constexpr (LTE_)
+      return rho * table_eval(p.tab_e, lte_temperature_rho_p(p, rho, pres));  // src/lte_mixture.cpp:448-467
+    else
+      return pres / (p.gamma - 1.0);
+  }
+  __device__ static inline double rho_e_at_temperature(const Params &p, double rho, double T) {
+    if constexpr (LTE_)
+      return rho * table_eval(p.tab_e, T);  // src/lte_mixture.cpp:424-441
+    else
+      return p.Rg / (p.gamma - 1.0) * rho * T;
+  }
+  __device__ static inline double sound(const Params &p, const State &s) {
+    if constexpr (LTE_)
+      return table_eval(p.tab_c, s.T);  // src/lte_mixture.cpp:357-372
+    else
+      return fast_sqrt(p.gamma * s.p * s.ir);
+  }
+  // computeStagnationState: DryAir's (src/equation_of_state.cpp:367-378) rebuilds rho e from the pressure; the table gas
+  // inherits GasMixture's (:100-113), total minus bulk kinetic energy
+  __device__ static inline double stagnation_energy(const Params &p, const double *U, const State &s) {
+    if constexpr (LTE_)
+      return U[ITH] - 0.5 * s.k;
+    else
+      return s.p / (p.gamma - 1.0);
   }
   __device__ static inline void prim(const Params &p, const double *U, double *Up) {
     const State s = make_state(p, U);
     Up[0] = U[0];
 #pragma unroll
     for (int d = 0; d < NVEL; d++) Up[1 + d] = s.vel[d];
-    Up[ITH] = s.p * p.inv_Rg * s.ir;
+    Up[ITH] = temperature(p, s);
   }
   __device__ static inline void clamp_species(double *) {}
   __device__ static inline double max_char_speed(const Params &p, const double *, const State &s) {
-    return fast_sqrt(s.k * s.ir) + fast_sqrt(p.gamma * s.p * s.ir);
+    return fast_sqrt(s.k * s.ir) + sound(p, s);
   }
   __device__ static inline double max_char_speed(const Params &p, const double *U) {
     return max_char_speed(p, U, make_state(p, U));
@@ -65,7 +172,10 @@ struct DryAirAxiPhys {
   __device__ static inline double pressure(const Params &p, const double *U) { return make_state(p, U).p; }
   __device__ static inline double sound_speed(const Params &p, const double *U) {  // src/equation_of_state.cpp:337-348
     const State s = make_state(p, U);
-    return sqrt(p.gamma * s.p * s.ir);
+    if constexpr (LTE_)
+      return sound(p, s);
+    else
+      return sqrt(p.gamma * s.p * s.ir);
   }
   __device__ static inline void conv_flux_n(const double *U, const State &s, const double *n, double *Fn) {
     const double un = s.vel[0] * n[0] + s.vel[1] * n[1];
@@ -96,10 +206,16 @@ struct DryAirAxiPhys {
   }
   // Sutherland viscosity, bulk viscosity and conductivity at the temperature of a conserved state
   __device__ static inline void transport(const Params &p, const State &s, double &visc, double &bulk, double &k) {
-    const double T = s.p * p.inv_Rg * s.ir;
-    visc = p.C1 * p.visc_mult * T * fast_sqrt(T) / (T + p.S0);
-    bulk = p.bulk_mult * visc;
-    k = p.cp_div_pr * visc;
+    if constexpr (LTE_) {  // LteTransport::ComputeFluxMolecularTransport, src/lte_transport_properties.cpp:84-107
+      visc = table_eval(p.tab_mu, s.T);
+      bulk = 0.0;
+      k = table_eval(p.tab_k, s.T);
+    } else {
+      const double T = s.p * p.inv_Rg * s.ir;
+      visc = p.C1 * p.visc_mult * T * fast_sqrt(T) / (T + p.S0);
+      bulk = p.bulk_mult * visc;
+      k = p.cp_div_pr * visc;
+    }
   }
   // Fv(U, g) . n with the axisymmetric stresses; `zero_heat` drops the conduction term (adiabatic wall)
   __device__ static inline void visc_normal_flux(const Params &p, const double *U, const double *g, const double *n,
@@ -108,7 +224,10 @@ struct DryAirAxiPhys {
     double visc, bulkv, k;
     transport(p, s, visc, bulkv, k);
     add_mixing_length<DIM, NVEL, NEQ>(ec, U, g, radius, visc, bulkv, k);
-    const double bulk = bulkv - 2. / 3. * visc;
+    double bulk = bulkv - 2. / 3. * visc;
+    visc *= ec.vsw;  // viscous sponge, src/fluxes.cpp:232-238 (after the -2/3 mu of the bulk viscosity)
+    bulk *= ec.vsw;
+    k *= ec.vsw;
     double divV = g[1 + 0 * NEQ] + g[2 + 1 * NEQ];
     if (radius > 0) divV += s.vel[0] / radius;
     double e = 0.0;
@@ -167,9 +286,9 @@ struct DryAirAxiPhys {
         Ug[1 + d] = bc.data[0] * bc.data[1 + d];
         ke += 0.5 * Ug[1 + d] * Ug[1 + d] / Ug[0];
       }
-      Ug[ITH] = s.p / (p.gamma - 1.0) + ke;
+      Ug[ITH] = rho_e_at_pressure(p, Ug[0], s.p) + ke;
     } else if (bc.category == TPSRHS_OUTLET) {
-      Ug[ITH] = bc.data[0] / (p.gamma - 1.0) + 0.5 * s.k;
+      Ug[ITH] = rho_e_at_pressure(p, U[0], bc.data[0]) + 0.5 * s.k;
     } else if (bc.type == TPSRHS_INV || bc.type == TPSRHS_SLIP) {
       const double nm = sqrt(n[0] * n[0] + n[1] * n[1]);
       const double vn = s.vel[0] * (n[0] / nm) + s.vel[1] * (n[1] / nm);
@@ -179,7 +298,7 @@ struct DryAirAxiPhys {
     } else if (bc.type == TPSRHS_VISC_ADIAB) {  // computeStagnationState, src/equation_of_state.cpp:367-378
 #pragma unroll
       for (int d = 0; d < NVEL; d++) Ug[1 + d] = 0.0;
-      Ug[ITH] = s.p / (p.gamma - 1.0);
+      Ug[ITH] = stagnation_energy(p, U, s);
     } else {  // VISC_ISOTH
       if (p.use_bc_in_grad) {
 #pragma unroll
@@ -187,7 +306,7 @@ struct DryAirAxiPhys {
       } else {
 #pragma unroll
         for (int d = 0; d < NVEL; d++) Ug[1 + d] = 0.0;
-        Ug[ITH] = p.Rg / (p.gamma - 1.0) * U[0] * bc.data[0];
+        Ug[ITH] = rho_e_at_temperature(p, U[0], bc.data[0]);
       }
     }
   }
@@ -218,10 +337,10 @@ struct DryAirAxiPhys {
 #pragma unroll
       for (int d = 0; d < NVEL; d++) Uw[1 + d] = 0.0;
       if (bc.type == TPSRHS_VISC_ADIAB) {
-        Uw[ITH] = s.p / (p.gamma - 1.0);
+        Uw[ITH] = stagnation_energy(p, U, s);
         adiabatic = true;
       } else {
-        Uw[ITH] = p.Rg / (p.gamma - 1.0) * U[0] * bc.data[0];
+        Uw[ITH] = rho_e_at_temperature(p, U[0], bc.data[0]);
       }
     }
     visc_normal_flux(p, Uw, g, n, radius, adiabatic, f, wec);
@@ -240,18 +359,31 @@ struct DryAirAxiPhys {
       UpB[ITH] = bc.data[0];
     }
   }
-  __device__ static inline void source(const Params &, const double *, const double *, const double *, double *src) {
+  // SourceTerm::updateTerms (src/source_term.cpp:62-256) for one species: only the radiation sink is left
+  __device__ static inline void source(const Params &p, const double *, const double *Up, const double *, double *src) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) src[eq] = 0.0;
+    if constexpr (LTE_) {
+      if (p.radiation == TPSRHS_NET_EMISSION) src[ITH] += -4.0 * kPi * table_eval(p.tab_nec, Up[ITH]);  // src/radiation.hpp:68
+    }
   }
   __device__ static inline void axisym_source(const Params &p, const double *U, const double *Up, const double *g,
                                               double radius, double *src) {
     const double rho = Up[0], ur = Up[1], ut = Up[3];
-    const double pres = p.Rg * Up[0] * Up[ITH];  // DryAir::ComputePressureFromPrimitives
+    double pres;
+    if constexpr (LTE_)
+      pres = Up[0] * table_eval(p.tab_R, Up[ITH]) * Up[ITH];  // LteMixture::ComputePressureFromPrimitives, src/lte_mixture.cpp:138-147
+    else
+      pres = p.Rg * Up[0] * Up[ITH];  // DryAir::ComputePressureFromPrimitives
     double tau_tt = 0.0, tau_tr = 0.0;
     if (p.eq_system != TPSRHS_EULER) {
       double visc, bulkv, k;
-      transport(p, make_state(p, U), visc, bulkv, k);  // GetViscosities, src/transport_properties.cpp:268-276
+      if constexpr (LTE_) {  // LteTransport::GetViscosities, src/lte_transport_properties.cpp:128-140: at the primitive T
+        visc = table_eval(p.tab_mu, Up[ITH]);
+        bulkv = 0.0;
+      } else {
+        transport(p, make_state(p, U), visc, bulkv, k);  // GetViscosities, src/transport_properties.cpp:268-276
+      }
       const double bulk = bulkv - 2. / 3. * visc;
       double divV = g[1 + 0 * NEQ] + g[2 + 1 * NEQ];
       if (radius > 0) divV += ur / radius;
@@ -265,6 +397,8 @@ struct DryAirAxiPhys {
     src[3] += (-rho * ur * ut + tau_tr) / radius;
   }
 };
+typedef GasAxiPhys<false> DryAirAxiPhys;
+typedef GasAxiPhys<true> LteAxiPhys;
 
 }  // namespace tpsrhs
 #endif

@@ -865,8 +865,17 @@ struct PlasmaPhys {
     }
     double h[NSP];
     enthalpies(p, s, h);
-    const double bulk = t.bulk - 2. / 3. * t.visc;
+    double bulk = t.bulk - 2. / 3. * t.visc;
     double k = t.k;
+    if constexpr (DIM == 2) {  // viscous sponge, src/fluxes.cpp:232-246: mu, mu_b - 2/3 mu, k_h and the ACTIVE species' velocities
+      t.visc *= ec.vsw;
+      bulk *= ec.vsw;
+      k *= ec.vsw;
+#pragma unroll
+      for (int d = 0; d < DIM; d++)
+#pragma unroll
+        for (int sp = 0; sp < NACTIVE; sp++) t.V[sp + d * NSP] *= ec.vsw;
+    }
     if (TWOT) {
 #pragma unroll
       for (int d = 0; d < DIM; d++) {
@@ -966,9 +975,15 @@ struct PlasmaPhys {
       double a = 0.0;
 #pragma unroll
       for (int d = 0; d < DIM; d++) a += t.V[sp + d * NSP] * n[d];
+      if (DIM == 2 && sp < NACTIVE) a *= ec.vsw;  // viscous sponge (src/fluxes.cpp:395-408), before the wall prescriptions
       Vn[sp] = w.species ? w.Vn[sp] * w.nm : a;
     }
-    const double bulk = t.bulk - 2. / 3. * t.visc;
+    double bulk = t.bulk - 2. / 3. * t.visc;
+    if constexpr (DIM == 2) {
+      t.visc *= ec.vsw;
+      bulk *= ec.vsw;
+      t.k *= ec.vsw;
+    }
     double divV = 0.0;
 #pragma unroll
     for (int i = 0; i < DIM; i++) divV += g[(1 + i) + i * NEQ];

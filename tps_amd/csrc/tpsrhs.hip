@@ -5,6 +5,7 @@
 // CPU fallback: without a HIP device tpsrhs_create returns TPSRHS_ERR_NO_DEVICE.
 #include "operator.hpp"
 #include "physics_dryair.hpp"
+#include "physics_dryair_axisym.hpp"
 #include "physics_plasma.hpp"
 
 #include <cmath>
@@ -22,6 +23,7 @@ DECL(pick_plasma_2d_n3a_hi); DECL(pick_plasma_2d_n3_hi); DECL(pick_plasma_2d_n4a
 DECL(pick_plasma_axi_n3a_hi); DECL(pick_plasma_axi_n3_hi); DECL(pick_plasma_axi_n4a_hi); DECL(pick_plasma_axi_n4_hi); DECL(pick_plasma_axi_n5a_hi); DECL(pick_plasma_axi_n5_hi); DECL(pick_plasma_axi_n6a_hi); DECL(pick_plasma_axi_n6_hi); DECL(pick_plasma_axi_n7a_hi); DECL(pick_plasma_axi_n7_hi); DECL(pick_plasma_axi_n8a_hi); DECL(pick_plasma_axi_n8_hi);
 #undef DECL
 void pick_dryair_axisym(tpsrhs_operator *op);
+void pick_lte_axisym(tpsrhs_operator *op);
 void pick_dryair_les(tpsrhs_operator *op);
 
 static thread_local std::string g_last_error;
@@ -361,8 +363,11 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   if (op->nc && disc->axisymmetric) throw Unsupported("the Gauss-Lobatto pair is built for the planar 2-D and the 3-D formulation");
   const bool plasma = phys->working_fluid == TPSRHS_USER_DEFINED;
   if (disc->axisymmetric && mesh->dim != 2) throw std::invalid_argument("the axisymmetric formulation needs a 2-D mesh");
-  if (phys->working_fluid != TPSRHS_DRY_AIR && !plasma) throw Unsupported("WorkingFluid::LTE_FLUID is out of scope");
-  if (disc->use_roe && (mesh->dim != 2 || disc->axisymmetric || plasma))
+  const bool lte = phys->working_fluid == TPSRHS_LTE_FLUID;
+  if (phys->working_fluid != TPSRHS_DRY_AIR && !plasma && !lte) throw std::invalid_argument("unknown working_fluid");
+  if (lte && (!disc->axisymmetric || op->nc))
+    throw Unsupported("WorkingFluid::LTE_FLUID (one-dimensional tables): built for the axisymmetric formulation, Gauss-Legendre pair");
+  if (disc->use_roe && (mesh->dim != 2 || disc->axisymmetric || plasma || lte))
     throw Unsupported("flow/useRoe: Eval_Roe of the reference is 2-D, single-species, not axisymmetric "
                       "(src/riemann_solver.cpp:117-206)");
   if (phys->eq_system != TPSRHS_EULER && phys->eq_system != TPSRHS_NS) throw Unsupported("NS_PASSIVE is out of scope");
@@ -370,13 +375,13 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   for (int i = 0; i < num_bcs; i++) {
     const tpsrhs_bc &b = bcs[i];
     const bool nr = is_non_reflecting(b.category, b.type);
-    if (nr && (plasma || disc->axisymmetric))
+    if (nr && (plasma || lte || disc->axisymmetric))
       throw Unsupported("non-reflecting inlet/outlet types: perfect gas (dry air), not axisymmetric -- the reference's "
                         "characteristic algebra (src/outletBC.cpp:573-1027)");
     if (nr && (b.type == TPSRHS_SUB_MF_NR || b.type == TPSRHS_SUB_MF_NR_PW) && !(b.data[7] > 0.0))
       throw std::invalid_argument("mass-flow outlet: data[7] must hold the total patch area");
     const bool face_inlet = is_face_inlet(b.category, b.type);
-    if (face_inlet && (op->dim != 3 || disc->axisymmetric))
+    if (face_inlet && (mesh->dim != 3 || disc->axisymmetric))
       throw Unsupported("face-relative inlets (subsonicFaceBasedX/Y/Z): 3-D (the reference's face frame has three components)");
     const bool ok = nr || face_inlet || (b.category == TPSRHS_INLET && b.type == TPSRHS_SUB_DENS_VEL) ||
                     (b.category == TPSRHS_OUTLET && b.type == TPSRHS_SUB_P) ||
@@ -444,8 +449,26 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   const int npe = (op->dim == 3) ? n1 * n1 * n1 : n1 * n1;
   op->ndofs = static_cast<int64_t>(op->ne) * npe;
 
-  if (plasma && (phys->sgs.model_type != TPSRHS_SGS_NONE || phys->visc_sponge.enabled))
-    throw Unsupported("sub-grid scale model / viscous sponge: built for dry air (planar 2-D and 3-D)");
+  // Viscous sponge of the 2-D kernels with the heavy interface (the mixtures planar and axisymmetric, axisymmetric dry air
+  // and table gas): the plane travels in MeshDev, the closures scale their coefficients (src/fluxes.cpp:232-246)
+  const bool heavy2d = op->dim == 2 && (plasma || disc->axisymmetric);
+  if ((plasma || lte || disc->axisymmetric) && phys->sgs.model_type != TPSRHS_SGS_NONE)
+    throw Unsupported("sub-grid scale models: built for dry air in 3-D");
+  if (phys->visc_sponge.enabled && (plasma || lte || disc->axisymmetric)) {
+    if (!heavy2d || op->nc)
+      throw Unsupported("viscous sponge for mixtures: built for the planar 2-D and the axisymmetric formulation, Gauss-Legendre pair");
+    const tpsrhs_visc_sponge &v = phys->visc_sponge;
+    if (!(v.width > 0.0)) throw std::invalid_argument("visc_sponge.width must be positive");
+    const double nmag = std::sqrt(v.normal[0] * v.normal[0] + v.normal[1] * v.normal[1]);  // normalised: src/fluxes.cpp:77-90
+    if (!(nmag > 0.0)) throw std::invalid_argument("visc_sponge.normal is zero");
+    op->vs2d.enabled = 1;
+    for (int k = 0; k < 2; k++) {
+      op->vs2d.n[k] = v.normal[k] / nmag;
+      op->vs2d.p[k] = v.point[k];
+    }
+    op->vs2d.width = v.width;
+    op->vs2d.ratio = v.ratio;
+  }
   if (plasma) {
     const int nsp = phys->mixture.num_species;
     const bool ambi = phys->mixture.ambipolar != 0, two_t = phys->mixture.two_temperature != 0;
@@ -479,8 +502,30 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     else
       table[geo][fam](op, two_t, tr);
   } else {
-    DryAirParams &d = *new (op->params) DryAirParams;
-    std::memset(&d, 0, sizeof(d));
+    // (the table gas extends the dry-air block: boundary conditions and switches are shared)
+    static_assert(sizeof(LteParams) <= sizeof(op->params), "parameter block");
+    LteParams *lp = lte ? new (op->params) LteParams : nullptr;
+    if (lp) std::memset(static_cast<void *>(lp), 0, sizeof(LteParams));
+    DryAirParams &d = lp ? *static_cast<DryAirParams *>(lp) : *new (op->params) DryAirParams;
+    if (!lp) std::memset(&d, 0, sizeof(d));
+    if (lp) {
+      const tpsrhs_lte &in = phys->lte;
+      lp->tab_e = upload_table(op, in.energy_table);
+      lp->tab_R = upload_table(op, in.gas_constant_table);
+      lp->tab_c = upload_table(op, in.sound_speed_table);
+      for (int k = 1; k < in.energy_table.n_data; k++)
+        if (!(in.energy_table.f_data[k] > in.energy_table.f_data[k - 1]))
+          throw std::invalid_argument("lte.energy_table: e(T) must increase (the inverse table T(e) is its transpose)");
+      tpsrhs_table rev = in.energy_table;  // "Construct e -> T table from T -> e", src/M2ulPhyS.cpp:193-200
+      rev.x_data = in.energy_table.f_data;
+      rev.f_data = in.energy_table.x_data;
+      lp->tab_T = upload_table(op, rev);
+      lp->tab_mu = upload_table(op, in.viscosity_table);
+      lp->tab_k = upload_table(op, in.conductivity_table);
+      lp->tab_sigma = upload_table(op, in.electric_conductivity_table);
+      lp->radiation = phys->radiation.model;
+      if (lp->radiation == TPSRHS_NET_EMISSION) lp->tab_nec = upload_table(op, phys->radiation.nec_table);
+    }
     d.gamma = phys->dry_air.specific_heat_ratio;
     d.Rg = phys->dry_air.gas_constant;
     d.inv_Rg = 1.0 / d.Rg;
@@ -502,7 +547,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     bool any_nr = false;
     for (int i = 0; i < num_bcs; i++) any_nr = any_nr || is_non_reflecting(bcs[i].category, bcs[i].type);
     // Fluxes: sub-grid scale model and viscous sponge (src/fluxes.cpp:223-246) -> the LES flavour of the kernels
-    const bool les = phys->sgs.model_type != TPSRHS_SGS_NONE || phys->visc_sponge.enabled;
+    const bool les = !heavy2d && (phys->sgs.model_type != TPSRHS_SGS_NONE || phys->visc_sponge.enabled);
     if (les) {
       if (phys->sgs.model_type < 0 || phys->sgs.model_type > TPSRHS_SGS_SIGMA)
         throw std::invalid_argument("unknown sgs.model_type");
@@ -538,7 +583,9 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
       op->d_extra.push_back(dd);
       d.elem_delta = dd;
       pick_dryair_les(op);
-    } else if (disc->axisymmetric)
+    } else if (lte)
+      pick_lte_axisym(op);
+    else if (disc->axisymmetric)
       pick_dryair_axisym(op);
     else if (op->dim == 3)
       any_nr ? pick_order<3, DryAirPhys<3, true>>(op) : pick_order<3, DryAirPhys<3>>(op);
