@@ -18,6 +18,8 @@ configs[1]/[2] per GPU.  Workloads:
                   2671-2672): volume operators through the quadrature points, dense 32 KB inverse mass per hex
   torch6          the mixture of the reference's torch input (plasma.ini): six species, two temperatures, not
                   ambipolar, 11 equations, on the axisymmetric 400x500 mesh of cfg5
+  lte_torch       the table gas of the reference's LTE torch inputs (plasma.lte1d.ini: fluid = lte_table, one-dimensional
+                  tables, radiation sink, viscosity-multiplier function), 5 equations, on the same mesh
 At N = 1 the JSON line also carries the workloads that were not selected, under `other_workloads`.
   cfg4            configs[3]: perfect-gas Navier-Stokes, p=3, on the 56x224x32 = 401 408-hex cylinder, cut into
                   N spanwise slabs (STRONG scaling: the total work is fixed)
@@ -104,6 +106,20 @@ def workload(name):
                 "reference's rate tables, its net-emission table",
                 lambda order: cases.argon_axisym(40, 50, order, physics=capi.argon_six_species_physics(
                     capi.NS, capi.CONSTANT, True, "tabulated", radiation=True)))
+    if name == "lte_torch":
+        def lte():
+            ph = capi.lte_physics(capi.NS, "rho0p255", radiation=True)
+            vs = ph.visc_sponge  # [viscosityMultiplierFunction] of test/inputs/plasma.lte1d.ini:52-58 on this tube
+            vs.enabled, vs.width, vs.ratio = 1, 0.02, 20.0
+            vs.normal[1], vs.point[1] = 1.0, 0.2
+            return ph
+        return (3, lte(), lambda p: cases.lte_axisym(2, 2, 3).bcs,
+                lambda X, p: cases.lte_state(X, p, seed=12345, amp=0.05),
+                "AXISYMMETRIC (r, z) 400x500 quads, the table gas of the reference's LTE torch inputs (fluid = lte_table, "
+                "one-dimensional tables: argon thermodynamics of test/inputs/argon_lte_thermo_table.dat at 0.255 kg/m^3, "
+                "transport of air_simple_transport_table.dat), net-emission radiation sink, viscosity-multiplier function, "
+                "inlet / pressure outlet / isothermal wall / axis",
+                lambda order: cases.lte_axisym(40, 50, order, radiation=True))
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -170,7 +186,7 @@ def main():
     ap.add_argument("--ntheta", type=int, default=112)
     ap.add_argument("--nz", type=int, default=16)
     ap.add_argument("--order", type=int, default=0, help="override the workload's polynomial order")
-    ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3", "cfg4", "cfg5", "torch6", "gll_dry", "gll_argon"])
+    ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3", "cfg4", "cfg5", "torch6", "gll_dry", "gll_argon", "lte_torch"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the multi-rank path on a one-GPU box (traces staged via host)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses device 0")
@@ -217,7 +233,7 @@ def main():
         """-> the JSON fields of one workload (rank 0; None elsewhere)"""
         order, physics, make_bcs, make_state, description, sample_case = workload(wname)
         order = args.order or order
-        axisym = wname in ("cfg5", "torch6")
+        axisym = wname in ("cfg5", "torch6", "lte_torch")
         strong = wname == "cfg4"
         if axisym:  # (r, z) tube 0.05 x 0.25 per rank, 400 x 500 quads; axial slabs at N > 1 (weak scaling)
             mesh = meshgen.annulus_quad_slab(400, 500, rank, world, r_in=0.0, r_out=0.05, length_local=0.25)
@@ -365,7 +381,7 @@ def main():
     r = run(args.workload, args.steps, args.warmup)
     others = {}
     if world == 1 and not args.no_other_workloads:
-        for wname in ("argon_p3", "cfg2", "cfg3", "cfg5", "torch6", "gll_dry"):
+        for wname in ("argon_p3", "cfg2", "cfg3", "cfg5", "torch6", "gll_dry", "lte_torch"):
             if wname != args.workload:
                 # the same K timed steps as the headline and at least 10 warm-ups: comparable round to round and
                 # with the profiles/ of the same command

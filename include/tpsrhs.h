@@ -432,6 +432,7 @@ int tpsrhs_set_dt(tpsrhs_handle h, double dt);
  * tpsrhs_physics / tpsrhs_disc; the ones below are configured here, after tpsrhs_create. */
 #define TPSRHS_MAXHEATSOURCES 4
 #define TPSRHS_MAXSPONGEZONES 2
+#define TPSRHS_MAXPASSIVESCALARS 4
 
 typedef struct tpsrhs_heat_source { /* heatSourceData, type "cylinder" (src/dataStructures.hpp:528-535) */
   double value;                      /* added to y[(dim+1)*NDofs + node] (src/forcing_terms.cpp:923-936) */
@@ -458,6 +459,17 @@ typedef struct tpsrhs_sponge_zone { /* SpongeZoneData (src/dataStructures.hpp:26
   double target_U[TPSRHS_MAXEQUATIONS];
 } tpsrhs_sponge_zone;
 
+/* PassiveScalar ([passiveScalars], src/M2ulPhyS.cpp:2855-2875; src/forcing_terms.cpp:768-870): at the nodes closer than
+ * `radius` to `coords` (the first `dim` entries), y[(num_equation-1) NDofs + node] -= |u| (Up_last - rho value) / radius
+ * with |u| over the `dim` velocity components and Up_last the LAST primitive variable -- whatever the equation system
+ * (the reference appends the term whenever such an entry exists: test/inputs/argonMinimal.ini:118-124 relaxes the last
+ * species of the ternary plasma with it). */
+typedef struct tpsrhs_passive_scalar { /* passiveScalarData (src/dataStructures.hpp:519-526) */
+  double coords[3];
+  double radius;
+  double value;
+} tpsrhs_passive_scalar;
+
 typedef struct tpsrhs_forcing {
   int has_pressure_gradient;         /* config.thereIsForcing(): ConstantPressureGradient, forcing_terms.cpp:115-171 */
   double pressure_gradient[3];
@@ -465,9 +477,11 @@ typedef struct tpsrhs_forcing {
   tpsrhs_heat_source heat_sources[TPSRHS_MAXHEATSOURCES];
   int num_sponge_zones;              /* SpongeZone */
   tpsrhs_sponge_zone sponge_zones[TPSRHS_MAXSPONGEZONES];
+  int num_passive_scalars;           /* PassiveScalar */
+  tpsrhs_passive_scalar passive_scalars[TPSRHS_MAXPASSIVESCALARS];
 } tpsrhs_forcing;
 
-/* Replaces the forcing.Append(...) calls of the RHSoperator constructor for ConstantPressureGradient,
+/* Replaces the forcing.Append(...) calls of the RHSoperator constructor for ConstantPressureGradient, PassiveScalar,
  * SpongeZone and HeatSource.  NULL removes them. */
 int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *forcing);
 

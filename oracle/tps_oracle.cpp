@@ -48,6 +48,7 @@ struct Operator {
   std::vector<std::vector<double>> spongeRadial;       // unit radial vector per node (annulus)
   std::vector<std::vector<int64_t>> spongePlaneNodes;  // nodesInMixedOutPlane (:545-606)
   std::vector<std::vector<int64_t>> heatNodes;         // nodeList_ of each HeatSource (:890-917)
+  std::vector<std::vector<int64_t>> scalarNodes;       // psData_[i]->nodes of PassiveScalar (:795-818)
   std::vector<double> joule;                           // joule_heating_ grid function (empty: none)
   std::vector<double> distance;                        // distance_ grid function (empty: none)
   std::unique_ptr<tpsoracle::MixingLengthTransport> mixlen;  // wraps `transport` when useMixingLength (M2ulPhyS.cpp:265-277)
@@ -579,6 +580,7 @@ struct Operator {
     // order of the forcing array: ConstantPressureGradient, SpongeZone(s), HeatSource(s), SourceTerm,
     // AxisymmetricSource, JouleHeating (src/rhs_operator.cpp:101-166)
     if (has_forcing && forcing_in.has_pressure_gradient) constantPressureGradient(y);
+    if (has_forcing) passiveScalar(y);
     if (has_forcing)
       for (size_t zn = 0; zn < spongeSigma.size(); zn++) spongeZone(static_cast<int>(zn), y);
     if (has_forcing)
@@ -606,10 +608,22 @@ struct Operator {
     spongeRadial.clear();
     spongePlaneNodes.clear();
     heatNodes.clear();
+    scalarNodes.clear();
     has_forcing = f != nullptr;
     if (!f) return;
     forcing_in = *f;
     const int64_t N = ndofs;
+    for (int i = 0; i < f->num_passive_scalars; i++) {  // PassiveScalar constructor, src/forcing_terms.cpp:795-818
+      const tpsrhs_passive_scalar &ps = f->passive_scalars[i];
+      std::vector<int64_t> list;
+      for (int64_t n = 0; n < N; n++) {
+        double dist = 0.;
+        for (int d = 0; d < dim; d++) dist += (coords[n + d * N] - ps.coords[d]) * (coords[n + d * N] - ps.coords[d]);
+        dist = std::sqrt(dist);
+        if (dist < ps.radius) list.push_back(n);
+      }
+      scalarNodes.push_back(list);
+    }
     for (int zn = 0; zn < f->num_sponge_zones; zn++) {
       tpsrhs_sponge_zone &sz = forcing_in.sponge_zones[zn];
       double mod = 0.;
@@ -680,6 +694,20 @@ struct Operator {
     if (phys.radiation.model != TPSRHS_NET_EMISSION) return;
     const int64_t N = ndofs;
     for (int64_t n = 0; n < N; n++) y[n + (1 + nvel) * N] += -4.0 * PI_ * lteNec.eval(Up[n + (1 + nvel) * N]);
+  }
+  // PassiveScalar: node lists of the constructor (src/forcing_terms.cpp:795-818), updateTerms (:826-848)
+  void passiveScalar(double *y) {
+    const int64_t N = ndofs;
+    for (int i = 0; i < forcing_in.num_passive_scalars; i++) {
+      const tpsrhs_passive_scalar &ps = forcing_in.passive_scalars[i];
+      const double Z = ps.value;
+      for (int64_t node : scalarNodes[i]) {
+        double vel = 0.;
+        for (int d = 0; d < dim; d++) vel += Up[node + (1 + d) * N] * Up[node + (1 + d) * N];
+        vel = std::sqrt(vel);
+        y[node + (neq - 1) * N] -= vel * (Up[node + (neq - 1) * N] - Up[node] * Z) / ps.radius;
+      }
+    }
   }
   void constantPressureGradient(double *y) {
     const int64_t N = ndofs;

@@ -116,6 +116,28 @@ def test_dry_air_axisymmetric_sponge_heat_joule():
     assert changed[3] > 0.0 and changed[4] > 0.0
 
 
+@pytest.mark.parametrize("fluid", ["ternary", "dry_air_2d", "two_temperature"])
+def test_passive_scalar(fluid):
+    """[passiveScalars] of test/inputs/argonMinimal.ini:118-124: xyz = 0, radius 0.1, value 1 on the ternary plasma -- the
+    term relaxes the LAST equation (there the ion density; with two temperatures the electron energy; for dry air the
+    total energy), src/forcing_terms.cpp:826-848"""
+    if fluid == "dry_air_2d":
+        mesh = meshgen.box_quad(6, 5, lengths=(1.0, 0.7), warp=0.1)
+        c = cases.Case("ps2d", mesh, capi.Disc(3, 0, 0, 0, 0), capi.dry_air_physics(capi.NS, visc_mult=300.0), [])
+        from tps_amd.rhs_operator import node_coordinates
+
+        U = cases.dry_air_state(node_coordinates(mesh, 3), seed=9)
+        scalars = [dict(xyz=(0.45, 0.3, 0.0), radius=0.28, value=200.0), dict(xyz=(0.9, 0.6, 0.0), radius=0.15, value=-50.0)]
+        tol = RHS_RTOL
+    else:
+        c = cases.argon_cyl3d(4, 12, 3, 2, fluid == "two_temperature", capi.CONSTANT, "arrhenius", capi.VISC_ISOTH)
+        U = c.state(seed=31, amp=0.01)
+        scalars = [dict(xyz=(0.0, 0.0, 0.0), radius=2.5, value=1.0)]  # around the cylinder (inner radius 0.5)
+        tol = 5 * RHS_RTOL
+    changed, _ = _run(c, U, capi.make_forcing(passive_scalars=scalars), None, tol)
+    assert changed[-1] > 0.0 and np.all(changed[:-1] == 0.0)
+
+
 def test_forcing_argument_checks():
     from tps_amd.rhs_operator import RHSoperator, TpsRhsError
 

@@ -90,3 +90,21 @@ def test_joule_heating_only_positive_entries():
     assert np.abs(d[:4]).max() == 0.0
     o.set_joule_heating(None)
     assert np.abs(o.mult(U) - y0).max() == 0.0
+
+
+def test_passive_scalar_closed_form():
+    # PassiveScalar: nodes within `radius` of the point (forcing_terms.cpp:795-818); the LAST equation gets
+    # -|u| (Up_last - rho Z) / radius (:826-848) -- for dry air the last primitive is the temperature
+    mesh, o, X = _box()
+    U = cases.dry_air_state(X, seed=4)
+    y0 = o.mult(U)
+    xyz, radius, Z = (0.4, 0.5, 0.6), 0.35, 250.0
+    o.set_forcing(capi.make_forcing(passive_scalars=[dict(xyz=xyz, radius=radius, value=Z)]))
+    d = o.mult(U) - y0
+    inside = np.linalg.norm(X - np.array(xyz)[:, None], axis=0) < radius
+    assert 0 < inside.sum() < X.shape[1]
+    vel = np.sqrt((U[1:4] ** 2).sum(axis=0)) / U[0]
+    T = (GAMMA - 1) * (U[4] - 0.5 * (U[1:4] ** 2).sum(axis=0) / U[0]) / (287.058 * U[0])
+    want = np.where(inside, -vel * (T - U[0] * Z) / radius, 0.0)
+    np.testing.assert_allclose(d[4], want, atol=1e-9 * np.abs(want).max())
+    assert np.abs(d[:4]).max() == 0.0

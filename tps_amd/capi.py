@@ -148,7 +148,7 @@ class Runtime(C.Structure):
                 ("reduce", REDUCE_FN), ("reduce_ctx", C.c_void_p)]
 
 
-MAXHEATSOURCES, MAXSPONGEZONES = 4, 2
+MAXHEATSOURCES, MAXSPONGEZONES, MAXPASSIVESCALARS = 4, 2, 4
 SPONGE_PLANAR, SPONGE_ANNULUS = 0, 1
 
 
@@ -163,17 +163,29 @@ class SpongeZone(C.Structure):  # SpongeZoneData (src/dataStructures.hpp:260-287
                 ("target_U", C.c_double * MAXEQUATIONS)]
 
 
+class PassiveScalarData(C.Structure):  # passiveScalarData, [passiveScalar*] (src/M2ulPhyS.cpp:2855-2875)
+    _fields_ = [("coords", C.c_double * 3), ("radius", C.c_double), ("value", C.c_double)]
+
+
 class Forcing(C.Structure):
     _fields_ = [("has_pressure_gradient", C.c_int), ("pressure_gradient", C.c_double * 3),
                 ("num_heat_sources", C.c_int), ("heat_sources", HeatSource * MAXHEATSOURCES),
-                ("num_sponge_zones", C.c_int), ("sponge_zones", SpongeZone * MAXSPONGEZONES)]
+                ("num_sponge_zones", C.c_int), ("sponge_zones", SpongeZone * MAXSPONGEZONES),
+                ("num_passive_scalars", C.c_int), ("passive_scalars", PassiveScalarData * MAXPASSIVESCALARS)]
 
 
-def make_forcing(pressure_gradient=None, heat_sources=(), sponge_zones=()) -> Forcing:
+def make_forcing(pressure_gradient=None, heat_sources=(), sponge_zones=(), passive_scalars=()) -> Forcing:
     """heat_sources: dicts(value, radius, point1, point2); sponge_zones: dicts(type, normal, point0, point_init,
     target_U[, r1, r2, mult_factor]) -- the [heatSource*] / [spongezone*] input sections
-    (src/M2ulPhyS.cpp:2752-2785, 3680-3755) with the target already in conserved variables."""
+    (src/M2ulPhyS.cpp:2752-2785, 3680-3755) with the target already in conserved variables; passive_scalars:
+    dicts(xyz, radius, value), the [passiveScalar*] sections."""
     f = Forcing()
+    f.num_passive_scalars = len(passive_scalars)
+    for i, ps in enumerate(passive_scalars):
+        for d in range(3):
+            f.passive_scalars[i].coords[d] = float(ps["xyz"][d]) if d < len(ps["xyz"]) else 0.0
+        f.passive_scalars[i].radius = float(ps["radius"])
+        f.passive_scalars[i].value = float(ps["value"])
     if pressure_gradient is not None:
         f.has_pressure_gradient = 1
         for d, v in enumerate(pressure_gradient):

@@ -229,6 +229,10 @@ struct ForcingDev {
     double *msum;            // [NEQ + 1] device: sum of F_c . n per equation, number of nodes
   } sponge[TPSRHS_MAXSPONGEZONES];
   const double *joule;  // [ndofs] or NULL
+  int nps, pad2;
+  struct Scalar {
+    double x0[3], radius, value;
+  } ps[TPSRHS_MAXPASSIVESCALARS];
 };
 
 // RK4 stage combination fused into the epilogue of k_flux inside tpsrhs_rk4_step / tpsrhs_advance (src/M2ulPhyS.cpp:
@@ -1790,6 +1794,24 @@ __device__ inline void apply_forcing(const ForcingDev &f, typename PH::PRef prm,
       gpv -= st.p * gr[(1 + d) + d * NEQ];
     }
     src[1 + NVEL] += gpv;
+  }
+  // PassiveScalar::updateTerms, src/forcing_terms.cpp:826-848 (node list of the constructor, :795-818): the last equation
+  if (f.nps > 0) {
+    double up[NEQ];
+    PH::prim(prm, u, up);
+    for (int i = 0; i < f.nps; i++) {
+      const ForcingDev::Scalar &ps = f.ps[i];
+      double dist = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) dist += (X[d] - ps.x0[d]) * (X[d] - ps.x0[d]);
+      if (sqrt(dist) < ps.radius) {
+        double vel = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) vel += up[1 + d] * up[1 + d];
+        vel = sqrt(vel);
+        src[NEQ - 1] -= vel * (up[NEQ - 1] - up[0] * ps.value) / ps.radius;
+      }
+    }
   }
   // SpongeZone::addSpongeZoneForcing, src/forcing_terms.cpp:637-711; sigma of the constructor, :553-606
   for (int z = 0; z < f.nsponge; z++) {

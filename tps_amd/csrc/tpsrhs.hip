@@ -925,7 +925,7 @@ int tpsrhs_set_dt(tpsrhs_handle h, double dt) {
 namespace {
 void upload_forcing(tpsrhs_operator *h) {
   const ForcingDev &f = h->forcing;
-  h->forcing_active = f.has_pg || f.nheat > 0 || f.nsponge > 0 || f.joule != nullptr;
+  h->forcing_active = f.has_pg || f.nheat > 0 || f.nsponge > 0 || f.nps > 0 || f.joule != nullptr;
   if (!h->forcing_active) return;
   HIP_CHECK(hipSetDevice(h->device));
   if (!h->d_forcing) h->d_forcing = dev_alloc<ForcingDev>(1);
@@ -954,6 +954,16 @@ int tpsrhs_set_forcing(tpsrhs_handle h, const tpsrhs_forcing *in) {
       if (in->num_heat_sources < 0 || in->num_heat_sources > TPSRHS_MAXHEATSOURCES || in->num_sponge_zones < 0 ||
           in->num_sponge_zones > TPSRHS_MAXSPONGEZONES)
         throw std::invalid_argument("tpsrhs_set_forcing: heat source / sponge zone count out of range");
+      if (in->num_passive_scalars < 0 || in->num_passive_scalars > TPSRHS_MAXPASSIVESCALARS)
+        throw std::invalid_argument("tpsrhs_set_forcing: passive scalar count out of range");
+      f.nps = in->num_passive_scalars;
+      for (int i = 0; i < f.nps; i++) {  // PassiveScalar constructor, src/forcing_terms.cpp:778-790
+        const tpsrhs_passive_scalar &s = in->passive_scalars[i];
+        if (!(s.radius > 0.0)) throw std::invalid_argument("tpsrhs_set_forcing: passive scalar radius must be positive");
+        for (int d = 0; d < 3; d++) f.ps[i].x0[d] = s.coords[d];
+        f.ps[i].radius = s.radius;
+        f.ps[i].value = s.value;
+      }
       const int dim = h->dim;
       f.has_pg = in->has_pressure_gradient ? 1 : 0;
       for (int d = 0; d < 3; d++) f.pg[d] = in->pressure_gradient[d];
