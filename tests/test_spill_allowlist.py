@@ -24,6 +24,18 @@ BENCH_INSTANTIATIONS = {
     "cfg5 = configs[4]": "Cfg<2,3,0>,PlasmaPhys<2,3,3,true,true,0>",
     "torch6": "Cfg<2,3,0>,PlasmaPhys<2,3,6,false,true,0>",
     "gll_dry (Gauss-Lobatto pair, dry air p=3)": "Cfg<3,3,1>,DryAirPhys<3,false,false>",
+    "lte_torch (table gas, axisymmetric)": "Cfg<2,3,0>,GasAxiPhys<true>",
+}
+# Waves per SIMD of the two hot sweeps of those workloads, by the register file (512 VGPRs per lane and SIMD on gfx950:
+# floor(512 / allocated)): the budget each kernel was tuned to.  A change that pushes one of them over its edge halves
+# or thirds its occupancy without a spill or any other sign -- round 3 met it: two more live registers in the six-species
+# k_gradient, 256 -> 258, one wave instead of two, torch6 k_gradient 0.49 -> 0.67 ms.
+BENCH_WAVES_PER_SIMD = {
+    "Cfg<3,3,0>,PlasmaPhys<3,3,3,true,false,1>": {"k_gradient": 2, "k_flux": 2},
+    "Cfg<3,2,0>,PlasmaPhys<3,3,3,true,false,1>": {"k_gradient": 2, "k_flux": 2},
+    "Cfg<3,3,0>,DryAirPhys<3,false,false>": {"k_gradient": 3, "k_flux": 3},
+    "Cfg<2,3,0>,PlasmaPhys<2,3,3,true,true,0>": {"k_gradient": 2, "k_flux": 2},
+    "Cfg<2,3,0>,PlasmaPhys<2,3,6,false,true,0>": {"k_gradient": 2, "k_flux": 2},
 }
 
 
@@ -67,6 +79,18 @@ def test_bench_and_baseline_kernels_do_not_spill(census):
                         if _norm(_) == k["kernel"])
                 if n > 0:
                     bad.append((what, k["kernel"], "scratch instructions", n))
+    assert not bad, bad
+
+
+def test_bench_kernels_keep_their_occupancy(census):
+    bad = []
+    for inst, want in BENCH_WAVES_PER_SIMD.items():
+        for kern, waves in want.items():
+            ks = [k for k in census if k["kernel"] == f"{kern}<{inst}>"]
+            assert len(ks) == 1, (kern, inst, len(ks))
+            regs = ks[0]["vgpr"] + ks[0]["agpr"]
+            if 512 // max(regs, 1) < waves:
+                bad.append((kern, inst, f"{regs} registers: {512 // regs} wave(s) per SIMD, tuned for {waves}"))
     assert not bad, bad
 
 

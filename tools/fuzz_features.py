@@ -58,8 +58,15 @@ for it in range(ncases):
                 feats.append("roe")
         elif geo == "axi":  # axisymmetric tube: dry air or an argon mixture, with the mixing-length model
             wall = int(rng.choice([capi.INV, capi.VISC_ADIAB, capi.VISC_ISOTH]))
-            fl = rng.choice(["dry", "ternary", "six"])
-            if fl == "dry":
+            fl = rng.choice(["dry", "ternary", "six", "lte"])
+            if fl == "lte":  # the table gas (fluid = lte_table, one-dimensional tables)
+                if wall == capi.VISC_ADIAB and rng.random() < 0.5:
+                    wall = capi.VISC_ISOTH
+                c = cases.lte_axisym(int(rng.integers(3, 7)), int(rng.integers(3, 8)), order, capi.NS, wall,
+                                     radiation=bool(rng.random() < 0.5), density=str(rng.choice(["rho0p005", "rho0p255"])))
+                c.disc.use_bc_in_grad = int(rng.random() < 0.5)
+                amp = 0.05
+            elif fl == "dry":
                 c = cases.dry_air_axisym(int(rng.integers(3, 7)), int(rng.integers(3, 8)), order, capi.NS, wall)
                 c.physics.dry_air.visc_mult = float(rng.choice([1.0, 50.0]))
                 amp = 0.05
@@ -72,6 +79,12 @@ for it in range(ncases):
             U = c.state(seed=seed, amp=amp)
             tang, dim = None, 2
             feats.append(fl)
+            if rng.random() < 0.5:  # [viscosityMultiplierFunction] in the 2-D heavy kernels
+                vs = ph.visc_sponge
+                vs.enabled, vs.width, vs.ratio = 1, float(rng.uniform(0.01, 0.08)), float(rng.uniform(2.0, 30.0))
+                vs.normal[0], vs.normal[1] = float(rng.uniform(-1, 1)), float(rng.uniform(0.2, 1.0))
+                vs.point[0], vs.point[1] = float(rng.uniform(0.0, 0.05)), float(rng.uniform(0.05, 0.2))
+                feats.append("sponge")
         else:
             two_t = bool(rng.random() < 0.5)
             c = cases.argon_cyl3d(4, int(rng.integers(8, 12)), 3, order, two_t, int(rng.choice([capi.CONSTANT, capi.ARGON_MINIMAL])), "arrhenius",
@@ -98,7 +111,7 @@ for it in range(ncases):
                 kw["heat_sources"] = [dict(value=float(rng.uniform(-1e4, 1e5)), radius=float(rng.uniform(0.2, 2.0)),
                                            point1=tuple(rng.uniform(-1, 1, 3)), point2=tuple(rng.uniform(1.5, 3, 3)))]
             if rng.random() < 0.5:
-                tu = target(1.15, (18.0, 1.0, -0.5)[:dim], 1.0e5) if dry else list(U[:, 3])
+                tu = target(1.15, (18.0, 1.0, -0.5)[:dim], 1.0e5) if dry else list(U[:, 3])  # (table gas, mixtures: a state of the field)
                 x0 = 5.0 if geo != "chan2d" else 0.6
                 kw["sponge_zones"] = [dict(type=capi.SPONGE_PLANAR, normal=(-1.0, float(rng.uniform(-0.2, 0.2)), 0.0),
                                            point0=(2 * x0, 0.0, 0.0), point_init=(x0, 0.0, 0.0), mult_factor=float(rng.uniform(0.2, 2.0)),
@@ -106,6 +119,10 @@ for it in range(ncases):
                 if dry and rng.random() < 0.4:  # mixed-out target: the plane through point_init, a generous node tolerance
                     kw["sponge_zones"][0].update(solution_type=capi.SPONGE_MIXEDOUT, tol=1.0 if geo == "cyl3d" else 0.12)
                     feats.append("mixedout")
+            if rng.random() < 0.4:  # PassiveScalar: the last equation, inside a ball
+                ctr = (5.0, 0.0, 0.0) if geo in ("cyl3d", "plasma3d") else ((0.02, 0.1, 0.0) if geo == "axi" else (0.5, 0.3, 0.0))
+                kw["passive_scalars"] = [dict(xyz=ctr, radius=float(rng.uniform(0.5, 6.0) if dim == 3 else rng.uniform(0.03, 0.4)),
+                                              value=float(rng.uniform(-2, 300)))]
             forcing = capi.make_forcing(**kw)
             feats.append("forcing:" + ",".join(sorted(k[:4] for k in kw)))
         joule = rng.uniform(-1e4, 5e4, U.shape[1]) if (dim == 3 and rng.random() < 0.3) else None

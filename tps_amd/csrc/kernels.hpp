@@ -267,9 +267,13 @@ struct MeshDev {
   VsDev vs;                    // viscous sponge of the 2-D kernels with the heavy interface (enabled = 0: none)
 };
 // what the closures of the 2-D heavy kernels take of the mixing-length model and the viscous sponge at one point
-__device__ inline EddyCtx closure_ctx(const MeshDev &m, bool dist_on, double dist, const double *X) {
+// (`park`: the block's LDS array of sponge weights, one word per lane -- see EddyCtx::vsw)
+__device__ inline EddyCtx closure_ctx(const MeshDev &m, bool dist_on, double dist, const double *X, double *park) {
   EddyCtx ec = dist_on ? eddy_at(m.ml, dist) : eddy_off();
-  if (m.vs.enabled) ec.vsw = visc_sponge_weight_2d(m.vs, X);  // uniform over the grid
+  if (m.vs.enabled) {  // uniform over the grid
+    park[threadIdx.x] = visc_sponge_weight_2d(m.vs, X);
+    ec.vsw = park;
+  }
   return ec;
 }
 
@@ -1325,7 +1329,8 @@ __device__ inline void visc_points(const MeshDev &m, const int2 *sFI, typename P
     double n[DIM], wq, Xq[DIM];
     face_geometry_rt<C>(d, &sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
     if constexpr (PH::HEAVY && DIM == 2) {  // dq: the wall distance at the points (mixing-length model) or NULL
-      PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, PH::AXISYM ? Xq[0] : -1.0, fn, closure_ctx(m, dq.on, dq.d[rd], Xq));
+      __shared__ double sVsw[C::BLOCK];
+      PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, PH::AXISYM ? Xq[0] : -1.0, fn, closure_ctx(m, dq.on, dq.d[rd], Xq, sVsw));
     } else if constexpr (PH::HEAVY) {
       PH::visc_trace(prm, nb, v[rd], v[rd] + NEQ, n, PH::AXISYM ? Xq[0] : -1.0, fn);
     } else if constexpr (PH::LES) {  // delta1 of src/face_integrator.cpp:253, transip of :333
@@ -2431,7 +2436,8 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
       } else {
         if constexpr (PH::HEAVY && DIM == 2) {  // (+ the mixing-length eddy viscosity when a distance function is set)
           const bool ml_on = m.ml.distance != nullptr;
-          const EddyCtx ec = closure_ctx(m, true, ml_on ? m.ml.distance[static_cast<int64_t>(e0 + le_n) * C::NPE + nd] : 0.0, Xn);
+          __shared__ double sVsw[C::BLOCK];
+          const EddyCtx ec = closure_ctx(m, true, ml_on ? m.ml.distance[static_cast<int64_t>(e0 + le_n) * C::NPE + nd] : 0.0, Xn, sVsw);
           if constexpr (PH::TWO_STEP)
             PH::total_flux(prm, uc, st, fc, gr, PH::AXISYM ? radius : -1.0, F, ec);
           else

@@ -72,21 +72,24 @@ __device__ inline double visc_sponge_weight_2d(const VsDev &v, const double *X) 
   wgt += 1.0;
   return wgt;
 }
-struct EddyCtx {  // what a closure needs of both at one point, by value: the constants, the (interpolated) distance, the sponge weight
-  bool on;
-  double dist, lmax, prt, bulk;
-  double vsw;  // weight of the viscous sponge at the point (1: none)
+struct EddyCtx {  // what a closure needs of both at one point: the model's constants, the (interpolated) distance, the sponge weight
+  const MixLenDev *ml;  // the mixing-length model's block (wave-uniform: the kernel's argument), NULL = off
+  double dist;
+  // Viscous sponge: base of the block's LDS array of weights (wave-uniform), one entry per lane, or NULL (none).  The
+  // weight is needed AFTER the transport closure; carried in a register across it, it is the 257th and 258th VGPR of the
+  // six-species two-temperature k_gradient (one wave per SIMD instead of two: torch6 k_gradient 0.49 -> 0.67 ms,
+  // measured), so the kernels park it in the lane's LDS word and the closure reads it where it scales its coefficients.
+  const double *vsw;
 };
-__device__ inline EddyCtx eddy_off() { return EddyCtx{false, 0.0, 0.0, 0.0, 0.0, 1.0}; }
-__device__ inline EddyCtx eddy_at(const MixLenDev &ml, double dist) {
-  return EddyCtx{ml.distance != nullptr, dist, ml.lmax, ml.prt, ml.bulk, 1.0};
-}
+__device__ inline EddyCtx eddy_off() { return EddyCtx{nullptr, 0.0, nullptr}; }
+__device__ inline EddyCtx eddy_at(const MixLenDev &ml, double dist) { return EddyCtx{ml.distance != nullptr ? &ml : nullptr, dist, nullptr}; }
+__device__ inline double sponge_weight(const EddyCtx &ec) { return ec.vsw ? ec.vsw[threadIdx.x] : 1.0; }
 // eddy viscosity rho l^2 |S| added to the molecular viscosity / raw bulk viscosity / heavy conductivity of a point
 // (g[eq + d*NEQ]: the primitive gradient; NVEL = 3 with DIM = 2: the axisymmetric strain terms)
 template <int DIM, int NVEL, int NEQ>
 __device__ inline void add_mixing_length(const EddyCtx &ec, const double *U, const double *g, double radius, double &visc,
                                          double &bulk, double &k) {
-  if (!ec.on) return;
+  if (!ec.ml) return;
   const double cp_over_pr = k / visc;
   const double rho = U[0];
   double S = 0.0;
@@ -108,11 +111,11 @@ __device__ inline void add_mixing_length(const EddyCtx &ec, const double *U, con
   }
   S = sqrt(S);
   double l = 0.41 * ec.dist;
-  if (l > ec.lmax) l = ec.lmax;
+  if (l > ec.ml->lmax) l = ec.ml->lmax;
   const double mut = rho * l * l * S;
   visc += mut;
-  bulk += ec.bulk * mut;
-  k += mut * cp_over_pr * ec.prt;
+  bulk += ec.ml->bulk * mut;
+  k += mut * cp_over_pr * ec.ml->prt;
 }
 
 // Where a point sits, for the closures that depend on it (LES flavour): grid scale of its element and position

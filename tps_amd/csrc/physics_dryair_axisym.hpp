@@ -27,50 +27,84 @@ struct LteParams : DryAirParams {
   TableDev tab_mu, tab_k, tab_sigma;      // mu(T), kappa(T), sigma(T)
   TableDev tab_nec;                       // net emission coefficient (src/radiation.hpp:54-69), when `radiation`
   int radiation;
+  // Search aids (the intervals they find are LinearTable::findInterval's, verified against the abscissae):
+  //  * the inverse table has no uniform axis, and the reference's bisection is 7 dependent loads per state: `ehint[j]` is
+  //    the interval of the left edge of the j-th of `nhint` uniform bins over the energy axis, the search walks on from there;
+  //  * e, R, c (one file, one temperature column) and mu, kappa share their abscissae: one search serves the tables
+  //    evaluated at the same temperature.
+  const int *ehint;
+  int nhint, thermo_same_grid, trans_same_grid;
+  double e0, inv_de;
 };
-// LinearTable::eval_x, src/table.cpp:103-113
-__device__ inline double table_eval_x(const TableDev &t, double xe) {
-  const int idx = table_interval(t, xe);
+// LinearTable::eval / eval_x (src/table.cpp:80-113) in a known interval
+__device__ inline double table_at(const TableDev &t, int idx, double xe) {
+  const double xt = t.x_log ? flog(xe) : xe;
+  double ft = t.a[idx] + t.b[idx] * xt;
+  if (t.f_log) ft = fexp(ft);
+  return ft;
+}
+__device__ inline double table_slope_at(const TableDev &t, int idx, double xe) {
   const double xt = t.x_log ? flog(xe) : xe;
   double ft_x = t.b[idx] * (t.x_log ? 1.0 / xe : 1.0);
   if (t.f_log) ft_x *= fexp(t.a[idx] + t.b[idx] * xt);
   return ft_x;
 }
+__device__ inline double table_eval_x(const TableDev &t, double xe) { return table_slope_at(t, table_interval(t, xe), xe); }
+// findInterval of the inverse table T(e) through the bins
+__device__ inline int lte_energy_interval(const LteParams &p, double e) {
+  const TableDev &t = p.tab_T;
+  if (p.ehint) {
+    const double fj = fmin(fmax((e - p.e0) * p.inv_de, 0.0), static_cast<double>(p.nhint - 1));  // (NaN -> 0)
+    int g = p.ehint[static_cast<int>(fj)];
+    while (g < t.n - 2 && e > t.x[g + 1]) g++;
+    if ((g == 0 || e > t.x[g]) && (g == t.n - 2 || !(e > t.x[g + 1]))) return g;
+  }
+  return table_interval(t, e);
+}
 // LteMixture::ComputeTemperatureInternal, src/lte_mixture.cpp:161-218: Newton on e(T) = energy from the inverse table
-// (the reference asserts convergence; a state that does not converge returns NaN here and is caught like any other)
-__device__ inline double lte_temperature(const LteParams &p, double energy) {
-  double T = table_eval(p.tab_T, energy);
-  double res = energy - table_eval(p.tab_e, T);
+// (the reference asserts convergence; a state that does not converge returns NaN here and is caught like any other).
+// `it`: the interval of the result in the temperature grid of the thermodynamic tables.
+__device__ inline double lte_temperature(const LteParams &p, double energy, int &it) {
+  double T = table_at(p.tab_T, lte_energy_interval(p, energy), energy);
+  it = table_interval(p.tab_e, T);
+  double res = energy - table_at(p.tab_e, it, T);
   const double res0 = fabs(res);
   const double atol = 1e-18, rtol = 1e-12, dT_atol = 1e-12, dT_rtol = 1e-8;
   bool converged = (fabs(res) < atol) || (fabs(res) / fabs(res0) < rtol);
   int niter = 0;
   while (!converged && niter < 20) {
-    const double dedT = table_eval_x(p.tab_e, T);
+    const double dedT = table_slope_at(p.tab_e, it, T);
     const double dT = res / dedT;
     T += dT;
-    res = energy - table_eval(p.tab_e, T);
+    it = table_interval(p.tab_e, T);
+    res = energy - table_at(p.tab_e, it, T);
     converged = (fabs(res) < atol) || (fabs(res) / res0 < rtol) || (fabs(dT) < dT_atol) || (fabs(dT) / T < dT_rtol);
     niter++;
   }
   return converged ? T : __builtin_nan("");
 }
+// a thermodynamic table other than e(T) at a temperature whose interval in e's grid is known
+__device__ inline double lte_thermo_at(const LteParams &p, const TableDev &t, int it, double T) {
+  return p.thermo_same_grid ? table_at(t, it, T) : table_eval(t, T);
+}
 // LteMixture::ComputeTemperatureFromDensityPressure, src/lte_mixture.cpp:236-296: Newton on p = rho R(T) T
 // (the reference goes on with the last iterate when the iteration has not converged)
-__device__ inline double lte_temperature_rho_p(const LteParams &p, double rho, double pres) {
+__device__ inline double lte_temperature_rho_p(const LteParams &p, double rho, double pres, int &it) {
   double T = pres / (rho * 208.);
-  double R = table_eval(p.tab_R, T);
+  it = table_interval(p.tab_R, T);
+  double R = table_at(p.tab_R, it, T);
   double res = pres - rho * R * T;
   const double res0 = fabs(res);
   const double atol = 1e-18, rtol = 1e-12, dT_atol = 1e-12, dT_rtol = 1e-8;
   bool converged = (fabs(res) < atol) || (fabs(res) / fabs(res0) < rtol);
   int niter = 0;
   while (!converged && niter < 20) {
-    const double R_T = table_eval_x(p.tab_R, T);
+    const double R_T = table_slope_at(p.tab_R, it, T);
     const double dpdT = rho * R + rho * R_T * T;
     const double dT = res / dpdT;
     T += dT;
-    R = table_eval(p.tab_R, T);
+    it = table_interval(p.tab_R, T);
+    R = table_at(p.tab_R, it, T);
     res = pres - rho * R * T;
     converged = (fabs(res) < atol) || (fabs(res) / res0 < rtol) || (fabs(dT) < dT_atol) || (fabs(dT) / T < dT_rtol);
     niter++;
@@ -102,6 +136,7 @@ struct GasAxiPhys {
     double ir, k, p;
     double vel[NVEL];
     double T;  // table gas only
+    int it;    // ... and the interval of T in the grid of the thermodynamic tables
   };
   __device__ static inline State make_state(const Params &p, const double *U) {
     State s;
@@ -114,8 +149,8 @@ struct GasAxiPhys {
     }
     s.k = m2 * s.ir;
     if constexpr (LTE_) {  // LteMixture::ComputePressure, src/lte_mixture.cpp:119-131
-      s.T = lte_temperature(p, (U[ITH] - 0.5 * s.k) / U[0]);
-      s.p = U[0] * table_eval(p.tab_R, s.T) * s.T;
+      s.T = lte_temperature(p, (U[ITH] - 0.5 * s.k) / U[0], s.it);
+      s.p = U[0] * lte_thermo_at(p, p.tab_R, s.it, s.T) * s.T;
     } else {
       s.p = (p.gamma - 1.0) * (U[ITH] - 0.5 * s.k);
     }
@@ -131,7 +166,11 @@ struct GasAxiPhys {
   }
   __device__ static inline double rho_e_at_pressure(const Params &p, double rho, double pres) {
     if constexpr (LTE_)
-      return rho * table_eval(p.tab_e, lte_temperature_rho_p(p, rho, pres));  // src/lte_mixture.cpp:448-467
+    {
+      int it;  // (the interval is R's: e shares it when the tables share their grid)
+      const double T = lte_temperature_rho_p(p, rho, pres, it);
+      return rho * (p.thermo_same_grid ? table_at(p.tab_e, it, T) : table_eval(p.tab_e, T));  // src/lte_mixture.cpp:448-467
+    }
     else
       return pres / (p.gamma - 1.0);
   }
@@ -143,7 +182,7 @@ struct GasAxiPhys {
   }
   __device__ static inline double sound(const Params &p, const State &s) {
     if constexpr (LTE_)
-      return table_eval(p.tab_c, s.T);  // src/lte_mixture.cpp:357-372
+      return lte_thermo_at(p, p.tab_c, s.it, s.T);  // src/lte_mixture.cpp:357-372
     else
       return fast_sqrt(p.gamma * s.p * s.ir);
   }
@@ -207,9 +246,10 @@ struct GasAxiPhys {
   // Sutherland viscosity, bulk viscosity and conductivity at the temperature of a conserved state
   __device__ static inline void transport(const Params &p, const State &s, double &visc, double &bulk, double &k) {
     if constexpr (LTE_) {  // LteTransport::ComputeFluxMolecularTransport, src/lte_transport_properties.cpp:84-107
-      visc = table_eval(p.tab_mu, s.T);
+      const int im = table_interval(p.tab_mu, s.T);
+      visc = table_at(p.tab_mu, im, s.T);
       bulk = 0.0;
-      k = table_eval(p.tab_k, s.T);
+      k = p.trans_same_grid ? table_at(p.tab_k, im, s.T) : table_eval(p.tab_k, s.T);
     } else {
       const double T = s.p * p.inv_Rg * s.ir;
       visc = p.C1 * p.visc_mult * T * fast_sqrt(T) / (T + p.S0);
@@ -225,9 +265,10 @@ struct GasAxiPhys {
     transport(p, s, visc, bulkv, k);
     add_mixing_length<DIM, NVEL, NEQ>(ec, U, g, radius, visc, bulkv, k);
     double bulk = bulkv - 2. / 3. * visc;
-    visc *= ec.vsw;  // viscous sponge, src/fluxes.cpp:232-238 (after the -2/3 mu of the bulk viscosity)
-    bulk *= ec.vsw;
-    k *= ec.vsw;
+    const double vsw = sponge_weight(ec);  // viscous sponge, src/fluxes.cpp:232-238 (after the -2/3 mu of the bulk viscosity)
+    visc *= vsw;
+    bulk *= vsw;
+    k *= vsw;
     double divV = g[1 + 0 * NEQ] + g[2 + 1 * NEQ];
     if (radius > 0) divV += s.vel[0] / radius;
     double e = 0.0;

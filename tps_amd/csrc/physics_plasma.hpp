@@ -868,13 +868,14 @@ struct PlasmaPhys {
     double bulk = t.bulk - 2. / 3. * t.visc;
     double k = t.k;
     if constexpr (DIM == 2) {  // viscous sponge, src/fluxes.cpp:232-246: mu, mu_b - 2/3 mu, k_h and the ACTIVE species' velocities
-      t.visc *= ec.vsw;
-      bulk *= ec.vsw;
-      k *= ec.vsw;
+      const double vsw = sponge_weight(ec);
+      t.visc *= vsw;
+      bulk *= vsw;
+      k *= vsw;
 #pragma unroll
       for (int d = 0; d < DIM; d++)
 #pragma unroll
-        for (int sp = 0; sp < NACTIVE; sp++) t.V[sp + d * NSP] *= ec.vsw;
+        for (int sp = 0; sp < NACTIVE; sp++) t.V[sp + d * NSP] *= vsw;
     }
     if (TWOT) {
 #pragma unroll
@@ -970,19 +971,20 @@ struct PlasmaPhys {
     if constexpr (DIM == 2) add_mixing_length<DIM, NVEL, NEQ>(ec, U, g, radius, t.visc, t.bulk, t.k);
     double h[NSP], Vn[NSP];
     enthalpies(p, s, h);
+    const double vsw = (DIM == 2) ? sponge_weight(ec) : 1.0;
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++) {
       double a = 0.0;
 #pragma unroll
       for (int d = 0; d < DIM; d++) a += t.V[sp + d * NSP] * n[d];
-      if (DIM == 2 && sp < NACTIVE) a *= ec.vsw;  // viscous sponge (src/fluxes.cpp:395-408), before the wall prescriptions
+      if (DIM == 2 && sp < NACTIVE) a *= vsw;  // viscous sponge (src/fluxes.cpp:395-408), before the wall prescriptions
       Vn[sp] = w.species ? w.Vn[sp] * w.nm : a;
     }
     double bulk = t.bulk - 2. / 3. * t.visc;
     if constexpr (DIM == 2) {
-      t.visc *= ec.vsw;
-      bulk *= ec.vsw;
-      t.k *= ec.vsw;
+      t.visc *= vsw;
+      bulk *= vsw;
+      t.k *= vsw;
     }
     double divV = 0.0;
 #pragma unroll

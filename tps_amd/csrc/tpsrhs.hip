@@ -520,6 +520,32 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
       rev.x_data = in.energy_table.f_data;
       rev.f_data = in.energy_table.x_data;
       lp->tab_T = upload_table(op, rev);
+      {  // search aid of the inverse table: the interval of the left edge of uniform bins over the energy axis
+        const int N = in.energy_table.n_data, nh = 4 * (N - 1);
+        const double *ex = in.energy_table.f_data;
+        const double de = (ex[N - 1] - ex[0]) / nh;
+        std::vector<int> hint(nh);
+        int idx = 0;
+        for (int j = 0; j < nh; j++) {
+          const double left = ex[0] + j * de;
+          while (idx < N - 2 && ex[idx + 1] < left) idx++;
+          hint[j] = idx;
+        }
+        int *dh = dev_upload(hint);
+        op->d_extra.push_back(dh);
+        lp->ehint = dh;
+        lp->nhint = nh;
+        lp->e0 = ex[0];
+        lp->inv_de = 1.0 / de;
+      }
+      auto same_grid = [](const tpsrhs_table &a, const tpsrhs_table &b) {
+        if (a.n_data != b.n_data || a.x_log_scale != b.x_log_scale) return 0;
+        for (int k = 0; k < a.n_data; k++)
+          if (a.x_data[k] != b.x_data[k]) return 0;
+        return 1;
+      };
+      lp->thermo_same_grid = same_grid(in.energy_table, in.gas_constant_table) && same_grid(in.energy_table, in.sound_speed_table);
+      lp->trans_same_grid = same_grid(in.viscosity_table, in.conductivity_table);
       lp->tab_mu = upload_table(op, in.viscosity_table);
       lp->tab_k = upload_table(op, in.conductivity_table);
       lp->tab_sigma = upload_table(op, in.electric_conductivity_table);
