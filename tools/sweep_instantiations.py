@@ -4,7 +4,8 @@ each, against the oracle.  Complements the randomised tools/fuzz_parity.py: roun
 species residual in some lanes (and one with a memory fault) that no test had touched.
 
     python tools/sweep_instantiations.py <geo: 3d|2d|axi> [nsp ...]      # driver: one worker process per (nsp, ambipolar)
-A worker that dies (GPU fault) takes only its own cases with it; the driver reports it and goes on."""
+A worker that dies (GPU fault) takes only its own cases with it; the driver reports it and goes on.
+SWEEP_SPONGE=1 (geometry axi): every case with the viscosity-multiplier function on."""
 import os
 import subprocess
 import sys
@@ -47,6 +48,10 @@ def worker(geo, nsp, ambi):
                     else:
                         c = cases.Case("box2d", meshgen.scramble_orientations(meshgen.box_quad(4, 3 if small else 5, lengths=(0.2, 0.1), warp=0.08), 7),
                                        capi.Disc(order, 0, 0, 0, 0), ph, [])
+                    if geo == "axi" and os.environ.get("SWEEP_SPONGE"):  # the viscous sponge of the 2-D heavy kernels, in every instantiation
+                        vs = ph.visc_sponge
+                        vs.enabled, vs.width, vs.ratio = 1, 0.04, 15.0
+                        vs.normal[0], vs.normal[1], vs.point[0], vs.point[1] = 0.3, 1.0, 0.02, 0.12
                     disc = capi.Disc(order, nc, nc, 1 if geo == "axi" else 0, 0)
                     amp = 0.005 if order == 1 else 0.01
                     nvel = 2 if geo == "2d" else 3
