@@ -35,6 +35,8 @@ def run(tag, ph, mesh, bcs, axisym=False):
     npe = (order + 1) ** mesh.dim
     for rep in range(2):
         got = hip_mult(mesh, disc, ph, bcs, U)
+        if os.environ.get("PROBE_DUMP") and rep == 0:  # for comparisons between two builds
+            np.save(os.path.join(ROOT, "gpurun_out", f"probe_{os.environ['PROBE_DUMP']}_{tag.replace(' ', '_')}.npy"), got["y"])
         sc = np.abs(ref["y"]).reshape(U.shape[0], -1).max(axis=1)
         err = np.abs(got["y"] - ref["y"]).reshape(U.shape[0], -1).max(axis=1) / sc
         uerr = np.abs(got["Up"] - ref["Up"]).max(axis=1) / np.abs(ref["Up"]).max(axis=1)
@@ -48,6 +50,19 @@ def run(tag, ph, mesh, bcs, axisym=False):
               f"elements {sorted(set((bad // npe).tolist()))[:24]} local nodes {sorted(set((bad % npe).tolist()))}", flush=True)
 
 
+if geo == "3d" and os.environ.get("PROBE_KNOBS"):
+    # which transport coefficient carries the wrong term?  multipliers of [plasma_models/transport]: viscosity, bulk viscosity,
+    # heavy conductivity, electron conductivity; diffusivities; mobilities
+    box = meshgen.scramble_orientations(meshgen.box_hex(3, 4, 3, warp=0.1), 254)
+    for name, fl, dm, mm in (("all 30", (30, 30, 30, 30), 30, 30), ("no diffusion", (30, 30, 30, 30), 0, 0), ("only diffusion", (0, 0, 0, 0), 30, 30),
+                             ("only viscosity", (30, 0, 0, 0), 0, 0), ("only k_h", (0, 0, 30, 0), 0, 0), ("only k_e", (0, 0, 0, 30), 0, 0),
+                             ("diffusion, no mobility", (0, 0, 0, 0), 30, 0), ("all 1", (1, 1, 1, 1), 1, 1)):
+        ph = physics()
+        for k in range(4):
+            ph.gas_transport.flux_trns_multiplier[k] = float(fl[k])
+        ph.gas_transport.diff_mult, ph.gas_transport.mobil_mult = float(dm), float(mm)
+        run("box " + name, ph, box, [])
+    sys.exit(0)
 if geo == "3d":
     c = cases.argon_cyl3d(2, 8, 3, order, physics=physics(), wall_type=capi.VISC_ISOTH)
     run("cylinder NS", c.physics, c.mesh, c.bcs)
