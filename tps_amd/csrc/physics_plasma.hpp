@@ -575,7 +575,7 @@ struct PlasmaPhys {
     }
     t.intot = q.intot;
     t.imho = 0.0;
-    double diff[NSP], mob[NSP];
+    double diff[NSP] = {}, mob[NSP] = {};  // (the multiplier block below reads them even when `diffusion` is off)
     const double iTe = fast_rcp(Te), iTh = TWOT ? fast_rcp(Th) : iTe;
     if (TRANSPORT == TRANSPORT_CONSTANT) {
       t.visc = p.c_visc;
