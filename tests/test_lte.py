@@ -270,3 +270,38 @@ def test_lte_unsupported():
     pl.visc_sponge.normal[0] = 1.0
     with pytest.raises(Exception, match="planar 2-D and the axisymmetric"):
         RHSoperator(meshgen.box_hex(3, 3, 3), capi.Disc(2, 0, 0, 0, 0), pl, [])
+
+
+def test_oracle_sponge_scales_the_right_coefficients_of_a_mixture():
+    """Fluxes::ComputeViscousFluxes with the viscosity-multiplier function on (src/fluxes.cpp:232-246): mu, mu_b - 2/3 mu, k_h
+    and the diffusion velocities of the ACTIVE species carry the weight w; k_e and the other species' velocities do not.
+    Closed-form consequences for one point of a two-temperature ternary mixture (constant transport, ambipolar: one active
+    species): the momentum rows and the active species row scale with w exactly; the electron-energy row's conduction part
+    does not."""
+    from oracle_lib import Oracle
+
+    mesh = meshgen.box_quad(3, 3, lengths=(1.0, 1.0))
+    ph0 = capi.argon_ternary_physics(capi.NS, True, capi.CONSTANT, None)
+    ph1 = capi.argon_ternary_physics(capi.NS, True, capi.CONSTANT, None)
+    vs = ph1.visc_sponge
+    vs.enabled, vs.width, vs.ratio = 1, 0.2, 11.0
+    vs.normal[0], vs.normal[1], vs.point[0], vs.point[1] = 0.0, 3.0, 0.0, 0.4  # normalised to (0, 1)
+    o0, o1 = Oracle(mesh, capi.Disc(1, 0, 0, 0, 0), ph0, []), Oracle(mesh, capi.Disc(1, 0, 0, 0, 0), ph1, [])
+    X = np.array([[0.3], [0.55]])
+    U = cases.plasma_state(X, ph0, nvel=2, seed=3, amp=0.0)[:, 0]
+    neq = U.size  # rho, rho u, rho v, rho E, rho Y_ion, rho e_e
+    rng = np.random.default_rng(5)
+    g = rng.uniform(-1.0, 1.0, neq * 2) * np.tile(np.maximum(np.abs(o0.prim(U)), 1.0), 2) * 5.0
+    x = (0.3, 0.55)
+    w = 1.0 + 10.0 * 0.5 * (np.tanh((0.55 - 0.4) / 0.2 - 2.0) + 1.0)
+    a, b = o1.viscous_flux_at(U, g, x, 0.1), o0.viscous_flux_at(U, g, x, 0.1)
+    for d in range(2):
+        rows = [1 + d * neq, 2 + d * neq, 4 + d * neq]  # momentum, active species
+        assert np.abs(a[rows] - w * b[rows]).max() < 1e-12 * np.abs(a[rows]).max()
+    # electron energy row: k_e grad T_e - h_e V_e with k_e and (ambipolar) V_e unweighted ... through the ambipolar field V_e
+    # depends on the weighted ion velocity, so only the pure-conduction case is a closed form: zero species gradients
+    g2 = np.zeros_like(g)
+    g2[neq - 1], g2[neq - 1 + neq] = 700.0, -300.0  # grad T_e only
+    a2, b2 = o1.viscous_flux_at(U, g2, x, 0.1), o0.viscous_flux_at(U, g2, x, 0.1)
+    assert np.abs(a2[[neq - 1, 2 * neq - 1]] - b2[[neq - 1, 2 * neq - 1]]).max() < 1e-12 * np.abs(b2).max()
+    assert np.abs(b2[[neq - 1, 2 * neq - 1]]).min() > 0.0
