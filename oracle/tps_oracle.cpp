@@ -1003,6 +1003,25 @@ int tpsoracle_get_primitives(void *h, double *out) {
   std::memcpy(out, op->Up.data(), op->Up.size() * sizeof(double));
   return 0;
 }
+// SourceTerm::updateTerms' side output plasma_conductivity_ (src/source_term.cpp:184,196) from the primitives of the last
+// Mult, for the table gas (numSpecies == 1: the `else` branch of :178-197): LteTransport::ComputeSourceMolecularTransport
+int tpsoracle_get_plasma_conductivity(void *h, double *out) {
+  Operator *op = static_cast<Operator *>(h);
+  try {
+    if (op->phys.working_fluid != TPSRHS_LTE_FLUID) throw std::runtime_error("plasma conductivity: restated for the table gas");
+    const int64_t N = op->ndofs;
+    for (int64_t n = 0; n < N; n++) {
+      double upn[tpsoracle::MAXEQ], gt[tpsoracle::MAXSP] = {0};
+      for (int eq = 0; eq < op->neq; eq++) upn[eq] = op->Up[n + eq * N];
+      op->transport->ComputeSourceTransportProperties(nullptr, upn, nullptr, nullptr, 0.0, gt, nullptr, nullptr, nullptr);
+      out[n] = gt[tpsoracle::ELECTRIC_CONDUCTIVITY];
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+}
 int tpsoracle_get_gradients(void *h, double *out) {
   Operator *op = static_cast<Operator *>(h);
   std::memcpy(out, op->gradUp.data(), op->gradUp.size() * sizeof(double));

@@ -164,6 +164,15 @@ class Oracle:
         lib().tpsoracle_get_primitives(self.h, _p(out))
         return out
 
+    def plasma_conductivity(self):
+        """plasma_conductivity_ of SourceTerm from the primitives of the last mult (table gas)"""
+        out = np.zeros(int(self.ndofs))
+        L = lib()
+        L.tpsoracle_get_plasma_conductivity.argtypes = [C.c_void_p, _dp]
+        if L.tpsoracle_get_plasma_conductivity(self.h, _p(out)) != 0:
+            raise RuntimeError("oracle: " + L.tpsoracle_last_error().decode())
+        return out
+
     def gradients(self):
         out = np.zeros((self.dim, self.neq, self.ndofs))
         lib().tpsoracle_get_gradients(self.h, _p(out))

@@ -305,3 +305,53 @@ def test_oracle_sponge_scales_the_right_coefficients_of_a_mixture():
     a2, b2 = o1.viscous_flux_at(U, g2, x, 0.1), o0.viscous_flux_at(U, g2, x, 0.1)
     assert np.abs(a2[[neq - 1, 2 * neq - 1]] - b2[[neq - 1, 2 * neq - 1]]).max() < 1e-12 * np.abs(b2).max()
     assert np.abs(b2[[neq - 1, 2 * neq - 1]]).min() > 0.0
+
+
+def _sigma_table(ph):
+    """(the sigma column of the reference's air_simple_transport_table.dat is zero: an argon-like ramp instead, SYNTHETIC,
+    zero below 5000 K so that the floor of 1 S/m is exercised)"""
+    Ts = np.linspace(300.0, 20000.0, 80)
+    sig = 0.35 * np.maximum(Ts - 5000.0, 0.0) ** 1.1
+    ph.lte.electric_conductivity_table = capi.make_table(Ts, sig, keep=ph._keep)
+    return Ts, sig
+
+
+def test_oracle_plasma_conductivity_closed_form():
+    """SourceTerm's side output for the table gas (src/source_term.cpp:196, src/lte_transport_properties.cpp:109-126):
+    sigma(T) of the table, not below 1 S/m -- the transport table of the reference's unit test has sigma = 0 at low T"""
+    from oracle_lib import Oracle
+
+    c = cases.lte_axisym(4, 5, 2)
+    Ts, sig = _sigma_table(c.physics)
+    U = c.state(seed=2)
+    o = Oracle(c.mesh, c.disc, c.physics, c.bcs)
+    o.mult(U)
+    T = o.primitives()[4]
+    want = np.maximum(np.interp(T, Ts, sig), 1.0)
+    got = o.plasma_conductivity()
+    assert got == pytest.approx(want, rel=1e-13)
+    assert (want > 1.0).any() and (want == 1.0).any()
+
+
+@pytest.mark.gpu
+def test_hip_plasma_conductivity():
+    import torch
+    from oracle_lib import Oracle
+    from tps_amd.rhs_operator import RHSoperator
+
+    c = cases.lte_axisym(5, 6, 3)
+    _sigma_table(c.physics)
+    U = c.state(seed=8)
+    o = Oracle(c.mesh, c.disc, c.physics, c.bcs)
+    o.mult(U)
+    op = RHSoperator(c.mesh, c.disc, c.physics, c.bcs)
+    x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
+    op.Mult(x, torch.empty_like(x))
+    got = op.getPlasmaConductivity().cpu().numpy()
+    assert got == pytest.approx(o.plasma_conductivity(), rel=1e-13)
+    op.close()
+    d = cases.dry_air_axisym(3, 3, 2)
+    op = RHSoperator(d.mesh, d.disc, d.physics, d.bcs)
+    with pytest.raises(Exception, match="table gas"):
+        op.getPlasmaConductivity()
+    op.close()

@@ -612,6 +612,7 @@ def load():
     lib.tpsrhs_update_gradients.argtypes = [vp, vp]
     lib.tpsrhs_get_primitives.argtypes = [vp, vp]
     lib.tpsrhs_get_gradients.argtypes = [vp, vp]
+    lib.tpsrhs_get_plasma_conductivity.argtypes = [vp, vp]
     lib.tpsrhs_height.restype = C.c_int64
     lib.tpsrhs_height.argtypes = [vp]
     lib.tpsrhs_num_dofs.restype = C.c_int64
@@ -643,7 +644,7 @@ def load():
 
 EXPORTED_SYMBOLS = [
     "tpsrhs_create", "tpsrhs_destroy", "tpsrhs_mult", "tpsrhs_mult_host", "tpsrhs_update_gradients",
-    "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
+    "tpsrhs_get_primitives", "tpsrhs_get_gradients", "tpsrhs_get_plasma_conductivity", "tpsrhs_height", "tpsrhs_num_dofs", "tpsrhs_num_equation",
     "tpsrhs_enable_kernel_timing", "tpsrhs_kernel_times", "tpsrhs_mult_times", "tpsrhs_kernel_bytes",
     "tpsrhs_eval_pointwise", "tpsrhs_table_eval", "tpsrhs_math_eval", "tpsrhs_face_tables",
     "tpsrhs_rk4_step", "tpsrhs_advance", "tpsrhs_set_dt", "tpsrhs_set_forcing", "tpsrhs_set_joule_heating", "tpsrhs_set_mixing_length", "tpsrhs_status_string",
