@@ -355,14 +355,15 @@ int tpsrhs_update_gradients(tpsrhs_handle h, const double *x);
  * copy the operator-owned device arrays to a DEVICE buffer (neq*NDofs / dim*neq*NDofs doubles). */
 int tpsrhs_get_primitives(tpsrhs_handle h, double *up_out);
 int tpsrhs_get_gradients(tpsrhs_handle h, double *gradup_out);
-/* SourceTerm's side output (src/source_term.cpp:184,196): the `plasma_conductivity_` grid function that the EM solver of
+/* SourceTerm's side output (src/source_term.cpp:125-199): the `plasma_conductivity_` grid function that the EM solver of
  * the cycle-avg-joule-coupled runs reads between flow steps (the other half of that coupling is
- * tpsrhs_set_joule_heating).  sigma at every node from the primitive state of the LAST Mult / tpsrhs_update_gradients:
- * for the table gas max(sigma(T), 1) (LteTransport::ComputeSourceMolecularTransport,
- * src/lte_transport_properties.cpp:109-126).  `sigma_out`: NDofs doubles, DEVICE memory, ordered on the operator's
- * stream.  Mixtures (computeMixtureElectricConductivity of the source transport): TPSRHS_ERR_UNSUPPORTED for now; dry
- * air has no SourceTerm (TPSRHS_ERR_UNSUPPORTED). */
-int tpsrhs_get_plasma_conductivity(tpsrhs_handle h, double *sigma_out);
+ * tpsrhs_set_joule_heating).  sigma at every node of the state `x` (DEVICE, the layout of tpsrhs_mult; species rows clamped
+ * at zero as SourceTerm does): the SrcTrns::ELECTRIC_CONDUCTIVITY of the transport model's source properties --
+ * mixtures: computeMixtureElectricConductivity(mobility, n) * MOLARELECTRONCHARGE (src/transport_properties.cpp:421-428,
+ * src/gas_transport.cpp:725-739, 1455-1463); table gas: max(sigma(T), 1) (src/lte_transport_properties.cpp:109-126).
+ * `sigma_out`: NDofs doubles, DEVICE memory, ordered on the operator's stream.  TPSRHS_ERR_UNSUPPORTED where the
+ * reference does not store it: dry air (no SourceTerm) and reacting mixtures that are not ambipolar (:178-197). */
+int tpsrhs_get_plasma_conductivity(tpsrhs_handle h, const double *x, double *sigma_out);
 
 /* A->Height() (src/rhs_operator.cpp:49), vfes->GetNDofs(), num_equation. */
 /* Point-wise closures of the gas model on the device, for n conserved states U[eq * n + i] (device pointers,

@@ -163,7 +163,9 @@ class RHSoperatorHIP : public mfem::TimeDependentOperator {
   void getPrimitives(mfem::Vector &up) const { check(tpsrhs_get_primitives(h_, up.Write())); }
   void getGradients(mfem::Vector &gradUp) const { check(tpsrhs_get_gradients(h_, gradUp.Write())); }
   // plasma_conductivity_ of SourceTerm (src/source_term.cpp:184,196) for the EM solver of the coupled runs
-  void getPlasmaConductivity(mfem::Vector &sigma) const { check(tpsrhs_get_plasma_conductivity(h_, sigma.Write())); }
+  void getPlasmaConductivity(const mfem::Vector &x, mfem::Vector &sigma) const {
+    check(tpsrhs_get_plasma_conductivity(h_, x.Read(), sigma.Write()));
+  }
   // the optional terms of the reference's constructor: forcing.Append(...) (src/rhs_operator.cpp:101-166), the
   // joule_heating_ and distance_ grid functions (device arrays owned by the caller; NULL-sized vector = off)
   void setForcing(const tpsrhs_forcing *f) { check(tpsrhs_set_forcing(h_, f)); }

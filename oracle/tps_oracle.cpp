@@ -1003,17 +1003,32 @@ int tpsoracle_get_primitives(void *h, double *out) {
   std::memcpy(out, op->Up.data(), op->Up.size() * sizeof(double));
   return 0;
 }
-// SourceTerm::updateTerms' side output plasma_conductivity_ (src/source_term.cpp:184,196) from the primitives of the last
-// Mult, for the table gas (numSpecies == 1: the `else` branch of :178-197): LteTransport::ComputeSourceMolecularTransport
-int tpsoracle_get_plasma_conductivity(void *h, double *out) {
+// SourceTerm::updateTerms' side output plasma_conductivity_ (src/source_term.cpp:125-199) for the state x: the clamped
+// node state and primitives through the transport model's ComputeSourceTransportProperties; stored by the reference for
+// single-species fluids, mixtures without reactions and ambipolar mixtures (:178-199)
+int tpsoracle_get_plasma_conductivity(void *h, const double *x, double *out) {
   Operator *op = static_cast<Operator *>(h);
   try {
-    if (op->phys.working_fluid != TPSRHS_LTE_FLUID) throw std::runtime_error("plasma conductivity: restated for the table gas");
+    if (op->phys.working_fluid == TPSRHS_DRY_AIR) throw std::runtime_error("plasma conductivity: dry air has no SourceTerm");
+    const bool mix = op->phys.working_fluid == TPSRHS_USER_DEFINED;
+    if (mix && !op->phys.mixture.ambipolar && op->phys.chemistry.num_reactions > 0)
+      throw std::runtime_error("plasma conductivity: not stored for a reacting mixture that is not ambipolar");
     const int64_t N = op->ndofs;
+    const int neq = op->neq, nact = op->mixture->numActiveSpecies;
     for (int64_t n = 0; n < N; n++) {
-      double upn[tpsoracle::MAXEQ], gt[tpsoracle::MAXSP] = {0};
-      for (int eq = 0; eq < op->neq; eq++) upn[eq] = op->Up[n + eq * N];
-      op->transport->ComputeSourceTransportProperties(nullptr, upn, nullptr, nullptr, 0.0, gt, nullptr, nullptr, nullptr);
+      double Un[tpsoracle::MAXEQ], upn[tpsoracle::MAXEQ], g[tpsoracle::MAXEQ * tpsoracle::MAXDIM] = {0};
+      for (int eq = 0; eq < neq; eq++) Un[eq] = x[n + eq * N];
+      op->mixture->GetPrimitivesFromConservatives(Un, upn);  // Up_ of the same state
+      for (int sp = 0; sp < nact; sp++) {  // src/source_term.cpp:127-132 (the reference's hard-coded 3 + 2 + sp)
+        const int eq = 3 + 2 + sp;
+        if (eq < neq) {
+          upn[eq] = std::max(upn[eq], 0.0);
+          Un[eq] = std::max(Un[eq], 0.0);
+        }
+      }
+      double Efield[tpsoracle::MAXDIM] = {0, 0, 0};
+      double gt[tpsoracle::MAXSP] = {0}, st[tpsoracle::MAXSP * 2] = {0}, dv[tpsoracle::MAXSP * tpsoracle::MAXDIM] = {0}, ns[tpsoracle::MAXSP] = {0};
+      op->transport->ComputeSourceTransportProperties(Un, upn, g, Efield, 0.0, gt, st, dv, ns);
       out[n] = gt[tpsoracle::ELECTRIC_CONDUCTIVITY];
     }
     return 0;

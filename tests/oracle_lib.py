@@ -164,12 +164,13 @@ class Oracle:
         lib().tpsoracle_get_primitives(self.h, _p(out))
         return out
 
-    def plasma_conductivity(self):
-        """plasma_conductivity_ of SourceTerm from the primitives of the last mult (table gas)"""
+    def plasma_conductivity(self, x):
+        """plasma_conductivity_ of SourceTerm for the state x"""
         out = np.zeros(int(self.ndofs))
         L = lib()
-        L.tpsoracle_get_plasma_conductivity.argtypes = [C.c_void_p, _dp]
-        if L.tpsoracle_get_plasma_conductivity(self.h, _p(out)) != 0:
+        L.tpsoracle_get_plasma_conductivity.argtypes = [C.c_void_p, _dp, _dp]
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        if L.tpsoracle_get_plasma_conductivity(self.h, _p(xx), _p(out)) != 0:
             raise RuntimeError("oracle: " + L.tpsoracle_last_error().decode())
         return out
 

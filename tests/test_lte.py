@@ -328,30 +328,65 @@ def test_oracle_plasma_conductivity_closed_form():
     o.mult(U)
     T = o.primitives()[4]
     want = np.maximum(np.interp(T, Ts, sig), 1.0)
-    got = o.plasma_conductivity()
+    got = o.plasma_conductivity(U)
     assert got == pytest.approx(want, rel=1e-13)
     assert (want > 1.0).any() and (want == 1.0).any()
 
 
 @pytest.mark.gpu
-def test_hip_plasma_conductivity():
+@pytest.mark.parametrize("fluid", ["lte", "ternary_minimal", "ternary_constant_2t", "six_ambipolar_mixture", "ternary_no_reactions"])
+def test_hip_plasma_conductivity(fluid):
+    """SourceTerm's plasma_conductivity_ (src/source_term.cpp:125-199): the table gas, and the mixtures the reference stores it
+    for -- ambipolar ones (test/inputs/argon.plasma.lte2noneq.ini: six species, ambipolar, constant transport) and
+    mixtures without reactions"""
     import torch
     from oracle_lib import Oracle
     from tps_amd.rhs_operator import RHSoperator
 
-    c = cases.lte_axisym(5, 6, 3)
-    _sigma_table(c.physics)
-    U = c.state(seed=8)
+    if fluid == "lte":
+        c = cases.lte_axisym(5, 6, 3)
+        _sigma_table(c.physics)
+        U = c.state(seed=8)
+    else:
+        if fluid == "ternary_minimal":
+            ph = capi.argon_ternary_physics(capi.NS, False, capi.ARGON_MINIMAL, "arrhenius")
+        elif fluid == "ternary_constant_2t":
+            ph = capi.argon_ternary_physics(capi.NS, True, capi.CONSTANT, "arrhenius")
+        elif fluid == "six_ambipolar_mixture":
+            ph = capi.argon_levels_physics(3, True, capi.NS, capi.ARGON_MIXTURE, False, True)
+        else:
+            ph = capi.argon_ternary_physics(capi.NS, False, capi.ARGON_MINIMAL, None, ambipolar=False)
+        ph.gas_transport.multiply = 1  # the mobility multiplier enters (src/gas_transport.cpp:725-736)
+        ph.gas_transport.mobil_mult, ph.gas_transport.diff_mult = 1.7, 0.6
+        c = cases.argon_axisym(5, 6, 2, physics=ph, r_in=0.0)
+        U = c.state(seed=8, amp=0.02)
     o = Oracle(c.mesh, c.disc, c.physics, c.bcs)
-    o.mult(U)
+    want = o.plasma_conductivity(U)
     op = RHSoperator(c.mesh, c.disc, c.physics, c.bcs)
     x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
-    op.Mult(x, torch.empty_like(x))
-    got = op.getPlasmaConductivity().cpu().numpy()
-    assert got == pytest.approx(o.plasma_conductivity(), rel=1e-13)
+    got = op.getPlasmaConductivity(x).cpu().numpy()
+    print(fluid, "sigma", want.min(), want.max(), "rel err", np.abs(got - want).max() / np.abs(want).max())
+    assert want.max() > 0.0
+    # (collision integrals through the device's exp / log, 2-4 ulp each, and a Curtiss-Hirschfelder sum: a few 1e-12)
+    assert got == pytest.approx(want, rel=1e-10)
     op.close()
+
+
+@pytest.mark.gpu
+def test_plasma_conductivity_refusals():
+    import torch
+    from tps_amd.rhs_operator import RHSoperator
+
     d = cases.dry_air_axisym(3, 3, 2)
     op = RHSoperator(d.mesh, d.disc, d.physics, d.bcs)
-    with pytest.raises(Exception, match="table gas"):
-        op.getPlasmaConductivity()
+    x = torch.tensor(np.ascontiguousarray(d.state()).ravel(), dtype=torch.float64, device=op.device)
+    with pytest.raises(Exception, match="no SourceTerm"):
+        op.getPlasmaConductivity(x)
+    op.close()
+    ph = capi.argon_ternary_physics(capi.NS, False, capi.ARGON_MINIMAL, "arrhenius", ambipolar=False)
+    c = cases.argon_axisym(3, 3, 2, physics=ph, r_in=0.0)
+    op = RHSoperator(c.mesh, c.disc, c.physics, c.bcs)
+    x = torch.tensor(np.ascontiguousarray(c.state(amp=0.01)).ravel(), dtype=torch.float64, device=op.device)
+    with pytest.raises(Exception, match="not ambipolar"):
+        op.getPlasmaConductivity(x)
     op.close()

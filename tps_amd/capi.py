@@ -612,7 +612,7 @@ def load():
     lib.tpsrhs_update_gradients.argtypes = [vp, vp]
     lib.tpsrhs_get_primitives.argtypes = [vp, vp]
     lib.tpsrhs_get_gradients.argtypes = [vp, vp]
-    lib.tpsrhs_get_plasma_conductivity.argtypes = [vp, vp]
+    lib.tpsrhs_get_plasma_conductivity.argtypes = [vp, vp, vp]
     lib.tpsrhs_height.restype = C.c_int64
     lib.tpsrhs_height.argtypes = [vp]
     lib.tpsrhs_num_dofs.restype = C.c_int64

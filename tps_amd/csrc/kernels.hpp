@@ -2626,7 +2626,8 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
 }
 
 // Point-wise closures of the gas model for n states U[eq + ...]: U is [NEQ][n] (byNODES), one lane per state
-// (tpsrhs_eval_pointwise).  quantity: 0 primitives -> out[NEQ][n], 1 pressure, 2 speed of sound, 3 |u| + c -> out[n]
+// (tpsrhs_eval_pointwise).  quantity: 0 primitives -> out[NEQ][n], 1 pressure, 2 speed of sound, 3 |u| + c, 4 electric
+// conductivity (tpsrhs_get_plasma_conductivity) -> out[n]
 template <class PH>
 __global__ __launch_bounds__(256) void k_point_eval(typename PH::KArg prm_k, int quantity, int64_t n,
                                                     const double *__restrict__ U, double *__restrict__ out) {
@@ -2646,6 +2647,9 @@ __global__ __launch_bounds__(256) void k_point_eval(typename PH::KArg prm_k, int
     out[i] = PH::pressure(prm, u);
   } else if (quantity == 2) {
     out[i] = PH::sound_speed(prm, u);
+  } else if (quantity == 4) {  // SrcTrns::ELECTRIC_CONDUCTIVITY as SourceTerm stores it (src/source_term.cpp:125-199): clamped species
+    PH::clamp_species(u);
+    out[i] = PH::electric_conductivity(prm, u);
   } else {
     out[i] = PH::max_char_speed(prm, u);
   }

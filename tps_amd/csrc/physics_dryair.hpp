@@ -911,6 +911,7 @@ struct DryAirPhys {
   }
 
   __device__ static inline void source(const Params &, const double *, const double *, const double *, double *) {}
+  __device__ static inline double electric_conductivity(const Params &, const double *) { return 0.0; }  // no SourceTerm for dry air
 };
 
 }  // namespace tpsrhs

@@ -408,6 +408,15 @@ struct GasAxiPhys {
       if (p.radiation == TPSRHS_NET_EMISSION) src[ITH] += -4.0 * kPi * table_eval(p.tab_nec, Up[ITH]);  // src/radiation.hpp:68
     }
   }
+  // SrcTrns::ELECTRIC_CONDUCTIVITY: LteTransport::ComputeSourceMolecularTransport, src/lte_transport_properties.cpp:109-126
+  __device__ static inline double electric_conductivity(const Params &p, const double *U) {
+    if constexpr (LTE_) {
+      const double sigma = table_eval(p.tab_sigma, make_state(p, U).T);
+      return sigma < 1.0 ? 1.0 : sigma;
+    } else {
+      return 0.0;
+    }
+  }
   __device__ static inline void axisym_source(const Params &p, const double *U, const double *Up, const double *g,
                                               double radius, double *src) {
     const double rho = Up[0], ur = Up[1], ut = Up[3];

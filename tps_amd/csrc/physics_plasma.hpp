@@ -771,6 +771,19 @@ struct PlasmaPhys {
 #pragma unroll
     for (int sp = 0; sp < NSP; sp++) V[sp] -= Vc;
   }
+  // SrcTrns::ELECTRIC_CONDUCTIVITY of ComputeSourceTransportProperties: computeMixtureElectricConductivity(mobility, n) *
+  // MOLARELECTRONCHARGE with the mobilities (q_e / k_B) Z_sp D_sp / T of the model's diffusivities -- the same construction
+  // as in the flux transport, multipliers included (src/transport_properties.cpp:421-428, src/gas_transport.cpp:725-739,
+  // 1455-1463).  What SourceTerm stores in plasma_conductivity_ (src/source_term.cpp:184-199).
+  __device__ static inline double electric_conductivity(PRef p, const double *U) {
+    const State s = make_state(p, U);
+    TCoef c;
+    transport_coeffs(p, U, s.Th, s.Te, true, c);
+    double mho = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NSP; sp++) mho += c.mob[sp] * c.n[sp] * p.charge[sp];
+    return mho * kMolarQe;
+  }
   // ComputeFluxTransportProperties: coefficients + the diffusion velocities of every direction
   __device__ static inline void transport(PRef p, const double *U, double Th, double Te, const double *g,
                                           bool diffusion, Trans &t) {

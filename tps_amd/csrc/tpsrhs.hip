@@ -1193,15 +1193,6 @@ int tpsrhs_eval_pointwise(tpsrhs_handle h, int quantity, int64_t n, const double
 }
 
 namespace {
-// LteTransport::ComputeSourceMolecularTransport (src/lte_transport_properties.cpp:109-126) at the nodes: what SourceTerm
-// stores in plasma_conductivity_ (src/source_term.cpp:196)
-__global__ void k_lte_conductivity(TableDev t, int64_t n, const double *__restrict__ T, double *__restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i < n) {
-    const double sigma = table_eval(t, T[i]);
-    out[i] = sigma < 1.0 ? 1.0 : sigma;
-  }
-}
 __global__ void k_table_eval(TableDev t, int64_t n, const double *__restrict__ x, double *__restrict__ f) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i < n) f[i] = table_eval(t, x[i]);
@@ -1313,17 +1304,15 @@ const char *tpsrhs_status_string(int status) {
   }
 }
 const char *tpsrhs_last_error(void) { return g_last_error.c_str(); }
-int tpsrhs_get_plasma_conductivity(tpsrhs_handle h, double *sigma_out) {
-  if (!h || !sigma_out) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_get_plasma_conductivity: NULL argument");
+int tpsrhs_get_plasma_conductivity(tpsrhs_handle h, const double *x, double *sigma_out) {
+  if (!h || !x || !sigma_out) return fail(TPSRHS_ERR_INVALID_ARGUMENT, "tpsrhs_get_plasma_conductivity: NULL argument");
   return guarded([&] {
-    if (h->phys.working_fluid != TPSRHS_LTE_FLUID)
-      throw Unsupported("plasma conductivity output: built for the table gas (fluid = lte_table)");
+    if (h->phys.working_fluid == TPSRHS_DRY_AIR) throw Unsupported("plasma conductivity output: dry air has no SourceTerm");
+    if (h->phys.working_fluid == TPSRHS_USER_DEFINED && !h->phys.mixture.ambipolar && h->phys.chemistry.num_reactions > 0)
+      throw Unsupported("plasma conductivity output: the reference's SourceTerm does not store it for a reacting mixture that "
+                        "is not ambipolar (src/source_term.cpp:178-197)");
     HIP_CHECK(hipSetDevice(h->device));
-    const LteParams &lp = *reinterpret_cast<const LteParams *>(h->params);
-    const double *T = h->d_Up + static_cast<int64_t>(h->nvel + 1) * h->ndofs;  // the temperature row of the last primitives
-    hipLaunchKernelGGL(k_lte_conductivity, dim3(static_cast<unsigned>((h->ndofs + 255) / 256)), dim3(256), 0, h->stream, lp.tab_sigma,
-                       h->ndofs, T, sigma_out);
-    HIP_CHECK(hipGetLastError());
+    h->point_eval(h, 4, h->ndofs, x, sigma_out);
   });
 }
 

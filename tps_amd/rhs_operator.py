@@ -113,11 +113,12 @@ class RHSoperator:
             raise TpsRhsError(st, "tpsrhs_get_gradients")
         return out.view(self.dim, self.num_equation, self.NDofs)
 
-    def getPlasmaConductivity(self) -> torch.Tensor:
-        """``plasma_conductivity_`` of ``SourceTerm`` (``src/source_term.cpp:184,196``): sigma at the nodes from the
-        primitives of the last ``Mult`` -- what the EM solver of the coupled torch runs reads (table gas only, for now)."""
+    def getPlasmaConductivity(self, x: torch.Tensor) -> torch.Tensor:
+        """``plasma_conductivity_`` of ``SourceTerm`` (``src/source_term.cpp:125-199``): sigma at the nodes of the state
+        ``x`` -- what the EM solver of the coupled torch runs reads (mixtures and the table gas)."""
+        self._check(x)
         out = torch.empty(self.NDofs, dtype=torch.float64, device=self.device)
-        st = self._lib.tpsrhs_get_plasma_conductivity(self._h, C.c_void_p(out.data_ptr()))
+        st = self._lib.tpsrhs_get_plasma_conductivity(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()))
         if st != 0:
             raise TpsRhsError(st, "tpsrhs_get_plasma_conductivity")
         return out
