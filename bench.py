@@ -134,10 +134,18 @@ def lib_sha16():
 
         from tps_amd import capi
 
+        # the core library and every kernel-family shared object it can load (its own directory, and the
+        # directories of TPSRHS_FAMILY_PATH, which come first)
+        import glob
+
+        libs = [capi.LIB_PATH]
+        for d in [p for p in os.environ.get("TPSRHS_FAMILY_PATH", "").split(":") if p] + [os.path.dirname(capi.LIB_PATH)]:
+            libs += sorted(glob.glob(os.path.join(d, "libtpsrhs_plasma_*.so")))
         h = hashlib.sha256()
-        with open(capi.LIB_PATH, "rb") as f:
-            for chunk in iter(lambda: f.read(1 << 22), b""):
-                h.update(chunk)
+        for lib in libs:
+            with open(lib, "rb") as f:
+                for chunk in iter(lambda: f.read(1 << 22), b""):
+                    h.update(chunk)
         _LIB_SHA.append(h.hexdigest()[:16])
     return _LIB_SHA[0]
 

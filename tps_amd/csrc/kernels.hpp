@@ -77,6 +77,15 @@ struct Stamper {
   }
 };
 #endif
+// Diagnostic builds only (-DTPSRHS_DUMPF=1, tools/probe_dumpf.py): the nodal flux and the point sources of every block of the
+// last k_flux launch of this translation unit, copied from LDS / registers into a __device__ array that no kernel reads.
+#ifndef TPSRHS_DUMPF
+#define TPSRHS_DUMPF 0
+#endif
+#if TPSRHS_DUMPF
+constexpr int DUMPF_MAX = 1 << 22;
+static __device__ double g_dumpf[DUMPF_MAX];
+#endif
 #if TPSRHS_STAMP == 1  // k_gradient
 #define STAMP_DECL Stamper stamper
 #define STAMP_ARG , stamper
@@ -2513,6 +2522,17 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   }
   block_sync<C::BLOCK>();  // sGf complete
   FSTAMP(2);
+#if TPSRHS_DUMPF
+  if (tid < C::NODES) {  // [block][F (NEQ*DIM) | src (NEQ)][NODES]
+    constexpr int ROWS = NEQ * DIM + NEQ;
+    if ((static_cast<int64_t>(bid) + 1) * ROWS * C::NODES <= DUMPF_MAX) {
+      double *out = g_dumpf + static_cast<int64_t>(bid) * ROWS * C::NODES + tid;
+      for (int k = 0; k < NEQ * DIM; k++) out[k * C::NODES] = sGf[k * C::NODES + tid];
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) out[(NEQ * DIM + eq) * C::NODES] = src[eq];
+    }
+  }
+#endif
 
   // ---- volume term: z_j = sum_m sum_a D[a][j_m] Ghat_m(a)   (src/domain_integrator.cpp:45-99)
   double z[NEQ];

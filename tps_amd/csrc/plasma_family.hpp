@@ -75,8 +75,38 @@ extern "C" int tpsrhs_debug_stamps(unsigned int *out, int nblocks) {
 }
 #endif
 
-#define TPSRHS_PLASMA_FAMILY(name, DIM, NVEL, NSP, AMBI)                          \
-  void name(tpsrhs_operator *op, bool two_temperature, int transport) {           \
-    pick_plasma_family<DIM, NVEL, NSP, AMBI>(op, two_temperature, transport);     \
+#if TPSRHS_DUMPF
+// diagnostic builds (one translation unit compiled with -DTPSRHS_DUMPF=1): what the last k_flux of this unit left
+extern "C" int tpsrhs_debug_dumpf(double *out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(tpsrhs::g_dumpf), static_cast<size_t>(n) * sizeof(double)) == hipSuccess ? 0 : 1;
+}
+#endif
+
+// One family = one shared object, libtpsrhs_<unit>.so, that the core library loads on demand (tpsrhs.hip::load_family).
+// The entry point is C: no exception crosses the boundary, a refusal comes back as a status code and a message.
+#define TPSRHS_PLASMA_FAMILY(name, DIM, NVEL, NSP, AMBI)                                                              \
+  extern "C" int name(tpsrhs_operator *op, int two_temperature, int transport, char *err, int errlen) {               \
+    auto say = [&](const char *what) {                                                                                \
+      if (err && errlen > 0) {                                                                                        \
+        std::strncpy(err, what, static_cast<size_t>(errlen) - 1);                                                     \
+        err[errlen - 1] = 0;                                                                                          \
+      }                                                                                                               \
+    };                                                                                                                \
+    try {                                                                                                             \
+      pick_plasma_family<DIM, NVEL, NSP, AMBI>(op, two_temperature != 0, transport);                                  \
+      return TPSRHS_OK;                                                                                               \
+    } catch (const Unsupported &e) {                                                                                  \
+      say(e.what());                                                                                                  \
+      return TPSRHS_ERR_UNSUPPORTED;                                                                                  \
+    } catch (const DeviceError &e) {                                                                                  \
+      say(e.what());                                                                                                  \
+      return TPSRHS_ERR_DEVICE;                                                                                       \
+    } catch (const std::invalid_argument &e) {                                                                        \
+      say(e.what());                                                                                                  \
+      return TPSRHS_ERR_INVALID_ARGUMENT;                                                                             \
+    } catch (const std::exception &e) {                                                                               \
+      say(e.what());                                                                                                  \
+      return TPSRHS_ERR_DEVICE;                                                                                       \
+    }                                                                                                                 \
   }
 #endif

@@ -8,20 +8,16 @@
 #include "physics_dryair_axisym.hpp"
 #include "physics_plasma.hpp"
 
+#include <dlfcn.h>
+
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <new>
 #include <thread>
 
-// kernel families instantiated in their own translation units (plasma_family.hpp)
-#define DECL(name) void name(tpsrhs_operator *op, bool two_temperature, int transport)
-DECL(pick_plasma_3d_n3a); DECL(pick_plasma_3d_n3); DECL(pick_plasma_3d_n4a); DECL(pick_plasma_3d_n4); DECL(pick_plasma_3d_n5a); DECL(pick_plasma_3d_n5); DECL(pick_plasma_3d_n6a); DECL(pick_plasma_3d_n6); DECL(pick_plasma_3d_n7a); DECL(pick_plasma_3d_n7); DECL(pick_plasma_3d_n8a); DECL(pick_plasma_3d_n8);
-DECL(pick_plasma_2d_n3a); DECL(pick_plasma_2d_n3); DECL(pick_plasma_2d_n4a); DECL(pick_plasma_2d_n4); DECL(pick_plasma_2d_n5a); DECL(pick_plasma_2d_n5); DECL(pick_plasma_2d_n6a); DECL(pick_plasma_2d_n6); DECL(pick_plasma_2d_n7a); DECL(pick_plasma_2d_n7); DECL(pick_plasma_2d_n8a); DECL(pick_plasma_2d_n8);
-DECL(pick_plasma_axi_n3a); DECL(pick_plasma_axi_n3); DECL(pick_plasma_axi_n4a); DECL(pick_plasma_axi_n4); DECL(pick_plasma_axi_n5a); DECL(pick_plasma_axi_n5); DECL(pick_plasma_axi_n6a); DECL(pick_plasma_axi_n6); DECL(pick_plasma_axi_n7a); DECL(pick_plasma_axi_n7); DECL(pick_plasma_axi_n8a); DECL(pick_plasma_axi_n8);
-// polynomial orders 4 and 5 (the `_hi` translation units)
-DECL(pick_plasma_3d_n3a_hi); DECL(pick_plasma_3d_n3_hi); DECL(pick_plasma_3d_n4a_hi); DECL(pick_plasma_3d_n4_hi); DECL(pick_plasma_3d_n5a_hi); DECL(pick_plasma_3d_n5_hi); DECL(pick_plasma_3d_n6a_hi); DECL(pick_plasma_3d_n6_hi); DECL(pick_plasma_3d_n7a_hi); DECL(pick_plasma_3d_n7_hi); DECL(pick_plasma_3d_n8a_hi); DECL(pick_plasma_3d_n8_hi);
-DECL(pick_plasma_2d_n3a_hi); DECL(pick_plasma_2d_n3_hi); DECL(pick_plasma_2d_n4a_hi); DECL(pick_plasma_2d_n4_hi); DECL(pick_plasma_2d_n5a_hi); DECL(pick_plasma_2d_n5_hi); DECL(pick_plasma_2d_n6a_hi); DECL(pick_plasma_2d_n6_hi); DECL(pick_plasma_2d_n7a_hi); DECL(pick_plasma_2d_n7_hi); DECL(pick_plasma_2d_n8a_hi); DECL(pick_plasma_2d_n8_hi);
-DECL(pick_plasma_axi_n3a_hi); DECL(pick_plasma_axi_n3_hi); DECL(pick_plasma_axi_n4a_hi); DECL(pick_plasma_axi_n4_hi); DECL(pick_plasma_axi_n5a_hi); DECL(pick_plasma_axi_n5_hi); DECL(pick_plasma_axi_n6a_hi); DECL(pick_plasma_axi_n6_hi); DECL(pick_plasma_axi_n7a_hi); DECL(pick_plasma_axi_n7_hi); DECL(pick_plasma_axi_n8a_hi); DECL(pick_plasma_axi_n8_hi);
-#undef DECL
+// The plasma kernel families (plasma_family.hpp) are shared objects of their own, libtpsrhs_<unit>.so next to this library,
+// loaded when an operator of that family is created: load_family below.
 void pick_dryair_axisym(tpsrhs_operator *op);
 void pick_lte_axisym(tpsrhs_operator *op);
 void pick_dryair_les(tpsrhs_operator *op);
@@ -29,6 +25,52 @@ void pick_dryair_les(tpsrhs_operator *op);
 static thread_local std::string g_last_error;
 
 namespace {
+
+// One shared object per plasma kernel family -- (geometry, species count, ambipolar or not, orders 1..3 or 4..5):
+// libtpsrhs_plasma_<geo>_n<species>[a][_hi].so in the directory of this library, or in a directory of the colon-separated
+// TPSRHS_FAMILY_PATH (development: A/B builds of one family).  dlopen'ed at the first operator that needs it and kept
+// for the life of the process (the operator holds pointers to its launch functions).  The entry point is C and
+// returns a status: no exception crosses the boundary.  A missing family is a loud error, never another code path.
+typedef int (*family_pick_fn)(tpsrhs_operator *, int, int, char *, int);
+family_pick_fn load_family(const std::string &unit) {
+  static std::mutex mu;
+  static std::map<std::string, family_pick_fn> loaded;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = loaded.find(unit);
+  if (it != loaded.end()) return it->second;
+  std::vector<std::string> dirs;
+  if (const char *env = std::getenv("TPSRHS_FAMILY_PATH")) {
+    std::string e(env);
+    size_t pos = 0;
+    while (pos <= e.size()) {
+      const size_t c = e.find(':', pos);
+      const std::string d = e.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+      if (!d.empty()) dirs.push_back(d);
+      if (c == std::string::npos) break;
+      pos = c + 1;
+    }
+  }
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void *>(&load_family), &info) && info.dli_fname) {
+    const std::string self(info.dli_fname);
+    const size_t slash = self.rfind('/');
+    dirs.push_back(slash == std::string::npos ? std::string(".") : self.substr(0, slash));
+  }
+  std::string tried;
+  for (const std::string &d : dirs) {
+    const std::string path = d + "/libtpsrhs_" + unit + ".so";
+    if (void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL)) {
+      const std::string sym = "pick_" + unit;
+      auto fn = reinterpret_cast<family_pick_fn>(dlsym(h, sym.c_str()));
+      if (!fn) throw std::runtime_error(path + " does not export " + sym);
+      loaded[unit] = fn;
+      return fn;
+    }
+    const char *why = dlerror();
+    tried += "\n  " + path + ": " + (why ? why : "not loadable");
+  }
+  throw Unsupported("kernel family " + unit + " is not available (run __graft_entry__.build()):" + tried);
+}
 
 // LinearTable::LinearTable (src/table.cpp:39-50): interval coefficients, uploaded with the abscissae
 TableDev upload_table(tpsrhs_operator *op, const tpsrhs_table &t) {
@@ -483,24 +525,16 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
     const int tr = (phys->transport_model == TPSRHS_CONSTANT)
                        ? TRANSPORT_CONSTANT
                        : (phys->transport_model == TPSRHS_ARGON_MINIMAL ? TRANSPORT_ARGON_MINIMAL : TRANSPORT_ARGON_MIXTURE);
-    typedef void (*pick_fn)(tpsrhs_operator *, bool, int);
-    // one translation unit per (geometry, species count, ambipolar) family, and a second one for the polynomial orders
+    // one shared object per (geometry, species count, ambipolar) family, and a second one for the polynomial orders
     // 4 and 5: every species count up to MAXSPECIES = 8 (MAXEQUATIONS = 13) of the reference's device build
     // (src/dataStructures.hpp:41-65), ambipolar or not
-    const pick_fn table[3][12] = {
-        {pick_plasma_3d_n3a, pick_plasma_3d_n3, pick_plasma_3d_n4a, pick_plasma_3d_n4, pick_plasma_3d_n5a, pick_plasma_3d_n5, pick_plasma_3d_n6a, pick_plasma_3d_n6, pick_plasma_3d_n7a, pick_plasma_3d_n7, pick_plasma_3d_n8a, pick_plasma_3d_n8},
-        {pick_plasma_2d_n3a, pick_plasma_2d_n3, pick_plasma_2d_n4a, pick_plasma_2d_n4, pick_plasma_2d_n5a, pick_plasma_2d_n5, pick_plasma_2d_n6a, pick_plasma_2d_n6, pick_plasma_2d_n7a, pick_plasma_2d_n7, pick_plasma_2d_n8a, pick_plasma_2d_n8},
-        {pick_plasma_axi_n3a, pick_plasma_axi_n3, pick_plasma_axi_n4a, pick_plasma_axi_n4, pick_plasma_axi_n5a, pick_plasma_axi_n5, pick_plasma_axi_n6a, pick_plasma_axi_n6, pick_plasma_axi_n7a, pick_plasma_axi_n7, pick_plasma_axi_n8a, pick_plasma_axi_n8}};
-    const pick_fn table_hi[3][12] = {
-        {pick_plasma_3d_n3a_hi, pick_plasma_3d_n3_hi, pick_plasma_3d_n4a_hi, pick_plasma_3d_n4_hi, pick_plasma_3d_n5a_hi, pick_plasma_3d_n5_hi, pick_plasma_3d_n6a_hi, pick_plasma_3d_n6_hi, pick_plasma_3d_n7a_hi, pick_plasma_3d_n7_hi, pick_plasma_3d_n8a_hi, pick_plasma_3d_n8_hi},
-        {pick_plasma_2d_n3a_hi, pick_plasma_2d_n3_hi, pick_plasma_2d_n4a_hi, pick_plasma_2d_n4_hi, pick_plasma_2d_n5a_hi, pick_plasma_2d_n5_hi, pick_plasma_2d_n6a_hi, pick_plasma_2d_n6_hi, pick_plasma_2d_n7a_hi, pick_plasma_2d_n7_hi, pick_plasma_2d_n8a_hi, pick_plasma_2d_n8_hi},
-        {pick_plasma_axi_n3a_hi, pick_plasma_axi_n3_hi, pick_plasma_axi_n4a_hi, pick_plasma_axi_n4_hi, pick_plasma_axi_n5a_hi, pick_plasma_axi_n5_hi, pick_plasma_axi_n6a_hi, pick_plasma_axi_n6_hi, pick_plasma_axi_n7a_hi, pick_plasma_axi_n7_hi, pick_plasma_axi_n8a_hi, pick_plasma_axi_n8_hi}};
-    const int geo = (op->dim == 3) ? 0 : (disc->axisymmetric ? 2 : 1);
-    const int fam = 2 * (nsp - 3) + (ambi ? 0 : 1);
-    if (op->order >= 4 && !op->nc)
-      table_hi[geo][fam](op, two_t, tr);
-    else
-      table[geo][fam](op, two_t, tr);
+    const char *geo = (op->dim == 3) ? "3d" : (disc->axisymmetric ? "axi" : "2d");
+    const std::string unit = std::string("plasma_") + geo + "_n" + std::to_string(nsp) + (ambi ? "a" : "") + ((op->order >= 4 && !op->nc) ? "_hi" : "");
+    char msg[512] = {0};
+    const int rc = load_family(unit)(op, two_t ? 1 : 0, tr, msg, static_cast<int>(sizeof msg));
+    if (rc == TPSRHS_ERR_UNSUPPORTED) throw Unsupported(msg);
+    if (rc == TPSRHS_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+    if (rc != TPSRHS_OK) throw DeviceError(msg);
   } else {
     // (the table gas extends the dry-air block: boundary conditions and switches are shared)
     static_assert(sizeof(LteParams) <= sizeof(op->params), "parameter block");
