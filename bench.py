@@ -12,12 +12,14 @@ configs[1]/[2] per GPU.  Workloads:
                   6 equations, 3 211 264 nodes
   cfg2            configs[1]: perfect-gas Navier-Stokes, p=3, 5 equations, 3 211 264 nodes
   cfg3            configs[2] itself: the same plasma at p=2
-  cfg5            configs[4] on one GPU: axisymmetric 400x500 quads, p=3, two-temperature argon plasma with
-                  constant transport, reactions and the NEC radiation source, 7 equations
+  cfg5            configs[4] on one GPU: axisymmetric 400x500 quads, p=3, two-temperature argon plasma with the
+                  argon mixture (collision-integral) transport, reactions and the NEC radiation source, 7 equations;
+                  cfg5_const: the same with constant transport (what rounds 1-3 reported as cfg5)
   gll_dry, gll_argon   cfg2 / argon_p3 on the reference's DEFAULT pair (Gauss-Lobatto basis + rules, src/M2ulPhyS.cpp:
                   2671-2672): volume operators through the quadrature points, dense 32 KB inverse mass per hex
   torch6          the mixture of the reference's torch input (plasma.ini): six species, two temperatures, not
-                  ambipolar, 11 equations, on the axisymmetric 400x500 mesh of cfg5
+                  ambipolar, 11 equations, constant transport as in that input, on the axisymmetric 400x500 mesh of
+                  cfg5; torch6_mix: the same mixture with the argon mixture transport
   lte_torch       the table gas of the reference's LTE torch inputs (plasma.lte1d.ini: fluid = lte_table, one-dimensional
                   tables, radiation sink, viscosity-multiplier function), 5 equations, on the same mesh
 At N = 1 the JSON line also carries the workloads that were not selected, under `other_workloads`.
@@ -87,25 +89,33 @@ def workload(name):
                 "collision-integral transport with 3rd-order electron conductivity, 2 Arrhenius reactions, inlet "
                 f"SUB_DENS_VEL / outlet SUB_P / isothermal wall ({what})",
                 lambda order: cases.argon_cyl3d(7, 28, 4, order))
-    if name == "cfg5":
-        ph = capi.argon_ternary_physics(capi.NS, True, capi.CONSTANT, "tabulated", radiation=True)
-        return (3, ph, lambda p: cases.argon_axisym(2, 2, 3).bcs,
+    if name in ("cfg5", "cfg5_const"):
+        # configs[4]: "full reacting RHS + transport + radiation source" -- the collision-integral transport of a mixture
+        # (GasMixtureTransport, third-order electron conductivity; SURVEY.md 8d: "ConstantTransport -> then
+        # GasMixtureTransport"); cfg5_const keeps the constant-transport variant rounds 1-3 reported as cfg5
+        tr = capi.CONSTANT if name == "cfg5_const" else capi.ARGON_MIXTURE
+        mk = lambda: capi.argon_ternary_physics(capi.NS, True, tr, "tabulated", radiation=True)  # noqa: E731
+        return (3, mk(), lambda p: cases.argon_axisym(2, 2, 3, physics=p).bcs,
                 lambda X, p: cases.plasma_state(X, p, nvel=3, seed=12345, amp=0.05, vel0=(1.0, 20.0, 3.0)),
-                "AXISYMMETRIC (r, z) 400x500 quads, two-temperature argon ternary plasma, constant transport, "
-                "ionisation / three-body recombination on the reference's rate tables (test/inputs/rate-coefficients), "
+                "AXISYMMETRIC (r, z) 400x500 quads, two-temperature argon ternary plasma, "
+                + ("constant transport, " if name == "cfg5_const" else "argon mixture transport (collision integrals, 3rd-order electron conductivity), ")
+                + "ionisation / three-body recombination on the reference's rate tables (test/inputs/rate-coefficients), "
                 "its net-emission table (rad-data/nec_sample.0.h5), inlet / outlet / isothermal wall / axis "
                 "(BASELINE.json configs[4] on one GPU)",
-                lambda order: cases.argon_axisym(40, 50, order))
-    if name == "torch6":
-        ph = capi.argon_six_species_physics(capi.NS, capi.CONSTANT, True, "tabulated", radiation=True)
-        return (3, ph, lambda p: cases.argon_axisym(2, 2, 3, physics=p).bcs,
+                lambda order: cases.argon_axisym(40, 50, order, physics=mk()))
+    if name in ("torch6", "torch6_mix"):
+        # torch6: the reference's torch input as it is (test/inputs/plasma.ini:163: transport_model = constant);
+        # torch6_mix: the same mixture with the argon mixture transport (GasMixtureTransport)
+        tr = capi.ARGON_MIXTURE if name == "torch6_mix" else capi.CONSTANT
+        mk = lambda: capi.argon_six_species_physics(capi.NS, tr, True, "tabulated", radiation=True)  # noqa: E731
+        return (3, mk(), lambda p: cases.argon_axisym(2, 2, 3, physics=p).bcs,
                 lambda X, p: cases.plasma_state(X, p, nvel=3, seed=12345, amp=0.05, vel0=(1.0, 20.0, 3.0)),
                 "AXISYMMETRIC (r, z) 400x500 quads, the six-species two-temperature argon mixture of the reference's "
                 "torch input (test/inputs/plasma.ini: Ar.+1, Ar_m, Ar_r, Ar_p, E, Ar; not ambipolar; 11 equations), "
-                "constant transport, the 14 tabulated electron-impact reactions of test/inputs/input.radDecay.ini on the "
+                + ("argon mixture transport, " if name == "torch6_mix" else "constant transport (plasma.ini:163), ")
+                + "the 14 tabulated electron-impact reactions of test/inputs/input.radDecay.ini on the "
                 "reference's rate tables, its net-emission table",
-                lambda order: cases.argon_axisym(40, 50, order, physics=capi.argon_six_species_physics(
-                    capi.NS, capi.CONSTANT, True, "tabulated", radiation=True)))
+                lambda order: cases.argon_axisym(40, 50, order, physics=mk()))
     if name == "lte_torch":
         def lte():
             ph = capi.lte_physics(capi.NS, "rho0p255", radiation=True)
@@ -194,7 +204,7 @@ def main():
     ap.add_argument("--ntheta", type=int, default=112)
     ap.add_argument("--nz", type=int, default=16)
     ap.add_argument("--order", type=int, default=0, help="override the workload's polynomial order")
-    ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3", "cfg4", "cfg5", "torch6", "gll_dry", "gll_argon", "lte_torch"])
+    ap.add_argument("--workload", default="argon_p3", choices=["argon_p3", "cfg2", "cfg3", "cfg4", "cfg5", "cfg5_const", "torch6", "torch6_mix", "gll_dry", "gll_argon", "lte_torch"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the multi-rank path on a one-GPU box (traces staged via host)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses device 0")
@@ -241,7 +251,7 @@ def main():
         """-> the JSON fields of one workload (rank 0; None elsewhere)"""
         order, physics, make_bcs, make_state, description, sample_case = workload(wname)
         order = args.order or order
-        axisym = wname in ("cfg5", "torch6", "lte_torch")
+        axisym = wname in ("cfg5", "cfg5_const", "torch6", "torch6_mix", "lte_torch")
         strong = wname == "cfg4"
         if axisym:  # (r, z) tube 0.05 x 0.25 per rank, 400 x 500 quads; axial slabs at N > 1 (weak scaling)
             mesh = meshgen.annulus_quad_slab(400, 500, rank, world, r_in=0.0, r_out=0.05, length_local=0.25)
@@ -389,7 +399,7 @@ def main():
     r = run(args.workload, args.steps, args.warmup)
     others = {}
     if world == 1 and not args.no_other_workloads:
-        for wname in ("argon_p3", "cfg2", "cfg3", "cfg5", "torch6", "gll_dry", "lte_torch"):
+        for wname in ("argon_p3", "cfg2", "cfg3", "cfg5", "cfg5_const", "torch6", "torch6_mix", "gll_dry", "lte_torch"):
             if wname != args.workload:
                 # the same K timed steps as the headline and at least 10 warm-ups: comparable round to round and
                 # with the profiles/ of the same command

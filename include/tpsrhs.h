@@ -244,8 +244,9 @@ typedef struct tpsrhs_visc_sponge { /* viscositySpongeData (src/M2ulPhyS.cpp:583
  * table T(e) is the energy table with abscissae and values swapped, as the reference builds it (:193-200), so the
  * energies must increase with the temperature.  The two-dimensional (T, rho) tables of the reference's CPU build
  * interpolate with GSL (third party, `flow/lte/table_dim = 2`) and are not built.  The radiation sink of SourceTerm
- * (src/source_term.cpp:207-209) is tpsrhs_physics::radiation; the electric conductivity table is carried for the
- * plasma-conductivity side output of SourceTerm (:196), which this library does not produce yet.
+ * (src/source_term.cpp:207-209) is tpsrhs_physics::radiation; the electric conductivity table feeds the
+ * plasma-conductivity side output of SourceTerm (:196): tpsrhs_get_plasma_conductivity.  Every table must have linear
+ * scales (x_log_scale = f_log_scale = 0, as the reference hard-codes): TPSRHS_ERR_INVALID_ARGUMENT otherwise.
  * Built for the axisymmetric formulation (the reference's LTE inputs, test/inputs/plasma.lte1d.ini), Gauss-Legendre
  * pair; anything else: TPSRHS_ERR_UNSUPPORTED. */
 typedef struct tpsrhs_lte { /* LteMixtureInput + the TableInputs of src/M2ulPhyS.cpp:176-255 */

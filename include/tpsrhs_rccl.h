@@ -43,7 +43,9 @@ int tpsrhs_rccl_reduce(void *ctx, double *values, int count, int op, void *strea
 int tpsrhs_rccl_stats(const tpsrhs_rccl_ctx *ctx, int64_t *halo_calls, int64_t *bytes_sent, int *peers_seen);
 int tpsrhs_rccl_set_skip(tpsrhs_rccl_ctx *ctx, int skip);
 /* ncclCommCount of the exchange communicator (the number of ranks RCCL itself sees), and whether the scalar
- * reductions run on a communicator of their own (ncclCommSplit at creation) or share the exchange's. */
+ * reductions run on a communicator of their own or share the exchange's (the default).  The second communicator is
+ * opt-in: TPSRHS_RCCL_SPLIT=1 in the environment of EVERY rank (ncclCommSplit is collective); the ranks then agree on the
+ * outcome -- all split, or all shared -- before tpsrhs_rccl_create returns. */
 int tpsrhs_rccl_comm_info(const tpsrhs_rccl_ctx *ctx, int *nranks, int *reduce_comm_is_separate);
 const char *tpsrhs_rccl_last_error(void);
 

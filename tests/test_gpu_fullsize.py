@@ -101,7 +101,7 @@ def _bench_axisym(wname, nz, length):
     return mesh, disc, ph, make_bcs(ph), make_state(X, ph), order
 
 
-@pytest.mark.parametrize("wname", ["cfg5", "torch6", "lte_torch"])
+@pytest.mark.parametrize("wname", ["cfg5", "cfg5_const", "torch6", "torch6_mix", "lte_torch"])
 def test_full_size_axisymmetric_layers_reproduce_the_oracle_checked_strip(wname):
     """Axial-translation invariance.  The tube is extruded along z between the inlet (z = 0) and the outlet (z = L);
     for a state that depends on r only, every layer of elements whose stencil does not reach those two patches -- the
@@ -126,3 +126,21 @@ def test_full_size_axisymmetric_layers_reproduce_the_oracle_checked_strip(wname)
         ks = k if k < 2 else (NZS - (NZF - k) if k >= NZF - 2 else 3)
         assert (np.abs(lay(full["y"], k) - lay(small["y"], ks)) <= tol).all(), (k, ks)
     assert np.isfinite(full["y"]).all()
+
+
+def test_config1_at_its_own_size_against_the_oracle():
+    """BASELINE.json configs[0] itself -- cyl3d perfect-gas Euler, p = 1, 10 x 24 x 8 = 1 920 hexes, the reference's
+    CPU-runnable plumbing case -- directly against the oracle (which does it in under a second): y, Up, gradUp and the
+    maximum characteristic speed of one Mult."""
+    c = cases.config(1)
+    assert c.mesh.num_elements == 1920
+    U = c.state(seed=12345)
+    got = hip_mult(c.mesh, c.disc, c.physics, c.bcs, U)
+    ref = oracle_mult(c.mesh, c.disc, c.physics, c.bcs, U)
+    err = rel_maxnorm(got["y"], ref["y"])
+    print("cfg1 at 1 920 hexes: y", err, "Up", rel_maxnorm(got["Up"], ref["Up"]).max())
+    assert err.max() < RHS_RTOL
+    assert rel_maxnorm(got["Up"], ref["Up"]).max() < 1e-13
+    g_ref = ref["gradUp"].reshape(-1, U.shape[1])
+    assert np.abs(got["gradUp"].reshape(-1, U.shape[1]) - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
+    assert abs(got["max_char_speed"] - ref["max_char_speed"]) <= 1e-12 * ref["max_char_speed"]

@@ -431,7 +431,7 @@ def test_plasma_orders_four_five(geo, order, nsp, two_t, transport):
     _compare(c.mesh, c.disc, c.physics, c.bcs, c.state(seed=23, amp=0.01), tol=_tol(0.01))
 
 
-@pytest.mark.parametrize("wname", ["cfg5", "torch6", "lte_torch"])
+@pytest.mark.parametrize("wname", ["cfg5", "cfg5_const", "torch6", "torch6_mix", "lte_torch"])
 def test_bench_axisymmetric_workloads_exact_physics(wname):
     """the physics, boundary conditions and state generator of bench.py's cfg5 (BASELINE.json configs[4]: ternary,
     two temperatures, axisymmetric, constant transport, the reference's rate tables + NEC table) and torch6 (six

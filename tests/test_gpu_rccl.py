@@ -3,6 +3,7 @@ to run the library's own code -- unique id, ncclCommInitRank, a grouped ncclSend
 (a rank may exchange with itself), ncclAllReduce, the counters -- through the same function pointers the operator
 calls.  The partitioned operator over RCCL needs one GPU per rank: tests/test_gpu_multirank.py (skipped below that)."""
 import ctypes as C
+import os
 import socket
 
 import numpy as np
@@ -49,8 +50,8 @@ def test_one_rank_communicator_moves_segments_and_reduces():
         s = halo.stats()
         assert {k: s[k] for k in ("halo_calls", "bytes_sent", "peers_seen", "nranks")} == {
             "halo_calls": 1, "bytes_sent": 8 * n, "peers_seen": 1, "nranks": 1}  # nranks = ncclCommCount
-        # the reductions ran on a communicator of their own (ncclCommSplit), not on the exchange's
-        assert s["reduce_comm"].startswith("own communicator")
+        # default: the reductions share the exchange's communicator (the second one is opt-in, TPSRHS_RCCL_SPLIT=1)
+        assert s["reduce_comm"].startswith("shared")
         halo.skip = True
         recv.zero_()
         assert halo.c_halo(halo.ctx, 1, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), 2, ranks, soff, roff,
@@ -58,5 +59,17 @@ def test_one_rank_communicator_moves_segments_and_reduces():
         side.synchronize()
         assert float(recv.abs().max()) == 0.0 and halo.stats()["halo_calls"] == 1
         halo.close()
+        # opt-in: a communicator of their own for the reductions, agreed on by every rank (here: one) before create returns
+        os.environ["TPSRHS_RCCL_SPLIT"] = "1"
+        try:
+            halo2 = RcclHalo(0)
+            v2 = torch.tensor([1.0, 2.0], dtype=torch.float64, device="cuda")
+            assert halo2.c_reduce(halo2.ctx, C.c_void_p(v2.data_ptr()), 2, 0, C.c_void_p(side.cuda_stream)) == 0
+            side.synchronize()
+            assert v2.cpu().tolist() == [1.0, 2.0]
+            assert halo2.stats()["reduce_comm"].startswith("own communicator")
+            halo2.close()
+        finally:
+            del os.environ["TPSRHS_RCCL_SPLIT"]
     finally:
         dist.destroy_process_group()

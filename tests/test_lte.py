@@ -367,8 +367,9 @@ def test_hip_plasma_conductivity(fluid):
     got = op.getPlasmaConductivity(x).cpu().numpy()
     print(fluid, "sigma", want.min(), want.max(), "rel err", np.abs(got - want).max() / np.abs(want).max())
     assert want.max() > 0.0
-    # (collision integrals through the device's exp / log, 2-4 ulp each, and a Curtiss-Hirschfelder sum: a few 1e-12)
-    assert got == pytest.approx(want, rel=1e-10)
+    # (collision integrals through the device's exp / log, 2-4 ulp each, and a Curtiss-Hirschfelder sum: 3.6e-12 ... 4.9e-12
+    #  measured in round 3; the bound is four times that, not two orders of magnitude)
+    assert got == pytest.approx(want, rel=2e-11)
     op.close()
 
 

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <string>
@@ -64,14 +65,41 @@ int tpsrhs_rccl_create(const void *id, int nranks, int rank, int device, tpsrhs_
     return fail("ncclCommInitRank", r);
   }
   // Operations on ONE communicator are serialised by RCCL whatever stream they are enqueued on; the boundary-mean /
-  // dt reductions run on the compute stream while the trace exchange runs on the communication stream, so they get
-  // a communicator of their own (ncclCommSplit: same ranks, same order).  Should the split be refused the reductions
-  // share the exchange's communicator as in round 2 (correct, less overlap); tpsrhs_rccl_comm_info reports which.
+  // dt reductions run on the compute stream while the trace exchange runs on the communication stream.  A communicator
+  // of their own (ncclCommSplit: same ranks, same order) lifts that ordering -- but two communicators in flight on one
+  // device are only deadlock-free if every rank enqueues their operations in the same relative order and both kernels
+  // can be resident, and this path has not run on more than one GPU yet.  So the split is OPT-IN, TPSRHS_RCCL_SPLIT=1
+  // (set identically on every rank: ncclCommSplit is collective), and its outcome is made collective: the ranks agree
+  // (a MIN all-reduce of the success flag on the exchange communicator) that EVERY rank has its second communicator,
+  // or every rank falls back to the shared one -- never a mixture, which would send one all-reduce to two communicators
+  // and hang.  tpsrhs_rccl_comm_info reports which.
   c->comm_reduce = c->comm;
-  ncclComm_t second = nullptr;
-  if (ncclCommSplit(c->comm, 0, rank, &second, nullptr) == ncclSuccess && second) {
-    c->comm_reduce = second;
-    c->own_reduce_comm = true;
+  const char *want = std::getenv("TPSRHS_RCCL_SPLIT");
+  if (want && want[0] == '1') {
+    ncclComm_t second = nullptr;
+    int ok = (ncclCommSplit(c->comm, 0, rank, &second, nullptr) == ncclSuccess && second) ? 1 : 0;
+    int *d_ok = nullptr;
+    bool agreed = false;
+    if (hipMalloc(reinterpret_cast<void **>(&d_ok), sizeof(int)) == hipSuccess) {
+      if (hipMemcpy(d_ok, &ok, sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+          ncclAllReduce(d_ok, d_ok, 1, ncclInt, ncclMin, c->comm, nullptr) == ncclSuccess && hipStreamSynchronize(nullptr) == hipSuccess &&
+          hipMemcpy(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess)
+        agreed = true;
+      hipFree(d_ok);
+    }
+    if (!agreed) {  // the agreement itself failed: the job cannot know what the other ranks do
+      if (second) ncclCommDestroy(second);
+      ncclCommDestroy(c->comm);
+      delete c;
+      g_err = "tpsrhs_rccl_create: the ranks could not agree on the outcome of ncclCommSplit";
+      return 1;
+    }
+    if (ok) {
+      c->comm_reduce = second;
+      c->own_reduce_comm = true;
+    } else if (second) {
+      ncclCommDestroy(second);  // another rank was refused: every rank shares the exchange communicator
+    }
   }
   *out = c;
   return 0;

@@ -1169,7 +1169,10 @@ struct GradLds {
   static constexpr int SUP = cmax(NEQ * C::NODES, (DIM == 2 ? 2 : 1) * CH * C::TN);  // 2-D: T chunks of both directions
   // (heavy point physics is register-bound, not LDS-bound: there the whole nodal gradient stays in J and the
   //  node lanes' registers are released before the physics)
-  static constexpr bool G_IN_LDS = PH::HEAVY;
+  // (the lean 3-D face kernel of the ternary mixtures -- visc_phase_lean3d -- re-reads the nodal gradient it has just written
+  //  from the L2, one Cartesian direction at a time: 12 KB per block, three waves per SIMD)
+  static constexpr bool LEAN3D = PH::LEAN_TRACE && DIM == 3 && !C::NC && C::BLOCK == 64 && C::Q_ROUNDS == 1;
+  static constexpr bool G_IN_LDS = PH::HEAVY && !LEAN3D;
   static constexpr int J = cmax(2 * NEQ * C::TN, (G_IN_LDS ? DIM : 1) * NEQ * C::NODES);
   static constexpr int W = CH * C::TW;
   // non-collocated variant: scratch of the volume operator / the quadrature-point gradient jump / the vectors of
@@ -1504,6 +1507,167 @@ __device__ inline void visc_phase_heavy3d(const MeshDev &m, const int2 *sFI, typ
     STAMP(8);
   }
 }
+// ---- the same phase in its LEAN form (round 4; ternary mixtures, collocated p <= 3 hexes, one wave per block): sized for
+// THREE waves per SIMD.  Differences from visc_phase_heavy3d:
+//   * the closure of a face point leaves PH::ViscLean (12-18 values) instead of ViscCoef + state + wall prescriptions (38);
+//   * nothing is carried across the closure for a second pass: a wall face's second pass (the few waves that touch a wall)
+//     interpolates the state again and adds its half to the record it wrote in the first;
+//   * the nodal gradient is not held in LDS (18 fields x 64 nodes = 9 KB): each Cartesian direction of it is re-read from
+//     the gradUp vector this block has just written -- an L2 hit -- into the 3 KB nodal buffer, the next one in flight
+//     while the current one is interpolated.
+template <class C, class PH, int D, int CD>
+__device__ inline void lean_grad_chunk(const double *sJ, double *Tb, double *Wb, const Tab<C> &tab, const Tables1D &ct0,
+                                       const double *n, double *gv, double *gn, int tid) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM, NVEL = PH::NVEL;
+  const Tables1D &ct = fresh_table(ct0);
+  trace_lines<C, D, NEQ>(sJ, Tb, ct, tid);
+  block_sync<C::BLOCK>();
+  interp1_lines<C, NEQ>(Tb, Wb, ct, tid);
+  block_sync<C::BLOCK>();
+  if (tid < C::TQ) {
+    const int pf = tid / C::NQ, q = tid - pf * C::NQ;
+    double bq[C::N1];
+#pragma unroll
+    for (int a = 0; a < C::N1; a++) bq[a] = tab.B[(q / C::Q1) * C::N1 + a];
+#pragma unroll
+    for (int k = 0; k < NEQ; k++) {
+      const double val = interp2_point<C>(Tb + k * C::TN, Wb + k * C::TW, bq, pf, q);
+      if (k >= 1 && k <= NVEL)
+        gv[(k - 1) + CD * DIM] = val;
+      else
+        gn[k] += n[CD] * val;
+    }
+  }
+  block_sync<C::BLOCK>();
+}
+// the three Cartesian directions of the nodal gradient through the nodal buffer sJ, the next one in flight (registers of
+// the node lanes) while the current one is interpolated to the face points of direction pair D
+template <class C, class PH, int D>
+__device__ inline void lean_grad_dir(const MeshDev &m, const double *gradUp_q, bool node_on, unsigned node, double *gnext, double *sJ,
+                                     double *Tb, double *Wb, const Tab<C> &tab, const Tables1D &ct, const double *n, double *gv,
+                                     double *gn, int tid) {
+  constexpr int NEQ = PH::NEQ;
+  auto stage = [&](auto ctag) {
+    constexpr int CD = decltype(ctag)::value;
+    if (node_on) {
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) sJ[eq * C::NODES + tid] = gnext[eq];
+      if (CD + 1 < C::DIM) {
+        // (node index and field stride through empty asm statements: the 18 field addresses of a node are formed where
+        //  they are used -- scalar arithmetic -- instead of being hoisted out of the loops and held in 36 VGPRs)
+        unsigned nq = node;
+        int64_t stride = m.ndofs;
+        asm volatile("" : "+v"(nq), "+s"(stride));
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) gnext[eq] = field_ptr(gradUp_q, (CD + 1) * NEQ + eq, stride)[nq];
+      }
+    }
+    block_sync<C::BLOCK>();
+    lean_grad_chunk<C, PH, D, CD>(sJ, Tb, Wb, tab, ct, n, gv, gn, tid);
+  };
+  stage(std::integral_constant<int, 0>());
+  stage(std::integral_constant<int, 1>());
+  stage(std::integral_constant<int, 2>());
+}
+template <class C, class PH>
+__device__ inline void visc_phase_lean3d(const MeshDev &m, const int2 *sFI, typename PH::PRef prm0, int e0, const double *sU,
+                                         const double *gradUp_q, bool node_on, unsigned node, double *sJ, double *Tb, double *Wb,
+                                         const double *sV, const Tab<C> &tab, const Tables1D &ct, double *__restrict__ TB,
+                                         int tid0 STAMP_PARAM) {
+  constexpr int NEQ = PH::NEQ, DIM = C::DIM;
+  static_assert(DIM == 3 && C::Q_ROUNDS == 1 && PH::NVEL == 3 && C::BLOCK == 64, "3-D, one wave, one round of face points per pair");
+#pragma clang loop unroll(disable)
+  for (int d = 0; d < DIM; d++) {
+    typename PH::PRef prm = PH::relaunder(prm0);  // the parameter loads of this direction stay inside it
+    // (the lane index through an empty asm: everything derived from it -- a dozen LDS addresses per line stage -- is
+    //  recomputed in the direction that uses it instead of being hoisted out of this loop and held, or spilled, across it)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int pf = tid / C::NQ, q = tid - pf * C::NQ;
+    const int le = pf >> 1, s = pf & 1;
+    const bool on = tid < C::TQ && (e0 + le) < m.ne;
+    int nb = 0;
+    double n[DIM] = {1.0, 0.0, 0.0};
+    if (on) {
+      double wq, Xq[DIM];
+      nb = sFI[le * C::NFACES + 2 * d + s].x;
+      face_geometry_rt<C>(d, &sV[le * C::NV * DIM], tab, s, q, n, wq, Xq);
+    }
+    // 0: no viscous term on this face, 1: interior face, 2: wall face (interior state, then wall-side state)
+    const int np_lane = on ? PH::visc_passes(prm, nb) : 0;
+    const int npass = (__ballot(np_lane == 2) != 0) ? 2 : ((__ballot(np_lane >= 1) != 0) ? 1 : 0);
+    double *out = TB + static_cast<int64_t>((e0 + le) * C::NFACES + 2 * d + s) * ((NEQ - 1) * C::NQ) + q;
+    if (on && np_lane == 0) {
+#pragma unroll
+      for (int eq = 1; eq < NEQ; eq++) out[(eq - 1) * C::NQ] = 0.0;
+    }
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < npass; pass++) {
+      double u[NEQ];
+#pragma unroll
+      for (int k = 0; k < NEQ; k++) u[k] = 1.0;
+      if (d == 0)
+        visc_state_dir<C, PH, 0>(sU, Tb, Wb, tab, ct, u, tid);
+      else if (d == 1)
+        visc_state_dir<C, PH, 1>(sU, Tb, Wb, tab, ct, u, tid);
+      else
+        visc_state_dir<C, PH, 2>(sU, Tb, Wb, tab, ct, u, tid);
+      STAMP(5);
+      PH::clamp_species(u);
+      // the first Cartesian direction of the nodal gradient goes out before the closure (an L2 round trip behind ~1 500
+      // FP64 instructions), the others while their predecessor is interpolated
+      double gnext[NEQ];
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) gnext[eq] = 0.0;
+      if (node_on) {
+        unsigned nq = node;
+        int64_t stride = m.ndofs;
+        asm volatile("" : "+v"(nq), "+s"(stride));
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) gnext[eq] = field_ptr(gradUp_q, eq, stride)[nq];
+      }
+      typename PH::ViscLean cf;
+      if (pass < np_lane) {
+        typename PH::PRef pq = PH::relaunder(prm);
+        double Us[NEQ];
+        typename PH::WallFlux w;
+        PH::visc_pass_state(pq, nb, pass, u, n, Us, w);
+        PH::visc_point_lean(pq, Us, w, cf);
+      }
+      STAMP(6);
+      double gv[DIM * DIM], gn[NEQ];
+#pragma unroll
+      for (int k = 0; k < DIM * DIM; k++) gv[k] = 0.0;
+#pragma unroll
+      for (int eq = 0; eq < NEQ; eq++) gn[eq] = 0.0;
+      if (d == 0)
+        lean_grad_dir<C, PH, 0>(m, gradUp_q, node_on, node, gnext, sJ, Tb, Wb, tab, ct, n, gv, gn, tid);
+      else if (d == 1)
+        lean_grad_dir<C, PH, 1>(m, gradUp_q, node_on, node, gnext, sJ, Tb, Wb, tab, ct, n, gv, gn, tid);
+      else
+        lean_grad_dir<C, PH, 2>(m, gradUp_q, node_on, node, gnext, sJ, Tb, Wb, tab, ct, n, gv, gn, tid);
+      STAMP(7);
+      if (pass < np_lane) {
+        double f[NEQ];
+        PH::visc_normal_flux_lean(cf, gv, gn, n, f);
+        if (nb >= 0) {
+#pragma unroll
+          for (int eq = 1; eq < NEQ; eq++) out[(eq - 1) * C::NQ] = f[eq];  // f[0] == 0 (src/fluxes.cpp:284)
+        } else if (pass == 0) {  // wall face: -1/2 (Fv_in + Fv_wall) . n, the interior half first
+#pragma unroll
+          for (int eq = 1; eq < NEQ; eq++) out[(eq - 1) * C::NQ] = -0.5 * f[eq];
+        } else {
+#pragma unroll
+          for (int eq = 1; eq < NEQ; eq++) out[(eq - 1) * C::NQ] -= 0.5 * f[eq];
+        }
+      }
+      STAMP(8);
+    }
+    if (on && npass == 0) {
+      // (np_lane == 0 for every lane: the zeros were written above)
+    }
+  }
+}
 // 2-D viscous phase: both direction pairs at once (see Cfg::TQ2)
 template <class C, class PH>
 __device__ inline void visc_phase_2d(const MeshDev &m, const int2 *sFI, typename PH::PRef prm, int e0,
@@ -1747,6 +1911,19 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
   }
   if (L::G_IN_LDS) block_sync<C::BLOCK>();
   STAMP(4);
+  if constexpr (L::LEAN3D) {
+    if (!(TPSRHS_ABLATE & 16)) {
+      // the lean face kernel reads the gradient back from the vector written above (same lanes, same addresses), after
+      // the stores have been acknowledged.  The memory clobber keeps the compiler from satisfying those reads from the
+      // registers that held g (which would keep all 36 of them alive across the closure).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const double *gq = gradUp;
+      const unsigned node = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
+      visc_phase_lean3d<C, PH>(m, sFI, prm, e0, sU, gq, node_on, node, sJ, sUp, sW, sV, tab, ct, TB, tid STAMP_ARG);
+    }
+    STAMP_FLUSH();
+    return;
+  }
 
   // ---- viscous normal-flux traces (T chunk in the sUp region: the nodal Up values are dead)
   if (!(TPSRHS_ABLATE & 16)) {

@@ -205,6 +205,7 @@ struct DryAirPhys {
   static constexpr bool VISC_USES_GRAD_RHO = false;  // Newtonian stress + Fourier flux: grad u and grad T only
   static constexpr bool HEAVY = false;  // light point physics: inlined at every face pass
   static constexpr bool TWO_STEP = false;  // no state-only closure worth separating from the gradient terms
+  static constexpr bool LEAN_TRACE = false;
   struct FluxCoef {};
   static constexpr int MINW_GRAD = TPSRHS_MINW_GRAD, MINW_FLUX = TPSRHS_MINW_FLUX;  // launch-bound waves per SIMD
   // k_gradient of the p = 3 hex (one wave per element, 10 KB of LDS).  Round 2 capped it at 128 VGPRs = four waves per

@@ -118,6 +118,7 @@ struct GasAxiPhys {
   static constexpr int DIM = 2, NVEL = 3, NEQ = 5, NACTIVE = 0, ITH = 4;
   static constexpr bool HAS_SOURCE = true, AXISYM = true, HEAVY = true, TWO_TEMPERATURE = false, HAS_NR_BC = false;
   static constexpr bool TWO_STEP = false;
+  static constexpr bool LEAN_TRACE = false;
   struct FluxCoef {};
   static constexpr bool VISC_USES_GRAD_RHO = false;
   static constexpr int MAX_ORDER = 4;

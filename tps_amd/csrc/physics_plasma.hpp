@@ -72,6 +72,9 @@ struct PlasmaParams {
   // argon ternary
   int third_order, multiply;
   int coll[NSP * NSP];  // tpsrhs_gas_coll of the species pairs [i + j*NSP], i <= j (argon mixture transport)
+  // which collision types occur (bit = 1 << tpsrhs_gas_coll): among the (sp, sp) pairs of the heavy species, among the
+  // (heavy, electron) pairs, among the pairs of two different heavy species -- filled by the host
+  int cmask_diag, cmask_e, cmask_h;
   double mult_flux[4], mult_spcs, mult_diff, mult_mobil;
   const ChemDev *chem;
   int eq_system, use_bc_in_grad, num_bcs, axisymmetric;
@@ -239,6 +242,9 @@ __device__ inline void eAr1r_n(double logT, double (&fit)[NR]) {
 #ifndef TPSRHS_PLASMA_MINW_GRAD3
 #define TPSRHS_PLASMA_MINW_GRAD3 2
 #endif
+#ifndef TPSRHS_PLASMA_MINW_GRAD_LEAN
+#define TPSRHS_PLASMA_MINW_GRAD_LEAN 3
+#endif
 enum { TRANSPORT_CONSTANT = 0, TRANSPORT_ARGON_MINIMAL = 1, TRANSPORT_ARGON_MIXTURE = 2 };
 
 template <int DIM_, int NVEL_, int NSP_, bool AMBI, bool TWOT, int TRANSPORT>
@@ -260,7 +266,13 @@ struct PlasmaPhys {
   // registers -- at two the sweeps spilled 150-340 VGPRs to scratch, and two such instantiations returned
   // scheduling-dependent wrong results (DESIGN.md "spilled instantiations")
   static constexpr int MINW_GRAD = (NSP_ > 3) ? 1 : TPSRHS_PLASMA_MINW_GRAD3;
-  static constexpr int minw_grad(int, int, int) { return MINW_GRAD; }
+  // The 3-D face kernel of the ternary mixtures carries the closure of a face point in its LEAN form (ViscLean below):
+  // 12-18 values across the gradient interpolation instead of 38, the nodal gradient re-read from the L2 instead of held
+  // in LDS -- 168 registers and 12 KB, THREE waves per SIMD (round 4; the collocated p <= 3 hexes, one wave per block).
+  static constexpr bool LEAN_TRACE = (NSP_ == 3) && (DIM_ == 3);
+  static constexpr int minw_grad(int dim, int p, int nc) {
+    return (LEAN_TRACE && dim == 3 && !nc && p <= 3) ? TPSRHS_PLASMA_MINW_GRAD_LEAN : MINW_GRAD;
+  }
   // (2-D / axisymmetric sweeps of four to six species stay at two: 20-200 spilled VGPRs, the state every round-1 and
   // round-2 sweep of the randomised parity driver ran in, and 20 % faster at torch6)
   static constexpr int MINW_FLUX = (NSP_ > 6 || (NSP_ > 3 && DIM_ == 3)) ? 1 : TPSRHS_PLASMA_MINW_FLUX;
@@ -537,22 +549,51 @@ struct PlasmaPhys {
     c.lnTh = TWOT ? flog(Th) : c.lnTe;
     return c;
   }
-  // GasMixtureTransport::collisionIntegral (src/gas_transport.cpp:995-1283), argon types.  (l, r) and the
-  // species are compile-time after unrolling; the pair's collision type is a uniform run-time value.
+  // GasMixtureTransport::collisionIntegral (src/gas_transport.cpp:995-1283), argon types, by collision TYPE.
+  //   CLMB_ATT / CLMB_REP: pi lambda_D^2 x the Coulomb fit (l, r) at the nondimensional temperature of the pair (the
+  //   electron's if it takes part); AR_E: the e-Ar polynomial (1, r); AR_AR1P: Ar-Ar+ (1,1); AR_AR: Ar-Ar (1,1) / (2,2).
   // tpsrhs_create has checked that every (pair, l, r) the transport asks for exists.
+  // A point has one set of collision inputs, so collisionIntegral(i, j, l, r) takes at most one value per (type, l, r,
+  // electron pair or not): the values of the types that occur (`mask`, wave-uniform, from the host) are computed ONCE
+  // per point and every species pair selects its own with its uniform type -- the same functions of the same arguments
+  // as the reference's pair-by-pair calls.  (Rounds 1-3 inlined a five-way type branch per pair: the e-Ar polynomial
+  // once per neutral species, the attractive Coulomb fit once per ion; a 7-species k_flux was 23 000 instructions with
+  // 900 branches.)
+  struct CollTab {
+    double att, rep, ar1p, are, arar;  // by tpsrhs_gas_coll: CLMB_ATT, CLMB_REP, AR_AR1P, AR_E, AR_AR
+  };
   template <int L, int R>
-  __device__ static inline double collision(PRef p, int i, int j, const MixColl &c) {
+  __device__ static inline CollTab coll_table(int mask, bool with_e, const MixColl &c) {
+    CollTab t;
+    t.att = t.rep = t.ar1p = t.are = t.arar = 0.0;
+    const coll::Arg &a = with_e ? c.e : c.h;
+    const double ln = with_e ? c.lnTe : c.lnTh;
+    if (mask & (1 << TPSRHS_CLMB_ATT)) {
+      const double *k = coll::c_coulomb[0][L - 1][R - 1];
+      t.att = c.circle * coll::cfit(k[0], k[1], k[2], k[3], a);
+    }
+    if (mask & (1 << TPSRHS_CLMB_REP)) {
+      const double *k = coll::c_coulomb[1][L - 1][R - 1];
+      t.rep = c.circle * coll::cfit(k[0], k[1], k[2], k[3], a);
+    }
+    if (mask & (1 << TPSRHS_AR_AR1P)) t.ar1p = coll::ArAr1P11(ln);
+    if (mask & (1 << TPSRHS_AR_E)) t.are = coll::eAr1r(R, ln);
+    if (mask & (1 << TPSRHS_AR_AR)) t.arar = (L == 1) ? coll::ArAr11(ln) : coll::ArAr22(c.Th);
+    return t;
+  }
+  // the table entry of the pair (i, j): a chain of selects on the wave-uniform type.  The five entries are read
+  // unconditionally first: written as `type == X ? t.x : v` the conditional loads are merged by the optimiser into ONE
+  // load with a selected offset, and the table then lives in scratch memory instead of registers.
+  __device__ static inline double coll_pick(PRef p, int i, int j, const CollTab &t) {
     const int a = i < j ? i : j, b = i < j ? j : i;
     const int type = p.coll[a + b * NSP];
-    const bool with_e = (a == IE) || (b == IE);
-    if (type == TPSRHS_CLMB_ATT || type == TPSRHS_CLMB_REP) {
-      const double *k = coll::c_coulomb[type == TPSRHS_CLMB_REP ? 1 : 0][L - 1][R - 1];
-      return c.circle * coll::cfit(k[0], k[1], k[2], k[3], with_e ? c.e : c.h);
-    }
-    if (type == TPSRHS_AR_E) return coll::eAr1r(R, with_e ? c.lnTe : c.lnTh);
-    if (type == TPSRHS_AR_AR1P) return coll::ArAr1P11(with_e ? c.lnTe : c.lnTh);
-    if (L == 1) return coll::ArAr11(with_e ? c.lnTe : c.lnTh);  // AR_AR
-    return coll::ArAr22(c.Th);
+    const double q_att = t.att, q_rep = t.rep, q_ar1p = t.ar1p, q_are = t.are, q_arar = t.arar;
+    double v = q_arar;
+    v = (type == TPSRHS_AR_E) ? q_are : v;
+    v = (type == TPSRHS_AR_AR1P) ? q_ar1p : v;
+    v = (type == TPSRHS_CLMB_REP) ? q_rep : v;
+    v = (type == TPSRHS_CLMB_ATT) ? q_att : v;
+    return v;
   }
 
   // ComputeFluxTransportProperties of the selected model; E-field = 0 (src/fluxes.cpp:200-201).
@@ -592,45 +633,54 @@ struct PlasmaPhys {
       const MixColl c = mix_inputs(p, q.n, Th, Te);
       const double sTe = fast_sqrt(Te), sTh = TWOT ? fast_sqrt(Th) : sTe;
       t.visc = t.bulk = t.k = 0.0;
-#pragma unroll
-      for (int sp = 0; sp < NSP; sp++) {
-        if (sp == IE) continue;
-        const double sv = p.vf_sq_mwp[sp] * sTh * fast_rcp(collision<2, 2>(p, sp, sp, c));
-        t.visc += q.X[sp] * sv;
-        t.k += q.X[sp] * (sv * p.kf_imwp[sp]);
-      }
-      const double ke_fac = p.ke_fac * sTe * q.X[IE];  // v_f k_f sqrt(T_e / m_e) X_e
-      if (p.third_order) {  // :1388-1407
-        constexpr double s2 = 1.4142135623730951;
-        const double Q22 = collision<2, 2>(p, IE, IE, c), Q23 = collision<2, 3>(p, IE, IE, c),
-                     Q24 = collision<2, 4>(p, IE, IE, c);
-        double L11 = s2 * q.X[IE] * Q22;
-        double L12 = s2 * q.X[IE] * (1.75 * Q22 - 2.0 * Q23);
-        double L22 = s2 * q.X[IE] * (4.8125 * Q22 - 7.0 * Q23 + 5. * Q24);
+      {
+        const CollTab d22 = coll_table<2, 2>(p.cmask_diag, false, c);  // (sp, sp) of the heavy species
 #pragma unroll
         for (int sp = 0; sp < NSP; sp++) {
           if (sp == IE) continue;
-          const double Q1[5] = {collision<1, 1>(p, sp, IE, c), collision<1, 2>(p, sp, IE, c), collision<1, 3>(p, sp, IE, c),
-                                collision<1, 4>(p, sp, IE, c), collision<1, 5>(p, sp, IE, c)};
+          const double sv = p.vf_sq_mwp[sp] * sTh * fast_rcp(coll_pick(p, sp, sp, d22));
+          t.visc += q.X[sp] * sv;
+          t.k += q.X[sp] * (sv * p.kf_imwp[sp]);
+        }
+      }
+      const double ke_fac = p.ke_fac * sTe * q.X[IE];  // v_f k_f sqrt(T_e / m_e) X_e
+      constexpr int EE = 1 << TPSRHS_CLMB_REP;         // (e, e): tpsrhs_create admits the repulsive Coulomb type only
+      if (p.third_order) {  // :1388-1407
+        constexpr double s2 = 1.4142135623730951;
+        const double Q22 = coll_table<2, 2>(EE, true, c).rep, Q23 = coll_table<2, 3>(EE, true, c).rep,
+                     Q24 = coll_table<2, 4>(EE, true, c).rep;
+        double L11 = s2 * q.X[IE] * Q22;
+        double L12 = s2 * q.X[IE] * (1.75 * Q22 - 2.0 * Q23);
+        double L22 = s2 * q.X[IE] * (4.8125 * Q22 - 7.0 * Q23 + 5. * Q24);
+        const CollTab e1 = coll_table<1, 1>(p.cmask_e, true, c), e2 = coll_table<1, 2>(p.cmask_e, true, c),
+                      e3 = coll_table<1, 3>(p.cmask_e, true, c), e4 = coll_table<1, 4>(p.cmask_e, true, c),
+                      e5 = coll_table<1, 5>(p.cmask_e, true, c);
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++) {
+          if (sp == IE) continue;
+          const double Q1[5] = {coll_pick(p, sp, IE, e1), coll_pick(p, sp, IE, e2), coll_pick(p, sp, IE, e3), coll_pick(p, sp, IE, e4),
+                                coll_pick(p, sp, IE, e5)};
           L11 += q.X[sp] * (6.25 * Q1[0] - 15. * Q1[1] + 12. * Q1[2]);
           L12 += q.X[sp] * (10.9375 * Q1[0] - 39.375 * Q1[1] + 57. * Q1[2] - 30. * Q1[3]);
           L22 += q.X[sp] * (19.140625 * Q1[0] - 91.875 * Q1[1] + 199.5 * Q1[2] - 210. * Q1[3] + 90. * Q1[4]);
         }
         t.ke = s2 * ke_fac * fast_rcp(L11 - L12 * L12 * fast_rcp(L22));
       } else {
-        t.ke = ke_fac * fast_rcp(collision<2, 2>(p, IE, IE, c));
+        t.ke = ke_fac * fast_rcp(coll_table<2, 2>(EE, true, c).rep);
       }
       if (diffusion) {
         double ibd[NSP * NSP];  // 1 / D_ij
 #pragma unroll
         for (int i = 0; i < NSP * NSP; i++) ibd[i] = 0.0;
         const double nrsTe = q.ntot * (sTe * iTe), nrsTh = TWOT ? q.ntot * (sTh * iTh) : nrsTe;  // n / sqrt(T)
+        // (1,1): the pairs with the electron at the electron temperature, the heavy pairs at the heavy-species one
+        const CollTab pe = coll_table<1, 1>(p.cmask_e, true, c), ph = coll_table<1, 1>(p.cmask_h, false, c);
 #pragma unroll
         for (int i = 0; i < NSP - 1; i++)
 #pragma unroll
           for (int j = i + 1; j < NSP; j++)
-            ibd[i + j * NSP] = ibd[j + i * NSP] =
-                ((i == IE || j == IE) ? nrsTe : nrsTh) * p.sq_muw_idfc[i + j * NSP] * collision<1, 1>(p, i, j, c);
+            ibd[i + j * NSP] = ibd[j + i * NSP] = ((i == IE || j == IE) ? nrsTe : nrsTh) * p.sq_muw_idfc[i + j * NSP] *
+                                                  coll_pick(p, i, j, (i == IE || j == IE) ? pe : ph);
 #pragma unroll
         for (int i = 0; i < NSP; i++) {
           double a = 0.0;
@@ -828,10 +878,11 @@ struct PlasmaPhys {
       const double mff = 4. / 3. * kAvogadro * sqrt(8. * kBoltz / kPi);
       const MixColl c = mix_inputs(p, q.n, Th, Te);
       const double vth = (mff / (15. / 4. * kBoltz * 5. / 16. * sqrt(kPi * kBoltz))) * p.ke_fac * fast_sqrt(Te);  // mff sqrt(T_e / m_e)
+      const CollTab pe = coll_table<1, 1>(p.cmask_e, true, c);
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) {
         if (sp == IE) continue;
-        mtfreq[sp] = vth * q.n[sp] * collision<1, 1>(p, sp, IE, c);
+        mtfreq[sp] = vth * q.n[sp] * coll_pick(p, sp, IE, pe);
         if (p.multiply) mtfreq[sp] *= p.mult_spcs;
       }
     } else {
@@ -1346,6 +1397,117 @@ struct PlasmaPhys {
     for (int sp = 0; sp < NACTIVE; sp++) Fn[NVEL + 2 + sp] = -U[NVEL + 2 + sp] * Vn[sp];
     if (TWOT) Fn[ITE] = -EF;
   }
+  // ---- the LEAN form of the two-step trace.  What the flux needs of the closure after the gradient has been brought in is
+  // little: mu, mu_b - 2/3 mu, k, the velocity -- and the heat carried by diffusion and the species fluxes, which are LINEAR
+  // in the normal derivatives of the rows the diffusion velocities read (density and active species; diffusion_velocity is
+  // a homogeneous linear map of them).  So the closure contracts that map with the enthalpies and species densities once:
+  // (1 + NACTIVE) x (1 + NACTIVE [+ 1 two-temperature]) coefficients -- 4 for the ambipolar single-temperature ternary
+  // mixture -- replace D/X, mobilities, mass fractions, number densities, enthalpies and the state (38 values -> 12).  The
+  // wall prescriptions (WallFlux) become the constant terms.  Same terms as visc_normal_flux_n, summed in another order
+  // (rounding).
+  static constexpr int NIN = 1 + NACTIVE;  // inputs of the diffusion map: d(rho)/dn, d(n_sp)/dn of the active species
+  struct ViscLean {
+    double mu, bulkp, kq, ke;                      // kq multiplies dT_h/dn (k_h, + k_e single-temperature); ke: dT_e/dn
+    double vel[NVEL];
+    double hf0, ef0, sf0[NACTIVE];                 // prescribed (wall) parts of the heavy / electron heat flux and species rows
+    double hfc[NIN], efc[NIN], sfc[NACTIVE][NIN];  // the same three as linear maps of the inputs
+  };
+  __device__ static inline void visc_point_lean(PRef p, const double *U, const WallFlux &w, ViscLean &L) {
+    const State s = make_state(p, U);
+    TCoef t;
+    transport_coeffs(p, U, s.Th, s.Te, !w.species, t);
+    double h[NSP];
+    enthalpies(p, s, h);
+    L.mu = t.visc;
+    L.bulkp = t.bulk - 2. / 3. * t.visc;
+#pragma unroll
+    for (int d = 0; d < NVEL; d++) L.vel[d] = s.vel[d];
+    L.kq = w.heavy_heat ? 0.0 : (TWOT ? t.k : t.k + t.ke);
+    L.hf0 = w.heavy_heat ? w.hf * w.nm : 0.0;
+    L.ke = (TWOT && !w.electron_heat) ? t.ke : 0.0;
+    L.ef0 = (TWOT && w.electron_heat) ? w.ef * w.nm : 0.0;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) L.sf0[sp] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+      L.hfc[j] = L.efc[j] = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < NACTIVE; sp++) L.sfc[sp][j] = 0.0;
+    }
+    if (w.species) {  // prescribed normal diffusion velocities (per unit area)
+      double Vn[NSP];
+#pragma unroll
+      for (int sp = 0; sp < NSP; sp++) Vn[sp] = w.Vn[sp] * w.nm;
+      if (!w.heavy_heat) {
+#pragma unroll
+        for (int sp = 0; sp < NSP; sp++)
+          if (!(TWOT && sp == IE)) L.hf0 += h[sp] * Vn[sp];
+      }
+      if (TWOT && !w.electron_heat) L.ef0 += h[IE] * Vn[IE];
+#pragma unroll
+      for (int sp = 0; sp < NACTIVE; sp++) L.sf0[sp] = -U[NVEL + 2 + sp] * Vn[sp];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NIN; j++) {
+        double gs[NEQ], V[NSP];
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) gs[eq] = 0.0;
+        gs[j == 0 ? 0 : NVEL + 2 + (j - 1)] = 1.0;
+        diffusion_velocity(p, t, gs, V);
+        if (!w.heavy_heat) {
+          double a = 0.0;
+#pragma unroll
+          for (int sp = 0; sp < NSP; sp++)
+            if (!(TWOT && sp == IE)) a += h[sp] * V[sp];
+          L.hfc[j] = a;
+        }
+        if (TWOT && !w.electron_heat) L.efc[j] = h[IE] * V[IE];
+#pragma unroll
+        for (int sp = 0; sp < NACTIVE; sp++) L.sfc[sp][j] = -U[NVEL + 2 + sp] * V[sp];
+      }
+    }
+  }
+  // gv[i + j*DIM] = d u_i / d x_j; gn[eq] = sum_d n_d dUp_eq/dx_d (scalar rows)
+  __device__ static inline void visc_normal_flux_lean(const ViscLean &L, const double *gv, const double *gn, const double *n,
+                                                      double *Fn) {
+    static_assert(!AXISYM, "planar / 3-D form");
+    double divV = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) divV += gv[i + i * DIM];
+    double e = 0.0;
+    Fn[0] = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) {
+      double sn = 0.0;
+#pragma unroll
+      for (int j = 0; j < DIM; j++) {
+        double st = L.mu * (gv[j + i * DIM] + gv[i + j * DIM]);
+        if (i == j) st += L.bulkp * divV;
+        sn += st * n[j];
+      }
+      Fn[1 + i] = sn;
+      e += sn * L.vel[i];
+    }
+    double gin[NIN];
+    gin[0] = gn[0];
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) gin[1 + sp] = gn[NVEL + 2 + sp];
+    double HF = L.hf0 - L.kq * gn[ITH], EF = TWOT ? L.ef0 - L.ke * gn[ITE] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+      HF += L.hfc[j] * gin[j];
+      if (TWOT) EF += L.efc[j] * gin[j];
+    }
+    Fn[ITH] = e - HF - EF;
+#pragma unroll
+    for (int sp = 0; sp < NACTIVE; sp++) {
+      double f = L.sf0[sp];
+#pragma unroll
+      for (int j = 0; j < NIN; j++) f += L.sfc[sp][j] * gin[j];
+      Fn[NVEL + 2 + sp] = f;
+    }
+    if (TWOT) Fn[ITE] = -EF;
+  }
   // The viscous trace of one face quadrature point.  Interior face (nb >= 0): Fv(U, g) . n.  Boundary
   // face: the complete additive viscous boundary term -1/2 (Fv_wall + Fv_in) . n of the wall types
   // (src/wallBC.cpp:302-320,448-468,492-510), zero for inlets and outlets.  One transport evaluation
@@ -1404,9 +1566,10 @@ struct PlasmaPhys {
     if (TRANSPORT == TRANSPORT_ARGON_MIXTURE) {  // src/gas_transport.cpp:1499-1535
       const MixColl c = mix_inputs(p, q.n, Th, Te);
       visc = 0.0;
+      const CollTab d22 = coll_table<2, 2>(p.cmask_diag, false, c);
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++)
-        if (sp != IE) visc += q.X[sp] * (p.vf_sq_mwp[sp] * fast_sqrt(Th) * fast_rcp(collision<2, 2>(p, sp, sp, c)));
+        if (sp != IE) visc += q.X[sp] * (p.vf_sq_mwp[sp] * fast_sqrt(Th) * fast_rcp(coll_pick(p, sp, sp, d22)));
       bulk = 0.0;
       if (p.multiply) {
         visc *= p.mult_flux[0];
