@@ -44,6 +44,17 @@ int tpsrhs_restart_info_read(const char *path, tpsrhs_restart_info *info);
 int tpsrhs_restart_read(const char *path, int num_equation, int64_t ndofs, const char *const *names, int order, double *U,
                         tpsrhs_restart_info *info);
 
+/* SERIALISED restart (`io/restartMode = singleFileRead*`, src/io.cpp:104-172, 460-530): ONE file holds the solution of
+ * the unpartitioned mesh, every dataset with NDofs_global entries ordered by global element (a discontinuous space: the
+ * dofs of global element g are entries [g * dofs_per_element, (g+1) * dofs_per_element) of each variable).  The reference
+ * reads it on rank 0 and sends every rank its elements; here every rank opens the file read-only and takes the elements it
+ * owns: `global_elements[e]` = id of local element e in the unpartitioned mesh (the partition the caller already has --
+ * tpsrhs_mesh needs it for nothing else).  U: [num_equation][num_elements * dofs_per_element], byNODES.  A serialised file
+ * is written with tpsrhs_restart_write from the global vector (dofs_global < 0: the reference omits that attribute there). */
+int tpsrhs_restart_read_serial(const char *path, int num_equation, int64_t num_elements, int dofs_per_element,
+                               const int64_t *global_elements, const char *const *names, int order, double *U,
+                               tpsrhs_restart_info *info);
+
 /* The reference's partitioned write of one rank (src/io.cpp:43-103, 701-724): truncates `path`. */
 int tpsrhs_restart_write(const char *path, int num_equation, int64_t ndofs, const char *const *names, const double *U,
                          const tpsrhs_restart_info *info);

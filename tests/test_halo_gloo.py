@@ -140,7 +140,9 @@ def _cfg4_worker(rank, world, port, q):
         pts = gl_nodes(n)
         per = n * n
         send = np.zeros((ns, dim, per))
-        sample = list(range(0, ns, 997)) + [ns // 2 - 1, ns // 2, ns - 1]
+        half = ns // 2
+        J = list(range(0, half, 997)) + [half - 1]  # the same positions in both segments: what I send as face j of the
+        sample = J + [j + half for j in J]         # segment towards a neighbour arrives as its face j of the segment from me
         mine = {}
         for s in sample:
             xy = face_point_coords(mesh, int(e[s]), int(f[s]), pts)
@@ -148,7 +150,6 @@ def _cfg4_worker(rank, world, port, q):
             for k in range(per):
                 send[s, :, permute(dim, int(sorient[s]), n, k % n, k // n)] = xy[k]
         recv = np.zeros_like(send)
-        half = ns // 2
         ranks_c = (C.c_int * 2)(int(nbr[0]), int(nbr[-1]))
         offs_c = (C.c_int64 * 3)(0, half * dim * per, ns * dim * per)
         halo = HaloExchange(host_buffers=True)

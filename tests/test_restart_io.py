@@ -92,3 +92,40 @@ def test_restart_to_mult_matches_the_oracle(tmp_path):
     ref = oracle_mult(c.mesh, c.disc, c.physics, c.bcs, U)
     assert rel_maxnorm(y.cpu().numpy().reshape(U.shape), ref["y"]).max() < 5 * RHS_RTOL
     op.close()
+
+
+def test_serialised_restart_is_scattered_by_global_element(tmp_path):
+    """`restartMode = singleFileRead` (src/io.cpp:104-172, 460-530): one file for the unpartitioned mesh; every rank takes the
+    dofs of the elements it owns.  A partition of a cylinder mesh: the parts read from the serial file equal the parts of the
+    global state, the partitioned files of the same state give the same vectors, errors are messages."""
+    from tps_amd import meshgen
+    from tps_amd.rhs_operator import node_coordinates
+
+    full = meshgen.ogrid_cylinder(3, 8, 4)
+    order, npe = 2, 27
+    names = restart.variable_names(3)
+    Ug = cases.dry_air_state(node_coordinates(full, order), seed=4)
+    serial = tmp_path / "restart_serial.sol.h5"
+    restart.write(serial, names, Ug, iteration=17, time=0.5, dt=1e-5, order=order, dimension=3)  # no dofs_global, as the reference
+    assert restart.read_info(serial).dofs_global == -1
+    owner = (np.arange(full.num_elements) * 7) % 3  # a scattered 3-way partition
+    parts = meshgen.partition(full, 3, owner)
+    seen = 0
+    for r, part in enumerate(parts):
+        ge = np.asarray(part.global_elements)
+        U, info = restart.read_serial(serial, names, ge, npe, order=order)
+        assert (info.iteration, info.time, info.ndofs) == (17, 0.5, full.num_elements * npe)
+        want = Ug.reshape(len(names), full.num_elements, npe)[:, ge, :].reshape(len(names), -1)
+        assert np.array_equal(U, want)
+        # ... and equals this rank's partitioned file of the same state
+        pf = tmp_path / f"restart_part.sol.{r}.h5"
+        restart.write(pf, names, want, order=order, dofs_global=full.num_elements * npe)
+        assert np.array_equal(restart.read(pf, names, want.shape[1], order=order)[0], U)
+        seen += ge.size
+    assert seen == full.num_elements
+    with pytest.raises(RuntimeError, match="outside the file"):
+        restart.read_serial(serial, names, [full.num_elements], npe)
+    with pytest.raises(RuntimeError, match="polynomial order"):
+        restart.read_serial(serial, names, [0], npe, order=3)
+    with pytest.raises(RuntimeError, match="whole elements"):
+        restart.read_serial(serial, names, [0], 25)

@@ -1,6 +1,6 @@
 """Where a block of the reacting k_gradient spends its cycles (diagnostic build, GPU box):
-    tools/build_variant.sh stamp "-DTPSRHS_STAMP=1" plasma_3d_n3a
-    TPSRHS_LIB=$PWD/tps_amd/csrc/_ab/stamp.so python tools/stamp_phases.py
+    tools/build_variant.sh stamp "-DTPSRHS_STAMP=1 -mllvm -disable-machine-licm" plasma_3d_n3a
+    TPSRHS_FAMILY_PATH=$PWD/tps_amd/csrc/_ab/stamp python tools/stamp_phases.py
 Prints the share of each phase in the summed s_memtime differences (shares, not lengths: the stamps fence
 overlaps the production kernel has)."""
 import ctypes as C
@@ -26,7 +26,7 @@ U = make_state(X, physics)
 op = RHSoperator(mesh, disc, physics, make_bcs(physics), device=0)
 x = torch.tensor(U.ravel(), dtype=torch.float64, device=op.device)
 y = torch.empty_like(x)
-lib = capi.load()
+lib = C.CDLL(os.path.join(os.environ["TPSRHS_FAMILY_PATH"].split(":")[0], "libtpsrhs_plasma_3d_n3a.so"))  # the diagnostic build of the family
 import numpy as np  # noqa: E402
 
 nblocks = mesh.num_elements // (2 if order == 2 else 1)  # elements per block: one p = 3 hex, two p = 2 hexes

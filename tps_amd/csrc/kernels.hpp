@@ -38,6 +38,9 @@ namespace tpsrhs {
 #ifndef TPSRHS_MINW_FLUX
 #define TPSRHS_MINW_FLUX 3  // <= 168 VGPRs: 3 waves per SIMD (the allocator otherwise lands on 170)
 #endif
+#ifndef TPSRHS_FLUX_LATE
+#define TPSRHS_FLUX_LATE 0  // experiment: k_flux issues the neighbour records of its first direction pair after the nodal physics
+#endif
 #ifndef TPSRHS_ABLATE
 #define TPSRHS_ABLATE 0  // timing experiments only (wrong results)
 #endif
@@ -2568,7 +2571,7 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   // the neighbour records of the first direction pair go out before the nodal physics (their latency hides behind it)
   // -- except in the wide 2-D kernels (more than 8 equations): 3 x NEQ values held across the closure there are 66
   // VGPRs of a kernel that otherwise spills 90 (torch6, round 2); those issue them where the face term starts
-  constexpr bool EARLY = !(DIM == 2 && NEQ > 8);
+  constexpr bool EARLY = !(DIM == 2 && NEQ > 8) && !TPSRHS_FLUX_LATE;
   if (EARLY) {
     issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta0, tid);
     if (!L::BOTH_2D) issue_visc_traces<C, 0, NEQ>(sFI, e0, TB, tb0, tid);

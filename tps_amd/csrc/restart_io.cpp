@@ -3,6 +3,7 @@
 
 #include <hdf5.h>
 
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -131,6 +132,44 @@ int tpsrhs_restart_read(const char *path, int num_equation, int64_t ndofs, const
       return fail("restart file: dataset " + p + " has the wrong size");
     if (H5Dread(d, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, U + static_cast<int64_t>(k) * ndofs) < 0)
       return fail("restart file: reading " + p + " failed");
+  }
+  return 0;
+}
+
+int tpsrhs_restart_read_serial(const char *path, int num_equation, int64_t num_elements, int dofs_per_element,
+                               const int64_t *global_elements, const char *const *names, int order, double *U,
+                               tpsrhs_restart_info *info) {
+  if (!path || !names || !U || num_equation < 1 || num_elements < 0 || dofs_per_element < 1 || (num_elements > 0 && !global_elements))
+    return fail("tpsrhs_restart_read_serial: invalid argument");
+  QuietErrors quiet;
+  Handle f(H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT), H5Fclose);
+  if (f < 0) return fail(std::string("cannot open restart file ") + path);
+  tpsrhs_restart_info local;
+  tpsrhs_restart_info *in = info ? info : &local;
+  const std::string first = std::string("/solution/") + names[0];
+  if (read_info(f, first.c_str(), in) != 0) return 1;
+  if (order >= 0 && in->order != order)
+    return fail("restart file of polynomial order " + std::to_string(in->order) + ", operator of order " + std::to_string(order) +
+                " (the reference's change of order on restart interpolates with MFEM: not part of this library)");
+  const int64_t nglob = in->ndofs, ndofs = num_elements * dofs_per_element;
+  if (nglob % dofs_per_element != 0) return fail("serial restart file: " + std::to_string(nglob) + " entries are not whole elements");
+  for (int64_t e = 0; e < num_elements; e++)
+    if (global_elements[e] < 0 || (global_elements[e] + 1) * dofs_per_element > nglob)
+      return fail("serial restart file: global element " + std::to_string(global_elements[e]) + " outside the file's " +
+                  std::to_string(nglob / dofs_per_element) + " elements");
+  std::vector<double> all(static_cast<size_t>(nglob));
+  for (int k = 0; k < num_equation; k++) {  // read_variable_data_hdf5 on the whole variable, then the rank's elements (:482-507)
+    const std::string p = std::string("/solution/") + names[k];
+    Handle d(H5Dopen2(f, p.c_str(), H5P_DEFAULT), H5Dclose);
+    if (d < 0) return fail("restart file: dataset " + p + " missing");
+    Handle sp(H5Dget_space(d), H5Sclose);
+    hsize_t n = 0;
+    if (H5Sget_simple_extent_ndims(sp) != 1 || H5Sget_simple_extent_dims(sp, &n, nullptr) < 0 || static_cast<int64_t>(n) != nglob)
+      return fail("restart file: dataset " + p + " has the wrong size");
+    if (H5Dread(d, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, all.data()) < 0) return fail("restart file: reading " + p + " failed");
+    double *out = U + static_cast<int64_t>(k) * ndofs;
+    for (int64_t e = 0; e < num_elements; e++)
+      std::memcpy(out + e * dofs_per_element, all.data() + global_elements[e] * dofs_per_element, sizeof(double) * dofs_per_element);
   }
   return 0;
 }

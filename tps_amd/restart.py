@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtpsrhs_io.so")
-EXPORTED_SYMBOLS = ["tpsrhs_restart_variable_names", "tpsrhs_restart_info_read", "tpsrhs_restart_read", "tpsrhs_restart_write",
+EXPORTED_SYMBOLS = ["tpsrhs_restart_variable_names", "tpsrhs_restart_info_read", "tpsrhs_restart_read", "tpsrhs_restart_read_serial", "tpsrhs_restart_write",
                     "tpsrhs_io_last_error"]
 _LIB = None
 
@@ -32,6 +32,8 @@ def load():
         lib.tpsrhs_restart_info_read.argtypes = [C.c_char_p, C.POINTER(RestartInfo)]
         lib.tpsrhs_restart_read.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.POINTER(C.c_char_p), C.c_int, C.c_void_p,
                                             C.POINTER(RestartInfo)]
+        lib.tpsrhs_restart_read_serial.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_char_p), C.c_int,
+                                                   C.c_void_p, C.POINTER(RestartInfo)]
         lib.tpsrhs_restart_write.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.POINTER(C.c_char_p), C.c_void_p, C.POINTER(RestartInfo)]
         _LIB = lib
     return _LIB
@@ -76,3 +78,15 @@ def write(path, names, U, iteration=0, time=0.0, dt=0.0, order=1, dimension=3, d
     if load().tpsrhs_restart_write(str(path).encode(), len(names), U.shape[1], _names(names), U.ctypes.data_as(C.c_void_p),
                                    C.byref(info)) != 0:
         raise RuntimeError(load().tpsrhs_io_last_error().decode())
+
+
+def read_serial(path, names, global_elements, dofs_per_element, order=-1):
+    """A rank's part of a SERIALISED restart file (one file for the unpartitioned mesh, ``src/io.cpp:104-172, 460-530``):
+    ``global_elements[e]`` = id of local element e in the unpartitioned mesh.  -> (U (len(names), ne * dofs_per_element), info)"""
+    ge = np.ascontiguousarray(global_elements, dtype=np.int64)
+    U = np.zeros((len(names), ge.size * int(dofs_per_element)))
+    info = RestartInfo()
+    if load().tpsrhs_restart_read_serial(str(path).encode(), len(names), ge.size, int(dofs_per_element), ge.ctypes.data_as(C.c_void_p),
+                                         _names(names), int(order), U.ctypes.data_as(C.c_void_p), C.byref(info)) != 0:
+        raise RuntimeError(load().tpsrhs_io_last_error().decode())
+    return U, info
