@@ -29,3 +29,19 @@ def test_every_plasma_instantiation_matches_the_oracle(geo, expected):
     assert not bad, bad[:5]
     assert not died, died
     assert ok == expected, (ok, expected)
+
+
+def test_every_single_fluid_flavour_matches_the_oracle():
+    """Round 4: the same for the single-fluid kernels -- dry air plain (2-D / 3-D, p = 1 ... 5, both basis pairs), with
+    non-reflecting patches, with a sub-grid scale model + the viscous sponge, axisymmetric dry air and the table gas
+    (p = 1 ... 4): 16 + 10 + 10 + 4 + 4 = 44 cases, two consecutive Mult calls each."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_instantiations.py"), "single"], capture_output=True, text=True,
+                       timeout=1500)
+    out = r.stdout
+    bad = [l for l in out.splitlines() if "WRONG" in l or "EXCEPTION" in l or "skipped" in l]
+    died = [l for l in out.splitlines() if l.startswith("==") and not l.rstrip().split("exit code ")[1].split()[0] == "0"]
+    ok = sum(1 for l in out.splitlines() if ": ok " in l)
+    print(out[-2500:])
+    assert not bad, bad[:5]
+    assert not died, died
+    assert ok == 44, ok

@@ -38,6 +38,9 @@ namespace tpsrhs {
 #ifndef TPSRHS_MINW_FLUX
 #define TPSRHS_MINW_FLUX 3  // <= 168 VGPRs: 3 waves per SIMD (the allocator otherwise lands on 170)
 #endif
+#ifndef TPSRHS_NO_MFMA
+#define TPSRHS_NO_MFMA 0  // A/B switch: 1 = the dense inverse mass of the p = 3 Gauss-Lobatto hex on the vector ALU (rounds 2-3)
+#endif
 #ifndef TPSRHS_FLUX_LATE
 #define TPSRHS_FLUX_LATE 0  // experiment: k_flux issues the neighbour records of its first direction pair after the nodal physics
 #endif
@@ -1087,6 +1090,58 @@ __device__ inline void nc_apply_minv(const double *__restrict__ minv, double *sR
   block_sync<C::BLOCK>();
 }
 
+// The same product on the matrix cores, for the p = 3 hex (64 nodes, two waves per block): Y[64 x NV] = Minv[64 x 64] .
+// R[64 x NV] as v_mfma_f64_16x16x4_f64 tiles -- the one dense element-local GEMM of the path (round 4; measured first in
+// tools/microbench/mfma_minv.hip: 8 500 cycles per hex and wave against 22 700 for the loop above, whose 64 dependent
+// row loads it is bound by).  Each wave owns two 16-row tiles of the result; per k-step (4 columns of Minv) a lane
+// supplies A[i = lane % 16][k = lane / 16] straight from global memory -- the block is symmetric, so the tile is read by
+// rows: 4 segments of 128 bytes per load -- and B[k][j = lane % 16] from a transposed, padded LDS copy of the vectors
+// (stride 17: conflict-free); D comes back as D[tile * 16 + lane / 16 + 4 r][lane % 16] and returns to the node-per-lane
+// layout through the same LDS buffer.  NV > 16: passes of 16 vectors.  FP64 matrix and vector peaks are equal on this
+// part: what the matrix cores buy here is the operand delivery (no 960 broadcast LDS reads, 16 independent loads in
+// flight), not arithmetic rate.  Same sums in the same order as the loop above (k ascending): results agree bit for bit
+// in the micro-benchmark.   sB: >= 64 * 17 doubles.
+typedef double mfma_v4d __attribute__((ext_vector_type(4)));
+template <class C, int NV>
+__device__ inline void nc_apply_minv_mfma(const double *__restrict__ minv, double *sB, bool node_on, int e, int nd, int tid,
+                                          double *v) {
+  static_assert(C::NPE == 64 && C::BLOCK == 128 && C::EPB == 1, "the p = 3 hex: one element, two waves");
+  constexpr int LD = 17;
+  const double *Mi = minv + static_cast<int64_t>(e) * (64 * 64);
+  const int wave = tid >> 6, lane = tid & 63, col = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int k0 = 0; k0 < NV; k0 += 16) {
+    if (tid < 64) {  // the node lanes lay their vectors out as B[k = node][j]
+#pragma unroll
+      for (int j = 0; j < 16; j++) sB[tid * LD + j] = (k0 + j < NV && node_on) ? v[(k0 + j < NV) ? k0 + j : 0] : 0.0;
+    }
+    block_sync<C::BLOCK>();
+    mfma_v4d d0 = {0.0, 0.0, 0.0, 0.0}, d1 = {0.0, 0.0, 0.0, 0.0};
+    const double *row = Mi + kk * 64 + (2 * wave) * 16 + col;  // Minv[k][i], i in this wave's two tiles
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ks++) {
+      const double b = ldsr(&sB[(ks * 4 + kk) * LD + col]);
+      const double a0 = row[ks * 256], a1 = row[ks * 256 + 16];
+      d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, d1, 0, 0, 0);
+    }
+    block_sync<C::BLOCK>();  // every read of B is done: the buffer takes D
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      sB[((2 * wave) * 16 + kk + 4 * r) * LD + col] = d0[r];
+      sB[((2 * wave + 1) * 16 + kk + 4 * r) * LD + col] = d1[r];
+    }
+    block_sync<C::BLOCK>();
+    if (tid < 64 && node_on) {
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        if (k0 + j < NV) v[k0 + j] = ldsr(&sB[tid * LD + j]);
+    }
+    block_sync<C::BLOCK>();
+  }
+  (void)nd;
+}
+
 // Face term of the gradient through the face quadrature points (GradFaceIntegrator::AssembleFaceVector,
 // src/faceGradientIntegration.cpp:40-140): g[eq + d*NEQ] += sum_q w_q phi_j(q) 1/2 (Up2 - Up1)(q) n_d(q) over the two
 // faces of direction D.  sT: own | neighbour traces of Up at the face nodes, [2*NEQ][TN]; scr: >= 2*NEQ*TW + NEQ*TQ.
@@ -1900,7 +1955,14 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
     }
   }
   // non-collocated: gradUp = Me^-1 (Ke Up + face terms), dense (src/gradients.cpp:198-229)
-  if constexpr (C::NC) nc_apply_minv<C, NEQ * DIM>(m.minv, pool + L::O_V, node_on, e0 + le_n, le_n, nd, tid, g);
+  if constexpr (C::NC) {
+    if constexpr (C::NPE == 64 && C::BLOCK == 128 && !TPSRHS_NO_MFMA) {
+      static_assert(L::V >= 64 * 17, "LDS buffer of the MFMA inverse mass");
+      nc_apply_minv_mfma<C, NEQ * DIM>(m.minv, pool + L::O_V, node_on, e0, nd, tid, g);
+    }
+    else
+      nc_apply_minv<C, NEQ * DIM>(m.minv, pool + L::O_V, node_on, e0 + le_n, le_n, nd, tid, g);
+  }
 
   STAMP(3);
   if (node_on) {
@@ -2787,7 +2849,12 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   }
 
   if constexpr (C::NC) {  // y = Me^-1 z (src/rhs_operator.cpp:432-448), then the point sources
-    nc_apply_minv<C, NEQ>(m.minv, sX, node_on, e0 + le_n, le_n, nd, tid, z);
+    if constexpr (C::NPE == 64 && C::BLOCK == 128 && !TPSRHS_NO_MFMA) {
+      static_assert(L::GF >= 64 * 17, "LDS buffer of the MFMA inverse mass");
+      nc_apply_minv_mfma<C, NEQ>(m.minv, sGf, node_on, e0, nd, tid, z);  // (the flux / scratch region is free by now; sU is not: stage 1 of the time loop reads it)
+    }
+    else
+      nc_apply_minv<C, NEQ>(m.minv, sX, node_on, e0 + le_n, le_n, nd, tid, z);
     inv_mass = 1.0;
   }
   if (node_on) {
