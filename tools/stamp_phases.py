@@ -20,13 +20,16 @@ import bench  # noqa: E402
 
 order, physics, make_bcs, make_state, description, _ = bench.workload(os.environ.get("STAMP_WORKLOAD", "argon_p3"))  # or cfg3
 mesh = meshgen.ogrid_cylinder_slab(28, 112, 16, 0, 1)
-disc = capi.Disc(order, 0, 0, 0, 0)
-X = node_coordinates(mesh, order)
+nc = 1 if os.environ.get("STAMP_WORKLOAD", "").startswith("gll") else 0  # the Gauss-Lobatto pair
+disc = capi.Disc(order, nc, nc, 0, 0)
+X = node_coordinates(mesh, order, nc)
 U = make_state(X, physics)
 op = RHSoperator(mesh, disc, physics, make_bcs(physics), device=0)
 x = torch.tensor(U.ravel(), dtype=torch.float64, device=op.device)
 y = torch.empty_like(x)
-lib = C.CDLL(os.path.join(os.environ["TPSRHS_FAMILY_PATH"].split(":")[0], "libtpsrhs_plasma_3d_n3a.so"))  # the diagnostic build of the family
+# the diagnostic build: a plasma family (TPSRHS_FAMILY_PATH) or, for the dry-air workloads, the core library (TPSRHS_LIB)
+lib = (C.CDLL(os.environ["TPSRHS_LIB"]) if os.environ.get("STAMP_WORKLOAD", "argon_p3") in ("cfg2", "gll_dry")
+       else C.CDLL(os.path.join(os.environ["TPSRHS_FAMILY_PATH"].split(":")[0], "libtpsrhs_plasma_3d_n3a.so")))
 import numpy as np  # noqa: E402
 
 nblocks = mesh.num_elements // (2 if order == 2 else 1)  # elements per block: one p = 3 hex, two p = 2 hexes

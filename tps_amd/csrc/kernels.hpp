@@ -1835,7 +1835,8 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
   const int tid = threadIdx.x;
   const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
   const int bid = m.blocks ? m.blocks[lin] : lin;
-  const int e0 = bid * C::EPB;
+  // (TPSRHS_ABLATE & 512, timing experiment: every block works on one of 8 elements -- all loads become cache hits)
+  const int e0 = (TPSRHS_ABLATE & 512) ? (bid % 8) * C::EPB : bid * C::EPB;
   __shared__ int2 sFI[C::EPB * C::NFACES];
   STAMP_DECL;
   STAMP_START();
@@ -2607,7 +2608,7 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   const int tid = threadIdx.x;
   const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
   const int bid = m.blocks ? m.blocks[lin] : lin;
-  const int e0 = bid * C::EPB;
+  const int e0 = (TPSRHS_ABLATE & 512) ? (bid % 8) * C::EPB : bid * C::EPB;  // (512: timing experiment, as in k_gradient)
   __shared__ int2 sFI[C::EPB * C::NFACES];
   FSTAMP_DECL;
   const bool node_on = tid < C::NODES && (e0 + tid / C::NPE) < m.ne;

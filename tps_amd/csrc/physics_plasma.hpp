@@ -51,6 +51,10 @@ struct ChemDev {  // ChemistryInput, device image (lives in a device buffer; uni
   signed char model[TPSRHS_MAXREACTIONS];
   signed char detailed_balance[TPSRHS_MAXREACTIONS];
   TableDev table[TPSRHS_MAXREACTIONS];
+  // table_share[r] = the first reaction whose rate table has the same abscissae as reaction r's (r itself if none): the
+  // interval found for one of them at a temperature serves the others at the same temperature (the 14 rate tables of the
+  // reference's test/inputs/rate-coefficients share one 500-point grid; the host compares the abscissae value by value)
+  signed char table_share[TPSRHS_MAXREACTIONS];
   int radiation;  // tpsrhs_radiation_model
   TableDev nec;
 };
@@ -1673,6 +1677,8 @@ struct PlasmaPhys {
       double creation[NSP];
 #pragma unroll
       for (int sp = 0; sp < NSP; sp++) creation[sp] = 0.0;
+      int tab_root = -1, tab_idx = 0;  // the last table interval found: (grid, temperature) -> interval
+      double tab_temp = 0.0;
       for (int r = 0; r < c.num_reactions; r++) {
         const bool el = (c.electron_index < 0) ? false : (c.reactant[c.electron_index + r * NSP] != 0);
         const double temp = el ? Tel : Thl;
@@ -1683,8 +1689,21 @@ struct PlasmaPhys {
         } else if (c.model[r] == TPSRHS_HOFFERTLIEN) {
           const double tf = E / kBoltz / temp;
           kf = A * (tf + 2.0) * fexp(b * flog(temp) - tf);
-        } else {
-          kf = table_eval(c.table[r], temp);
+        } else {  // LinearTable::eval (src/table.cpp:80-101); the interval search shared between tables of one grid
+          const TableDev &tb = c.table[r];
+          const int root = c.table_share[r];
+          int ti;
+          if (root == tab_root && temp == tab_temp) {
+            ti = tab_idx;
+          } else {
+            ti = table_interval(tb, temp);
+            tab_root = root;
+            tab_temp = temp;
+            tab_idx = ti;
+          }
+          const double xt = tb.x_log ? flog(temp) : temp;
+          kf = tb.a[ti] + tb.b[ti] * xt;
+          if (tb.f_log) kf = fexp(kf);
         }
         double rate = 1.0;
 #pragma unroll

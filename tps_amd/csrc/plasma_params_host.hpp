@@ -172,7 +172,22 @@ void fill_plasma_params(PlasmaParams<NSP> &p, ChemDev &chem, const tpsrhs_disc *
       c->reactant[sp + r * NSP] = static_cast<signed char>(a);
       c->product[sp + r * NSP] = static_cast<signed char>(b);
     }
-    if (ch.reaction_models[r] == TPSRHS_TABULATED_RXN) c->table[r] = place_table(ch.rate_tables[r]);
+    c->table_share[r] = static_cast<signed char>(r);
+    if (ch.reaction_models[r] == TPSRHS_TABULATED_RXN) {
+      c->table[r] = place_table(ch.rate_tables[r]);
+      const tpsrhs_table &t = ch.rate_tables[r];
+      for (int q = 0; q < r; q++) {  // an earlier tabulated reaction on the same abscissae (same scale flag: the same search)?
+        if (ch.reaction_models[q] != TPSRHS_TABULATED_RXN || c->table_share[q] != q) continue;
+        const tpsrhs_table &o = ch.rate_tables[q];
+        if (o.n_data != t.n_data) continue;
+        bool same = true;
+        for (int k = 0; k < t.n_data && same; k++) same = (o.x_data[k] == t.x_data[k]);
+        if (same) {
+          c->table_share[r] = static_cast<signed char>(q);
+          break;
+        }
+      }
+    }
   }
   c->radiation = phys->radiation.model;
   if (c->radiation == TPSRHS_NET_EMISSION) c->nec = place_table(phys->radiation.nec_table);

@@ -639,6 +639,15 @@ int guarded(F &&f) {
 
 }  // namespace
 
+#if TPSRHS_STAMP
+// diagnostic builds of this unit (-DTPSRHS_STAMP=1 / 2, tools/stamp_phases.py with a dry-air workload): the phase cycles of
+// the first `nblocks` blocks of the last stamped kernel
+extern "C" int tpsrhs_debug_stamps(unsigned int *out, int nblocks) {
+  const size_t bytes = static_cast<size_t>(nblocks) * tpsrhs::NSTAMP * sizeof(unsigned int);
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(tpsrhs::g_stamp), bytes) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" {
 
 int tpsrhs_create(const tpsrhs_mesh *mesh, const tpsrhs_disc *disc, const tpsrhs_physics *physics, int num_bcs,
