@@ -821,7 +821,10 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::KAr
 // mass matrix of a non-affine element has no tensor structure and is applied as the dense NPE x NPE block the
 // reference stores too (32 KB per hex at p = 3, streamed once per sweep).
 // =============================================================================================
-constexpr int NC_NFC = 2;  // fields per chunk of the volume operators (LDS scratch per chunk ~ 9 KB per field at p = 3)
+#ifndef TPSRHS_NC_NFC
+#define TPSRHS_NC_NFC 3  // (round 4: 2 -> 3, gll_dry 3.23 -> 3.07 ms; 5 -- one chunk for dry air -- halves the occupancy: 4.58 ms)
+#endif
+constexpr int NC_NFC = TPSRHS_NC_NFC;  // fields per chunk of the volume operators (LDS scratch per chunk ~ 9 KB per field at p = 3)
 
 // One axis of a tensor-product operator on `nbatch` arrays [d2][d1][d0] in LDS:
 //   out[b][..r..] = sum_a c(r, a) in[b][..a..] along axis AX (0 = fastest), a < NIN = d_AX, r < NOUT;
@@ -2398,6 +2401,13 @@ struct FluxLds {
   static_assert(!C::NC || X >= NEQ * C::NODES, "staging of the inverse-mass vectors");
 };
 
+template <class PH>
+__device__ inline typename PH::PRef flux_params(typename PH::PRef p) {
+  if constexpr (PH::LAUNDER_FLUX)
+    return PH::relaunder(p);
+  else
+    return p;
+}
 template <class C, class PH, int D>
 __device__ inline void face_flux_dir(const MeshDev &m, typename PH::PRef prm, int e0, const double *sU,
                                      double *X, double *Yb, const double *sV, const Tab<C> &tab, const Tables1D &ct,
@@ -2511,12 +2521,15 @@ __device__ inline void issue_visc_traces_2d(const int2 *sFI, int e0, const doubl
   }
 }
 template <class C, class PH>
-__device__ inline void face_flux_2d(const MeshDev &m, typename PH::PRef prm, int e0, const double *sU, double *X,
+__device__ inline void face_flux_2d(const MeshDev &m, typename PH::PRef prm0, int e0, const double *sU, double *X,
                                     double *Yb, const double *sV, const Tab<C> &tab, const Tables1D &ct,
                                     const NbTraces<C, PH::NEQ> &ta0, const NbTraces<C, PH::NEQ> &ta1,
                                     const NbFlux2<C, PH::NEQ> &tb, bool node_on, int le_n, const int *idx, double *z,
                                     int tid) {
   static_assert(C::DIM == 2, "2-D only");
+  // (the table gas: its table records are fetched from the parameter image HERE, not at the top of the kernel, where they
+  //  would sit in -- or be spilled from -- 100 SGPRs across the nodal physics)
+  typename PH::PRef prm = flux_params<PH>(prm0);
   constexpr int NEQ = PH::NEQ, DIM = 2;
   constexpr int XS = 2 * NEQ * C::TN;  // own | neighbour traces of one direction pair
   trace_lines<C, 0, NEQ>(sU, X, ct, tid);

@@ -206,6 +206,7 @@ struct DryAirPhys {
   static constexpr bool HEAVY = false;  // light point physics: inlined at every face pass
   static constexpr bool TWO_STEP = false;  // no state-only closure worth separating from the gradient terms
   static constexpr bool LEAN_TRACE = false;
+  static constexpr bool LAUNDER_FLUX = false;  // k_flux re-fetches the parameter image where its face term starts (the table gas)
   struct FluxCoef {};
   static constexpr int MINW_GRAD = TPSRHS_MINW_GRAD, MINW_FLUX = TPSRHS_MINW_FLUX;  // launch-bound waves per SIMD
   // k_gradient of the p = 3 hex (one wave per element, 10 KB of LDS).  Round 2 capped it at 128 VGPRs = four waves per

@@ -37,22 +37,26 @@ struct LteParams : DryAirParams {
   double e0, inv_de;
 };
 // LinearTable::eval / eval_x (src/table.cpp:80-113) in a known interval
-__device__ inline double table_at(const TableDev &t, int idx, double xe) {
+template <class TD>
+__device__ inline double table_at(const TD &t, int idx, double xe) {
   const double xt = t.x_log ? flog(xe) : xe;
   double ft = t.a[idx] + t.b[idx] * xt;
   if (t.f_log) ft = fexp(ft);
   return ft;
 }
-__device__ inline double table_slope_at(const TableDev &t, int idx, double xe) {
+template <class TD>
+__device__ inline double table_slope_at(const TD &t, int idx, double xe) {
   const double xt = t.x_log ? flog(xe) : xe;
   double ft_x = t.b[idx] * (t.x_log ? 1.0 / xe : 1.0);
   if (t.f_log) ft_x *= fexp(t.a[idx] + t.b[idx] * xt);
   return ft_x;
 }
-__device__ inline double table_eval_x(const TableDev &t, double xe) { return table_slope_at(t, table_interval(t, xe), xe); }
+template <class TD>
+__device__ inline double table_eval_x(const TD &t, double xe) { return table_slope_at(t, table_interval(t, xe), xe); }
 // findInterval of the inverse table T(e) through the bins
-__device__ inline int lte_energy_interval(const LteParams &p, double e) {
-  const TableDev &t = p.tab_T;
+template <class LP>
+__device__ inline int lte_energy_interval(const LP &p, double e) {
+  const auto &t = p.tab_T;
   if (p.ehint) {
     const double fj = fmin(fmax((e - p.e0) * p.inv_de, 0.0), static_cast<double>(p.nhint - 1));  // (NaN -> 0)
     int g = p.ehint[static_cast<int>(fj)];
@@ -64,7 +68,8 @@ __device__ inline int lte_energy_interval(const LteParams &p, double e) {
 // LteMixture::ComputeTemperatureInternal, src/lte_mixture.cpp:161-218: Newton on e(T) = energy from the inverse table
 // (the reference asserts convergence; a state that does not converge returns NaN here and is caught like any other).
 // `it`: the interval of the result in the temperature grid of the thermodynamic tables.
-__device__ inline double lte_temperature(const LteParams &p, double energy, int &it) {
+template <class LP>
+__device__ inline double lte_temperature(const LP &p, double energy, int &it) {
   double T = table_at(p.tab_T, lte_energy_interval(p, energy), energy);
   it = table_interval(p.tab_e, T);
   double res = energy - table_at(p.tab_e, it, T);
@@ -84,12 +89,14 @@ __device__ inline double lte_temperature(const LteParams &p, double energy, int 
   return converged ? T : __builtin_nan("");
 }
 // a thermodynamic table other than e(T) at a temperature whose interval in e's grid is known
-__device__ inline double lte_thermo_at(const LteParams &p, const TableDev &t, int it, double T) {
+template <class LP, class TD>
+__device__ inline double lte_thermo_at(const LP &p, const TD &t, int it, double T) {
   return p.thermo_same_grid ? table_at(t, it, T) : table_eval(t, T);
 }
 // LteMixture::ComputeTemperatureFromDensityPressure, src/lte_mixture.cpp:236-296: Newton on p = rho R(T) T
 // (the reference goes on with the last iterate when the iteration has not converged)
-__device__ inline double lte_temperature_rho_p(const LteParams &p, double rho, double pres, int &it) {
+template <class LP>
+__device__ inline double lte_temperature_rho_p(const LP &p, double rho, double pres, int &it) {
   double T = pres / (rho * 208.);
   it = table_interval(p.tab_R, T);
   double R = table_at(p.tab_R, it, T);
@@ -119,6 +126,7 @@ struct GasAxiPhys {
   static constexpr bool HAS_SOURCE = true, AXISYM = true, HEAVY = true, TWO_TEMPERATURE = false, HAS_NR_BC = false;
   static constexpr bool TWO_STEP = false;
   static constexpr bool LEAN_TRACE = false;
+  static constexpr bool LAUNDER_FLUX = LTE_;  // k_flux re-fetches the parameter image where its face term starts (the table gas)
   struct FluxCoef {};
   static constexpr bool VISC_USES_GRAD_RHO = false;
   static constexpr int MAX_ORDER = 4;
@@ -128,18 +136,36 @@ struct GasAxiPhys {
   static constexpr bool HAS_MIXED_OUT = false;  // mixed-out sponge target: dry air, planar / 3-D
   static constexpr bool LTE = LTE_;
   typedef std::conditional_t<LTE_, LteParams, DryAirParams> Params;
-  typedef Params KArg;
-  typedef const Params &PRef;
-  typedef const BcDev &BcRef;
-  __device__ static inline PRef pref(const KArg &k) { return k; }
-  __device__ static inline PRef relaunder(PRef p) { return p; }
+  // The table gas reads its parameter block -- eight table records, 70-180 spilled SGPRs when it travelled by value in the
+  // kernel-argument segment (round 3) -- from a device image through the CONSTANT address space, like the plasma kernels
+  // (PlasmaPhys::KArg); dry air keeps the by-value block.
+  typedef std::conditional_t<LTE_, const Params *, Params> KArg;
+  typedef std::conditional_t<LTE_, const Params __attribute__((address_space(4))) &, const Params &> PRef;
+  typedef std::conditional_t<LTE_, const BcDev __attribute__((address_space(4))) &, const BcDev &> BcRef;
+  __device__ static inline PRef pref(const KArg &k) {
+    if constexpr (LTE_)
+      return *(const Params __attribute__((address_space(4))) *)k;
+    else
+      return k;
+  }
+  __device__ static inline PRef relaunder(PRef p) {
+    if constexpr (LTE_) {  // as PlasmaPhys::relaunder: loads through the result cannot be hoisted above this point
+      const unsigned long long a = reinterpret_cast<unsigned long long>(&p);
+      unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a));
+      unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a >> 32));
+      asm volatile("" : "+s"(lo), "+s"(hi));
+      return *reinterpret_cast<const Params __attribute__((address_space(4))) *>((static_cast<unsigned long long>(hi) << 32) | lo);
+    } else {
+      return p;
+    }
+  }
   struct State {
     double ir, k, p;
     double vel[NVEL];
     double T;  // table gas only
     int it;    // ... and the interval of T in the grid of the thermodynamic tables
   };
-  __device__ static inline State make_state(const Params &p, const double *U) {
+  __device__ static inline State make_state(PRef p, const double *U) {
     State s;
     s.ir = fast_rcp(U[0]);
     double m2 = 0.0;
@@ -159,13 +185,13 @@ struct GasAxiPhys {
   }
   // temperature of a state; rho e of a density at a pressure (modifyEnergyForPressure) / at a temperature
   // (computeStagnantStateWithTemp); speed of sound
-  __device__ static inline double temperature(const Params &p, const State &s) {
+  __device__ static inline double temperature(PRef p, const State &s) {
     if constexpr (LTE_)
       return s.T;
     else
       return s.p * p.inv_Rg * s.ir;
   }
-  __device__ static inline double rho_e_at_pressure(const Params &p, double rho, double pres) {
+  __device__ static inline double rho_e_at_pressure(PRef p, double rho, double pres) {
     if constexpr (LTE_)
     {
       int it;  // (the interval is R's: e shares it when the tables share their grid)
@@ -175,13 +201,13 @@ struct GasAxiPhys {
     else
       return pres / (p.gamma - 1.0);
   }
-  __device__ static inline double rho_e_at_temperature(const Params &p, double rho, double T) {
+  __device__ static inline double rho_e_at_temperature(PRef p, double rho, double T) {
     if constexpr (LTE_)
       return rho * table_eval(p.tab_e, T);  // src/lte_mixture.cpp:424-441
     else
       return p.Rg / (p.gamma - 1.0) * rho * T;
   }
-  __device__ static inline double sound(const Params &p, const State &s) {
+  __device__ static inline double sound(PRef p, const State &s) {
     if constexpr (LTE_)
       return lte_thermo_at(p, p.tab_c, s.it, s.T);  // src/lte_mixture.cpp:357-372
     else
@@ -189,13 +215,13 @@ struct GasAxiPhys {
   }
   // computeStagnationState: DryAir's (src/equation_of_state.cpp:367-378) rebuilds rho e from the pressure; the table gas
   // inherits GasMixture's (:100-113), total minus bulk kinetic energy
-  __device__ static inline double stagnation_energy(const Params &p, const double *U, const State &s) {
+  __device__ static inline double stagnation_energy(PRef p, const double *U, const State &s) {
     if constexpr (LTE_)
       return U[ITH] - 0.5 * s.k;
     else
       return s.p / (p.gamma - 1.0);
   }
-  __device__ static inline void prim(const Params &p, const double *U, double *Up) {
+  __device__ static inline void prim(PRef p, const double *U, double *Up) {
     const State s = make_state(p, U);
     Up[0] = U[0];
 #pragma unroll
@@ -203,14 +229,14 @@ struct GasAxiPhys {
     Up[ITH] = temperature(p, s);
   }
   __device__ static inline void clamp_species(double *) {}
-  __device__ static inline double max_char_speed(const Params &p, const double *, const State &s) {
+  __device__ static inline double max_char_speed(PRef p, const double *, const State &s) {
     return fast_sqrt(s.k * s.ir) + sound(p, s);
   }
-  __device__ static inline double max_char_speed(const Params &p, const double *U) {
+  __device__ static inline double max_char_speed(PRef p, const double *U) {
     return max_char_speed(p, U, make_state(p, U));
   }
-  __device__ static inline double pressure(const Params &p, const double *U) { return make_state(p, U).p; }
-  __device__ static inline double sound_speed(const Params &p, const double *U) {  // src/equation_of_state.cpp:337-348
+  __device__ static inline double pressure(PRef p, const double *U) { return make_state(p, U).p; }
+  __device__ static inline double sound_speed(PRef p, const double *U) {  // src/equation_of_state.cpp:337-348
     const State s = make_state(p, U);
     if constexpr (LTE_)
       return sound(p, s);
@@ -225,7 +251,7 @@ struct GasAxiPhys {
     Fn[3] = U[3] * un;
     Fn[ITH] = un * (U[ITH] + s.p);
   }
-  __device__ static inline void lax_friedrichs(const Params &p, const double *U1, const double *U2, const double *n,
+  __device__ static inline void lax_friedrichs(PRef p, const double *U1, const double *U2, const double *n,
                                                double *F) {
     const State s1 = make_state(p, U1), s2 = make_state(p, U2);
     const double lam = fmax(max_char_speed(p, U1, s1), max_char_speed(p, U2, s2));
@@ -237,15 +263,15 @@ struct GasAxiPhys {
     for (int eq = 0; eq < NEQ; eq++) F[eq] = 0.5 * (f1[eq] + f2[eq]) - hl * (U2[eq] - U1[eq]);
   }
   // RiemannSolverTPS::Eval: Lax-Friedrichs only here (Eval_Roe is 2-D single-species, not axisymmetric)
-  __device__ static inline void riemann(const Params &p, const double *U1, const double *U2, const double *n, double *F) {
+  __device__ static inline void riemann(PRef p, const double *U1, const double *U2, const double *n, double *F) {
     lax_friedrichs(p, U1, U2, n, F);
   }
-  __device__ static inline void riemann_bc(const Params &p, const BcDev &, const double *U1, const double *Ug,
+  __device__ static inline void riemann_bc(PRef p, BcRef, const double *U1, const double *Ug,
                                            const double *n, double *F) {
     lax_friedrichs(p, U1, Ug, n, F);
   }
   // Sutherland viscosity, bulk viscosity and conductivity at the temperature of a conserved state
-  __device__ static inline void transport(const Params &p, const State &s, double &visc, double &bulk, double &k) {
+  __device__ static inline void transport(PRef p, const State &s, double &visc, double &bulk, double &k) {
     if constexpr (LTE_) {  // LteTransport::ComputeFluxMolecularTransport, src/lte_transport_properties.cpp:84-107
       const int im = table_interval(p.tab_mu, s.T);
       visc = table_at(p.tab_mu, im, s.T);
@@ -259,11 +285,17 @@ struct GasAxiPhys {
     }
   }
   // Fv(U, g) . n with the axisymmetric stresses; `zero_heat` drops the conduction term (adiabatic wall)
-  __device__ static inline void visc_normal_flux(const Params &p, const double *U, const double *g, const double *n,
+  __device__ static inline void visc_normal_flux(PRef p, const double *U, const double *g, const double *n,
                                                  double radius, bool zero_heat, double *Fn, const EddyCtx &ec = eddy_off()) {
     const State s = make_state(p, U);
     double visc, bulkv, k;
     transport(p, s, visc, bulkv, k);
+    visc_normal_flux_of(s, visc, bulkv, k, U, g, n, radius, zero_heat, Fn, ec);
+  }
+  // ... of a state whose closure (for the table gas: a Newton inversion of e(T) and the transport tables) is known
+  __device__ static inline void visc_normal_flux_of(const State &s, double visc, double bulkv, double k, const double *U,
+                                                    const double *g, const double *n, double radius, bool zero_heat, double *Fn,
+                                                    const EddyCtx &ec = eddy_off()) {
     add_mixing_length<DIM, NVEL, NEQ>(ec, U, g, radius, visc, bulkv, k);
     double bulk = bulkv - 2. / 3. * visc;
     const double vsw = sponge_weight(ec);  // viscous sponge, src/fluxes.cpp:232-238 (after the -2/3 mu of the bulk viscosity)
@@ -294,7 +326,7 @@ struct GasAxiPhys {
     if (!zero_heat) e += k * (g[ITH + 0 * NEQ] * n[0] + g[ITH + 1 * NEQ] * n[1]);
     Fn[ITH] = e;
   }
-  __device__ static inline void total_flux(const Params &p, const double *U, const State &s, const double *g,
+  __device__ static inline void total_flux(PRef p, const double *U, const State &s, const double *g,
                                            double radius, double *F, const EddyCtx &ec = eddy_off()) {
     const double H = U[ITH] + s.p;
 #pragma unroll
@@ -305,17 +337,20 @@ struct GasAxiPhys {
       F[ITH + d * NEQ] = s.vel[d] * H;
     }
     if (p.eq_system == TPSRHS_EULER) return;
-    // F_c - F_v: the viscous flux along each coordinate direction is its normal flux with n = e_d
+    // F_c - F_v: the viscous flux along each coordinate direction is its normal flux with n = e_d; the state's closure
+    // (`s`: the caller's) and the transport coefficients are evaluated ONCE, not per direction (round 4)
+    double visc, bulkv, k;
+    transport(p, s, visc, bulkv, k);
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
       const double nd[DIM] = {d == 0 ? 1.0 : 0.0, d == 1 ? 1.0 : 0.0};
       double fv[NEQ];
-      visc_normal_flux(p, U, g, nd, radius, false, fv, ec);
+      visc_normal_flux_of(s, visc, bulkv, k, U, g, nd, radius, false, fv, ec);
 #pragma unroll
       for (int eq = 0; eq < NEQ; eq++) F[eq + d * NEQ] -= fv[eq];
     }
   }
-  __device__ static inline void bc_ghost(const Params &p, const BcDev &bc, const double *U, const double *n,
+  __device__ static inline void bc_ghost(PRef p, BcRef bc, const double *U, const double *n,
                                          double *Ug, const double * = nullptr) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) Ug[eq] = U[eq];
@@ -353,7 +388,7 @@ struct GasAxiPhys {
     }
   }
   // the viscous trace of one face quadrature point (see PlasmaPhys::visc_trace)
-  __device__ static inline void visc_trace(const Params &p, int nb, const double *U, const double *g, const double *n,
+  __device__ static inline void visc_trace(PRef p, int nb, const double *U, const double *g, const double *n,
                                            double radius, double *fn, const EddyCtx &ec = eddy_off()) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) fn[eq] = 0.0;
@@ -362,7 +397,7 @@ struct GasAxiPhys {
       visc_normal_flux(p, U, g, n, radius, false, fn, ec);
       return;
     }
-    const BcDev &bc = p.bc[-nb - 1];
+    BcRef bc = p.bc[-nb - 1];
     if (bc.category != TPSRHS_WALL || bc.type == TPSRHS_SLIP) return;  // slip wall: Riemann flux only (src/wallBC.cpp:326-428)
     // the wall routines hand the flux class distance 0 (viscous walls, src/wallBC.cpp:441-536) or the interpolated
     // distance (inviscid wall, :309-313)
@@ -392,7 +427,7 @@ struct GasAxiPhys {
 #pragma unroll
     for (int eq = 1; eq < NEQ; eq++) fn[eq] -= 0.5 * f[eq];
   }
-  __device__ static inline void bc_grad_prim(const Params &p, const BcDev &bc, const double *Up, double *UpB) {
+  __device__ static inline void bc_grad_prim(PRef p, BcRef bc, const double *Up, double *UpB) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) UpB[eq] = Up[eq];
     if (p.use_bc_in_grad && bc.category == TPSRHS_WALL && bc.type == TPSRHS_VISC_ISOTH) {
@@ -402,7 +437,7 @@ struct GasAxiPhys {
     }
   }
   // SourceTerm::updateTerms (src/source_term.cpp:62-256) for one species: only the radiation sink is left
-  __device__ static inline void source(const Params &p, const double *, const double *Up, const double *, double *src) {
+  __device__ static inline void source(PRef p, const double *, const double *Up, const double *, double *src) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) src[eq] = 0.0;
     if constexpr (LTE_) {
@@ -410,7 +445,7 @@ struct GasAxiPhys {
     }
   }
   // SrcTrns::ELECTRIC_CONDUCTIVITY: LteTransport::ComputeSourceMolecularTransport, src/lte_transport_properties.cpp:109-126
-  __device__ static inline double electric_conductivity(const Params &p, const double *U) {
+  __device__ static inline double electric_conductivity(PRef p, const double *U) {
     if constexpr (LTE_) {
       const double sigma = table_eval(p.tab_sigma, make_state(p, U).T);
       return sigma < 1.0 ? 1.0 : sigma;
@@ -418,7 +453,7 @@ struct GasAxiPhys {
       return 0.0;
     }
   }
-  __device__ static inline void axisym_source(const Params &p, const double *U, const double *Up, const double *g,
+  __device__ static inline void axisym_source(PRef p, const double *U, const double *Up, const double *g,
                                               double radius, double *src) {
     const double rho = Up[0], ur = Up[1], ut = Up[3];
     double pres;

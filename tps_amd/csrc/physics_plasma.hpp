@@ -93,8 +93,10 @@ __device__ inline double ipow(double x, int k) {  // pow(x, small non-negative i
 // LinearTable::findInterval (src/table.cpp:52-78): the interval idx with x[idx] < xe <= x[idx+1], clamped to the
 // table (lower_bound, then first - 1).  Bisection as in the reference, or -- on a uniformly spaced table -- the
 // interval computed from the spacing and corrected / verified against the abscissae, which selects the same
-// interval with 2-3 dependent loads instead of 9-10.
-__device__ inline int table_interval(const TableDev &t, double xe) {
+// interval with 2-3 dependent loads instead of 9-10.  (TD: a TableDev in the generic or in the CONSTANT address space --
+// the records of the table gas live in its parameter image.)
+template <class TD>
+__device__ inline int table_interval(const TD &t, double xe) {
   if (t.inv_dx > 0.0) {
     int g = static_cast<int>((xe - t.x0) * t.inv_dx);
     g = max(0, min(t.n - 2, g));
@@ -117,7 +119,8 @@ __device__ inline int table_interval(const TableDev &t, double xe) {
   first = max(1, min(t.n - 1, first));
   return first - 1;
 }
-__device__ inline double table_eval(const TableDev &t, double xe) {  // src/table.cpp:80-101
+template <class TD>
+__device__ inline double table_eval(const TD &t, double xe) {  // src/table.cpp:80-101
   const int idx = table_interval(t, xe);
   const double xt = t.x_log ? flog(xe) : xe;
   double ft = t.a[idx] + t.b[idx] * xt;
@@ -274,6 +277,7 @@ struct PlasmaPhys {
   // 12-18 values across the gradient interpolation instead of 38, the nodal gradient re-read from the L2 instead of held
   // in LDS -- 168 registers and 12 KB, THREE waves per SIMD (round 4; the collocated p <= 3 hexes, one wave per block).
   static constexpr bool LEAN_TRACE = (NSP_ == 3) && (DIM_ == 3);
+  static constexpr bool LAUNDER_FLUX = false;  // k_flux re-fetches the parameter image where its face term starts (the table gas)
   static constexpr int minw_grad(int dim, int p, int nc) {
     return (LEAN_TRACE && dim == 3 && !nc && p <= 3) ? TPSRHS_PLASMA_MINW_GRAD_LEAN : MINW_GRAD;
   }
