@@ -38,6 +38,9 @@ namespace tpsrhs {
 #ifndef TPSRHS_MINW_FLUX
 #define TPSRHS_MINW_FLUX 3  // <= 168 VGPRs: 3 waves per SIMD (the allocator otherwise lands on 170)
 #endif
+#ifndef TPSRHS_NT_STORES
+#define TPSRHS_NT_STORES 0  // experiment: non-temporal stores of the streams k_gradient never reads back (Up, TB)
+#endif
 #ifndef TPSRHS_NO_MFMA
 #define TPSRHS_NO_MFMA 0  // A/B switch: 1 = the dense inverse mass of the p = 3 Gauss-Lobatto hex on the vector ALU (rounds 2-3)
 #endif
@@ -1713,7 +1716,12 @@ __device__ inline void visc_phase_lean3d(const MeshDev &m, const int2 *sFI, type
         PH::visc_normal_flux_lean(cf, gv, gn, n, f);
         if (nb >= 0) {
 #pragma unroll
-          for (int eq = 1; eq < NEQ; eq++) out[(eq - 1) * C::NQ] = f[eq];  // f[0] == 0 (src/fluxes.cpp:284)
+          for (int eq = 1; eq < NEQ; eq++) {  // f[0] == 0 (src/fluxes.cpp:284)
+            if (TPSRHS_NT_STORES)
+              __builtin_nontemporal_store(f[eq], &out[(eq - 1) * C::NQ]);
+            else
+              out[(eq - 1) * C::NQ] = f[eq];
+          }
         } else if (pass == 0) {  // wall face: -1/2 (Fv_in + Fv_wall) . n, the interior half first
 #pragma unroll
           for (int eq = 1; eq < NEQ; eq++) out[(eq - 1) * C::NQ] = -0.5 * f[eq];
@@ -1873,7 +1881,10 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
       sUp[eq * C::NODES + tid] = up[eq];
       // the Up grid function (a side effect Mult owns, src/rhs_operator.cpp:623-651) is written here: this
       // sweep is not bandwidth-bound, k_traces is
-      field_ptr(Upout, eq, m.ndofs)[n] = up[eq];
+      if (TPSRHS_NT_STORES)
+        __builtin_nontemporal_store(up[eq], &field_ptr(Upout, eq, m.ndofs)[n]);
+      else
+        field_ptr(Upout, eq, m.ndofs)[n] = up[eq];
     }
   }
   block_sync<C::BLOCK>();
