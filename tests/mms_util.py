@@ -233,3 +233,122 @@ def compute_rhs_errors(l2_norm, y, S):
     e1 = np.hypot(l2_norm(y[1]), l2_norm(y[2])) / np.hypot(l2_norm(S[1]), l2_norm(S[2]))
     e2 = l2_norm(y[3]) / l2_norm(S[3])
     return e0, e1, e2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# test/mms.euler.test: the transient 3-D Euler solution `euler_transient_3d` (MASA [third party, absent]) run for 300 / 600
+# RK4 steps on periodic-cube.mesh refined once / twice, p = 1, basisType = integrationRule = 0 (test/inputs/
+# mms.euler.3d.r1.ini, r2.ini); the test holds the convergence RATES of the density / velocity / pressure errors.
+# EVERY parameter of the solution is set by the reference (src/masa_handler.cpp:356-417, below); the form is MASA's:
+#     rho = rho_0 + rho_x sin(a_rhox pi x/L) + rho_y cos(a_rhoy pi y/L) + rho_z sin(a_rhoz pi z/L) + rho_t sin(a_rhot pi t/L)
+#     u   = u_0   + u_x   sin(a_ux   pi x/L) + u_y   cos(a_uy   pi y/L) + u_z   cos(a_uz   pi z/L) + u_t   cos(a_ut   pi t/L)
+#     v   = v_0   + v_x   cos(a_vx   pi x/L) + v_y   sin(a_vy   pi y/L) + v_z   sin(a_vz   pi z/L) + v_t   sin(a_vt   pi t/L)
+#     w   = w_0   + w_x   sin(a_wx   pi x/L) + w_y   sin(a_wy   pi y/L) + w_z   cos(a_wz   pi z/L) + w_t   cos(a_wt   pi t/L)
+#     p   = p_0   + p_x   cos(a_px   pi x/L) + p_y   sin(a_py   pi y/L) + p_z   cos(a_pz   pi z/L) + p_t   cos(a_pt   pi t/L)
+# (the spatial part is MASA's published euler_3d, the time terms follow its euler_transient_1d; `forms` = one letter
+# s / c per variable for the TIME term, so that tools/mms_euler_transient.py can run the family -- the default is the
+# form above).
+TPS_EULER_TRANSIENT_3D = dict(
+    Gamma=1.4, L=2.0,
+    rho_0=1.0, rho_x=0.1, rho_y=0.1, rho_z=0.0, rho_t=0.15, u_0=130.0, u_x=10.0, u_y=5.0, u_z=0.0, u_t=10.0,
+    v_0=5.0, v_x=1.0, v_y=-1.0, v_z=0.0, v_t=2.0, w_0=0.0, w_x=2.0, w_y=1.0, w_z=0.0, w_t=-1.0,
+    p_0=101300.0, p_x=101.0, p_y=101.0, p_z=0.0, p_t=1013.0,
+    a_rhox=2.0, a_rhoy=2.0, a_rhoz=0.0, a_rhot=400.0, a_ux=2.0, a_uy=2.0, a_uz=0.0, a_ut=400.0,
+    a_vx=2.0, a_vy=2.0, a_vz=0.0, a_vt=400.0, a_wx=2.0, a_wy=2.0, a_wz=0.0, a_wt=0.0,
+    a_px=2.0, a_py=2.0, a_pz=0.0, a_pt=400.0)
+
+
+class _Transient3D:
+    def __init__(self, fprim, fstate, fsource):
+        self._fp, self._fu, self._fs = fprim, fstate, fsource
+
+    @staticmethod
+    def _eval(f, X, t):
+        z = np.zeros(X.shape[1])
+        return np.array([np.asarray(a, dtype=np.float64) + z for a in f(X[0], X[1], X[2], t)])
+
+    def prim(self, X, t):  # rho, u, v, w, p
+        return self._eval(self._fp, X, t)
+
+    def state(self, X, t):  # conserved, as src/masa_handler.cpp:318-335 assembles it
+        return self._eval(self._fu, X, t)
+
+    def source(self, X, t):  # masa_eval_source_*: Q = dU/dt + div F(U)
+        return self._eval(self._fs, X, t)
+
+
+@functools.lru_cache(maxsize=None)
+def euler_transient_3d(forms="scscc"):
+    import sympy as sp
+
+    P = TPS_EULER_TRANSIENT_3D
+    x, y, z, t = sp.symbols("x y z t")
+    L, pi = P["L"], sp.pi
+    tf = [sp.sin if c == "s" else sp.cos for c in forms]
+
+    def arg(name, s):
+        return P[name] * pi * s / L
+
+    rho = P["rho_0"] + P["rho_x"] * sp.sin(arg("a_rhox", x)) + P["rho_y"] * sp.cos(arg("a_rhoy", y)) + P["rho_z"] * sp.sin(arg("a_rhoz", z)) + P["rho_t"] * tf[0](arg("a_rhot", t))
+    u = P["u_0"] + P["u_x"] * sp.sin(arg("a_ux", x)) + P["u_y"] * sp.cos(arg("a_uy", y)) + P["u_z"] * sp.cos(arg("a_uz", z)) + P["u_t"] * tf[1](arg("a_ut", t))
+    v = P["v_0"] + P["v_x"] * sp.cos(arg("a_vx", x)) + P["v_y"] * sp.sin(arg("a_vy", y)) + P["v_z"] * sp.sin(arg("a_vz", z)) + P["v_t"] * tf[2](arg("a_vt", t))
+    w = P["w_0"] + P["w_x"] * sp.sin(arg("a_wx", x)) + P["w_y"] * sp.sin(arg("a_wy", y)) + P["w_z"] * sp.cos(arg("a_wz", z)) + P["w_t"] * tf[3](arg("a_wt", t))
+    p = P["p_0"] + P["p_x"] * sp.cos(arg("a_px", x)) + P["p_y"] * sp.sin(arg("a_py", y)) + P["p_z"] * sp.cos(arg("a_pz", z)) + P["p_t"] * tf[4](arg("a_pt", t))
+    g = P["Gamma"]
+    vel, X = [u, v, w], [x, y, z]
+    E = p / (g - 1) + rho * sum(c * c for c in vel) / 2
+    U = [rho, rho * u, rho * v, rho * w, E]
+    F = [[rho * vel[d] for d in range(3)]]
+    for i in range(3):
+        F.append([U[1 + i] * vel[d] + (p if i == d else 0) for d in range(3)])
+    F.append([vel[d] * (E + p) for d in range(3)])
+    S = [sp.diff(U[k], t) + sum(sp.diff(F[k][d], X[d]) for d in range(3)) for k in range(5)]
+    a = (x, y, z, t)
+    return _Transient3D(sp.lambdify(a, [rho, u, v, w, p], "numpy"), sp.lambdify(a, U, "numpy"), sp.lambdify(a, S, "numpy"))
+
+
+def lp_errors_box(X, U, ms, t, p, gamma=1.4):
+    """M2ulPhyS::checkSolutionError for dry air (src/masa_handler.cpp:139-152): the L2 errors of the density, velocity and
+    pressure grid functions against the exact fields, as mfem::GridFunction::ComputeLpError(2, coefficient) forms them
+    with its default rule [third party: MFEM, fem/gridfunc.cpp: Gauss-Legendre of order 2 p + 3 per element].
+    Axis-aligned box elements with a tensor Gauss-Legendre nodal basis (X: node coordinates (3, ne * (p+1)^3), U: the
+    conserved state at the nodes); the nodal interpolants are evaluated at the rule's points in physical coordinates,
+    which does not depend on how an element's local axes are oriented."""
+    npe = (p + 1) ** 3
+    ne = X.shape[1] // npe
+    nq = (2 * p + 3) // 2 + 1
+    gq, wq = np.polynomial.legendre.leggauss(nq)
+    gq, wq = 0.5 * (gq + 1.0), 0.5 * wq
+    gn = 0.5 * (np.polynomial.legendre.leggauss(p + 1)[0] + 1.0)
+    rho = U[0]
+    fields = np.stack([rho, U[1] / rho, U[2] / rho, U[3] / rho,
+                       (gamma - 1.0) * (U[4] - 0.5 * (U[1] ** 2 + U[2] ** 2 + U[3] ** 2) / rho)]).reshape(5, ne, npe)
+    Xe = X.reshape(3, ne, npe)
+    lag, xq, vol = [], [], np.ones(ne)
+    for d in range(3):
+        lo, hi = Xe[d].min(axis=1), Xe[d].max(axis=1)
+        h = (hi - lo) / (gn[-1] - gn[0])
+        x0 = lo - gn[0] * h
+        pts = x0[:, None] + gq[None, :] * h[:, None]  # (ne, nq)
+        # 1-D nodal positions of the element in this direction, and the Lagrange factor of every node at every point
+        knots = x0[:, None] + gn[None, :] * h[:, None]  # (ne, p+1)
+        ld = np.ones((ne, npe, nq))
+        for a in range(p + 1):
+            mine = np.isclose(Xe[d][:, :, None], knots[:, None, a:a + 1], rtol=0, atol=1e-9 * np.abs(h)[:, None, None] + 1e-300)[..., 0]
+            fac = np.ones((ne, nq))
+            for b in range(p + 1):
+                if b != a:
+                    fac *= (pts - knots[:, b:b + 1]) / (knots[:, a:a + 1] - knots[:, b:b + 1])
+            ld = np.where(mine[:, :, None], fac[:, None, :], ld)
+        lag.append(ld)
+        xq.append(pts)
+        vol = vol * h
+    # values at the points: (5, ne, nq, nq, nq)
+    vals = np.einsum("fen,eni,enj,enk->feijk", fields, lag[0], lag[1], lag[2], optimize=True)
+    Xq = np.stack([np.broadcast_to(xq[0][:, :, None, None], (ne, nq, nq, nq)), np.broadcast_to(xq[1][:, None, :, None], (ne, nq, nq, nq)),
+                   np.broadcast_to(xq[2][:, None, None, :], (ne, nq, nq, nq))]).reshape(3, -1)
+    exact = ms.prim(Xq, t).reshape(5, ne, nq, nq, nq)
+    w3 = wq[:, None, None] * wq[None, :, None] * wq[None, None, :]
+    d2 = (vals - exact) ** 2
+    integ = lambda a: float(np.sqrt(np.sum(a * w3[None] * vol[:, None, None, None])))  # noqa: E731
+    return integ(d2[0]), integ(d2[1] + d2[2] + d2[3]), integ(d2[4])

@@ -315,6 +315,55 @@ __device__ inline int xcd_block(int b, int n) {
 #endif
 }
 
+// L2 warm-up for a block that starts LATER on this XCD (TPSRHS_PREFETCH = its distance in the XCD's chunk of the block
+// list; 0: off).  With xcd_block() the workgroups of one XCD walk a contiguous chunk in order, so the block `dist`
+// further down the list starts on THIS L2 when about `dist` of the resident blocks have retired.  One 4-byte load per
+// 128-byte line of its nodal rows, its vertices and its face records: the lines are on their way (or in the L2) when
+// that block's own loads arrive, which otherwise pay a full trip to HBM before the first instruction of its physics.
+// The loaded words are returned to the caller, who hands them to an empty asm after the barrier it waits at anyway
+// (loads return in order: nothing waits longer than it did), so the compiler can neither drop nor re-use them early.
+#ifndef TPSRHS_PREFETCH
+#define TPSRHS_PREFETCH 0
+#endif
+template <class C, int NU, int NG>
+__device__ inline int prefetch_block(const MeshDev &m, int lin, int nblocks, const double *U, const double *G) {
+  int junk = 0;
+#if TPSRHS_PREFETCH
+  const int lin2 = lin + TPSRHS_PREFETCH;
+  if (lin2 < nblocks) {  // (the last blocks of the last XCD's chunk warm nothing; a chunk border warms the next XCD's
+                         //  first blocks on the wrong L2: 7 x dist of 50 000 blocks)
+    const int bid2 = m.blocks ? m.blocks[lin2] : lin2;
+    const int64_t n0 = static_cast<int64_t>(bid2) * C::EPB * C::NPE;
+    constexpr int LPR = (C::NODES * 8 + 127) / 128;  // lines per nodal row of the block
+    constexpr int NL = (NU + NG) * LPR;
+    constexpr int VL = (C::EPB * C::NV * C::DIM * 8 + 127) / 128, FL = (C::EPB * C::NFACES * 8 + 127) / 128;
+#pragma unroll
+    for (int l0 = 0; l0 < NL + VL + FL; l0 += C::BLOCK) {
+      const int l = l0 + static_cast<int>(threadIdx.x);
+      const char *p = nullptr;
+      if (l < NL) {
+        const int f = l / LPR, seg = l - f * LPR;
+        const int64_t n = n0 + seg * 16;
+        if (n < m.ndofs) p = reinterpret_cast<const char *>((f < NU ? U + f * m.ndofs : G + (f - NU) * m.ndofs) + n);
+      } else if (l < NL + VL) {
+        const int64_t w = static_cast<int64_t>(bid2) * C::EPB * C::NV * C::DIM + (l - NL) * 16;
+        if (w < static_cast<int64_t>(m.ne) * C::NV * C::DIM) p = reinterpret_cast<const char *>(m.verts + w);
+      } else if (l < NL + VL + FL) {
+        const int64_t w = static_cast<int64_t>(bid2) * C::EPB * C::NFACES + (l - NL - VL) * 16;
+        if (w < static_cast<int64_t>(m.ne) * C::NFACES) p = reinterpret_cast<const char *>(m.face_info + w);
+      }
+      if (p) junk ^= *reinterpret_cast<const int *>(p);
+    }
+  }
+#endif
+  return junk;
+}
+__device__ inline void prefetch_done(int junk) {
+#if TPSRHS_PREFETCH
+  asm volatile("" ::"v"(junk));
+#endif
+}
+
 // Face records of the block's elements -> LDS, once, so that no later stage has a global load on the
 // path to a neighbour address (nb = INT32_MIN marks the faces of elements past the end of the mesh).
 template <class C>
@@ -1864,7 +1913,9 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
   load_face_info<C>(sFI, m, e0);
   load_tables<C>(tab, ct);
   load_vertices<C>(sV, m, e0);
+  const int pf_junk = prefetch_block<C, NEQ, 0>(m, lin, static_cast<int>(gridDim.x), U, U);
   block_sync<C::BLOCK>();
+  prefetch_done(pf_junk);
   STAMP(0);
   // neighbour Up traces of all direction pairs: issued first, consumed by the jump passes
   NbTraces<C, NEQ> ta0, ta1, ta2;
@@ -2651,7 +2702,9 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   load_face_info<C>(sFI, m, e0);
   load_tables<C>(tab, ct);
   load_vertices<C>(sV, m, e0);
+  const int pf_junk = prefetch_block<C, NEQ, NEQ * DIM>(m, lin, static_cast<int>(gridDim.x), U, gradUp);
   block_sync<C::BLOCK>();
+  prefetch_done(pf_junk);
   FSTAMP(0);
   NbTraces<C, NEQ> ta0;
   NbFlux<C, NEQ> tb0;

@@ -114,3 +114,70 @@ def read_mfem_mesh(path) -> HostMesh:
     keep = np.array(keep, dtype=np.int64)
     return HostMesh(dim, nvert, np.ascontiguousarray(ev), np.ascontiguousarray(coords),
                     np.ascontiguousarray(bv[keep]).reshape(len(keep), nv_el // 2), np.ascontiguousarray(battr[keep]))
+
+
+def refine_uniform(mesh: HostMesh, levels: int = 1) -> HostMesh:
+    """``[flow] refinement_levels`` (src/M2ulPhyS.cpp:353-356: ``serial_mesh->UniformRefinement()`` per level): every
+    quadrilateral / hexahedron is split into 4 / 8 children at the midpoints of its edges, faces and cell.  Topology as
+    in MFEM: one new vertex per edge, per face and per element, shared by the elements that share the edge / face (new ids
+    are keyed by the parent vertex ids they average, so periodic identifications carry over); geometry from the parent's
+    OWN corner coordinates (multi-linear), which keeps periodic images apart.  Needs at least three elements around a
+    periodic direction (two vertices then name one edge only), like every mesh the library accepts."""
+    for _ in range(int(levels)):
+        mesh = _refine_once(mesh)
+    return mesh
+
+
+def _refine_once(mesh: HostMesh) -> HostMesh:
+    dim = mesh.dim
+    nv_el = 1 << dim
+    from .meshgen import _HEX_CORNERS, _QUAD_CORNERS
+
+    corners = _QUAD_CORNERS if dim == 2 else _HEX_CORNERS  # MFEM vertex -> corner bits
+    ids = {}
+
+    def vid(key):
+        k = tuple(sorted(key))
+        if k not in ids:
+            ids[k] = len(ids)
+        return ids[k]
+
+    for v in range(mesh.num_vertices):  # old vertices keep their ids
+        ids[(v,)] = v
+    ev, ec = mesh.elem_vertices, mesh.elem_coords
+    ne = ev.shape[0]
+    new_ev = np.empty((ne * nv_el, nv_el), dtype=np.int32)
+    new_ec = np.empty((ne * nv_el, nv_el, dim), dtype=np.float64)
+    # points of the 3^dim lattice of an element: lattice index per axis 0, 1 (midpoint), 2
+    lattice = np.array(np.meshgrid(*([np.arange(3)] * dim), indexing="ij")).reshape(dim, -1).T
+    for e in range(ne):
+        pid, pxyz = {}, {}
+        for lat in lattice:
+            # parent corners this point averages: per axis 0 -> bit 0, 2 -> bit 1, 1 -> both
+            sel = [c for c in range(nv_el) if all(lat[a] == 1 or corners[c][a] == lat[a] // 2 for a in range(dim))]
+            key = [int(ev[e, c]) for c in sel]
+            # an edge / face midpoint of a periodic ring: keyed by its vertex ids; the cell centre by the element
+            pid[tuple(lat)] = vid(key) if len(sel) < nv_el else vid(key + [-(e + 1)])
+            pxyz[tuple(lat)] = ec[e, sel].mean(axis=0)
+        for child in range(nv_el):
+            off = corners[child]  # the child that touches parent corner `child`
+            for c in range(nv_el):
+                lat = tuple(int(off[a] + corners[c][a]) for a in range(dim))
+                new_ev[e * nv_el + child, c] = pid[lat]
+                new_ec[e * nv_el + child, c] = pxyz[lat]
+    nb = mesh.bdr_vertices.shape[0]
+    nvf = nv_el // 2
+    fc = _QUAD_CORNERS if dim == 3 else np.array([[0], [1]])
+    new_bv = np.empty((nb * nvf, nvf), dtype=np.int32)
+    for b in range(nb):
+        bvs = [int(x) for x in mesh.bdr_vertices[b]]
+        flat = np.array(np.meshgrid(*([np.arange(3)] * (dim - 1)), indexing="ij")).reshape(dim - 1, -1).T
+        pid = {}
+        for lat in flat:
+            sel = [c for c in range(nvf) if all(lat[a] == 1 or fc[c][a] == lat[a] // 2 for a in range(dim - 1))]
+            pid[tuple(lat)] = vid([bvs[c] for c in sel])
+        for child in range(nvf):
+            for c in range(nvf):
+                lat = tuple(int(fc[child][a] + fc[c][a]) for a in range(dim - 1))
+                new_bv[b * nvf + child, c] = pid[lat]
+    return HostMesh(dim, len(ids), new_ev, new_ec, new_bv, np.repeat(mesh.bdr_attributes, nvf).astype(np.int32))
