@@ -277,6 +277,7 @@ struct MeshDev {
   const int *blocks;           // workgroup -> block of EPB consecutive elements (NULL: identity); lets one
                                // launch cover the interior and another the blocks that touch shared faces
   int ne;
+  int reverse;                 // 1: the sweep walks each XCD's chunk of the block list backwards (xcd_block)
   int64_t ndofs;
   const double *verts;         // [ne][NV][DIM] lexicographic corners
   const int2 *face_info;       // [ne*NFACES] {neighbour slot | -(bc+1), orientation code}
@@ -304,63 +305,18 @@ __device__ inline EddyCtx closure_ctx(const MeshDev &m, bool dist_on, double dis
 #ifndef TPSRHS_XCD_ORDER
 #define TPSRHS_XCD_ORDER 1
 #endif
-__device__ inline int xcd_block(int b, int n) {
+__device__ inline int xcd_block(int b, int n, int reverse = 0) {
 #if TPSRHS_XCD_ORDER
   constexpr int X = 8;
   const int q = n / X, r = n - q * X;
   const int x = b % X, k = b / X;
-  return x * q + (x < r ? x : r) + k;
+  // reverse: the same chunk, last block first.  Consecutive sweeps of a Mult run in opposite directions (operator.hpp):
+  // what the previous sweep wrote LAST -- still in this XCD's L2 and in the memory-side cache -- is read FIRST, instead of
+  // every sweep streaming 0.6 - 1 GB through a least-recently-used cache in the one order that never hits
+  const int kk = reverse ? (q + (x < r ? 1 : 0)) - 1 - k : k;
+  return x * q + (x < r ? x : r) + kk;
 #else
-  return b;
-#endif
-}
-
-// L2 warm-up for a block that starts LATER on this XCD (TPSRHS_PREFETCH = its distance in the XCD's chunk of the block
-// list; 0: off).  With xcd_block() the workgroups of one XCD walk a contiguous chunk in order, so the block `dist`
-// further down the list starts on THIS L2 when about `dist` of the resident blocks have retired.  One 4-byte load per
-// 128-byte line of its nodal rows, its vertices and its face records: the lines are on their way (or in the L2) when
-// that block's own loads arrive, which otherwise pay a full trip to HBM before the first instruction of its physics.
-// The loaded words are returned to the caller, who hands them to an empty asm after the barrier it waits at anyway
-// (loads return in order: nothing waits longer than it did), so the compiler can neither drop nor re-use them early.
-#ifndef TPSRHS_PREFETCH
-#define TPSRHS_PREFETCH 0
-#endif
-template <class C, int NU, int NG>
-__device__ inline int prefetch_block(const MeshDev &m, int lin, int nblocks, const double *U, const double *G) {
-  int junk = 0;
-#if TPSRHS_PREFETCH
-  const int lin2 = lin + TPSRHS_PREFETCH;
-  if (lin2 < nblocks) {  // (the last blocks of the last XCD's chunk warm nothing; a chunk border warms the next XCD's
-                         //  first blocks on the wrong L2: 7 x dist of 50 000 blocks)
-    const int bid2 = m.blocks ? m.blocks[lin2] : lin2;
-    const int64_t n0 = static_cast<int64_t>(bid2) * C::EPB * C::NPE;
-    constexpr int LPR = (C::NODES * 8 + 127) / 128;  // lines per nodal row of the block
-    constexpr int NL = (NU + NG) * LPR;
-    constexpr int VL = (C::EPB * C::NV * C::DIM * 8 + 127) / 128, FL = (C::EPB * C::NFACES * 8 + 127) / 128;
-#pragma unroll
-    for (int l0 = 0; l0 < NL + VL + FL; l0 += C::BLOCK) {
-      const int l = l0 + static_cast<int>(threadIdx.x);
-      const char *p = nullptr;
-      if (l < NL) {
-        const int f = l / LPR, seg = l - f * LPR;
-        const int64_t n = n0 + seg * 16;
-        if (n < m.ndofs) p = reinterpret_cast<const char *>((f < NU ? U + f * m.ndofs : G + (f - NU) * m.ndofs) + n);
-      } else if (l < NL + VL) {
-        const int64_t w = static_cast<int64_t>(bid2) * C::EPB * C::NV * C::DIM + (l - NL) * 16;
-        if (w < static_cast<int64_t>(m.ne) * C::NV * C::DIM) p = reinterpret_cast<const char *>(m.verts + w);
-      } else if (l < NL + VL + FL) {
-        const int64_t w = static_cast<int64_t>(bid2) * C::EPB * C::NFACES + (l - NL - VL) * 16;
-        if (w < static_cast<int64_t>(m.ne) * C::NFACES) p = reinterpret_cast<const char *>(m.face_info + w);
-      }
-      if (p) junk ^= *reinterpret_cast<const int *>(p);
-    }
-  }
-#endif
-  return junk;
-}
-__device__ inline void prefetch_done(int junk) {
-#if TPSRHS_PREFETCH
-  asm volatile("" ::"v"(junk));
+  return reverse ? n - 1 - b : b;
 #endif
 }
 
@@ -815,7 +771,7 @@ __global__ __launch_bounds__(C::BLOCK) void k_traces(MeshDev m, typename PH::KAr
   __shared__ double sF[2 * NEQ * C::NODES];
   __shared__ double sT[(C::DIM == 2 ? 2 : 1) * 2 * NEQ * C::TN];
   const int tid = threadIdx.x;
-  const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), m.reverse);
   const int bid = m.blocks ? m.blocks[lin] : lin;
   const int e0 = bid * C::EPB;
   if (tid < C::NODES) {
@@ -1893,7 +1849,7 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
   double *sW = pool + L::O_W;    // W chunk of the viscous phase
 
   const int tid = threadIdx.x;
-  const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), m.reverse);
   const int bid = m.blocks ? m.blocks[lin] : lin;
   // (TPSRHS_ABLATE & 512, timing experiment: every block works on one of 8 elements -- all loads become cache hits)
   const int e0 = (TPSRHS_ABLATE & 512) ? (bid % 8) * C::EPB : bid * C::EPB;
@@ -1913,9 +1869,7 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
   load_face_info<C>(sFI, m, e0);
   load_tables<C>(tab, ct);
   load_vertices<C>(sV, m, e0);
-  const int pf_junk = prefetch_block<C, NEQ, 0>(m, lin, static_cast<int>(gridDim.x), U, U);
   block_sync<C::BLOCK>();
-  prefetch_done(pf_junk);
   STAMP(0);
   // neighbour Up traces of all direction pairs: issued first, consumed by the jump passes
   NbTraces<C, NEQ> ta0, ta1, ta2;
@@ -2681,7 +2635,7 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   double *sX = sGf, *sY = sGf + L::X;
 
   const int tid = threadIdx.x;
-  const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int lin = xcd_block(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), m.reverse);
   const int bid = m.blocks ? m.blocks[lin] : lin;
   const int e0 = (TPSRHS_ABLATE & 512) ? (bid % 8) * C::EPB : bid * C::EPB;  // (512: timing experiment, as in k_gradient)
   __shared__ int2 sFI[C::EPB * C::NFACES];
@@ -2702,9 +2656,7 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
   load_face_info<C>(sFI, m, e0);
   load_tables<C>(tab, ct);
   load_vertices<C>(sV, m, e0);
-  const int pf_junk = prefetch_block<C, NEQ, NEQ * DIM>(m, lin, static_cast<int>(gridDim.x), U, gradUp);
   block_sync<C::BLOCK>();
-  prefetch_done(pf_junk);
   FSTAMP(0);
   NbTraces<C, NEQ> ta0;
   NbFlux<C, NEQ> tb0;

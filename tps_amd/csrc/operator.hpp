@@ -140,12 +140,15 @@ struct tpsrhs_operator {
 
   void (*launch)(tpsrhs_operator *, const double *, double *, bool) = nullptr;
   void (*point_eval)(tpsrhs_operator *, int, int64_t, const double *, double *) = nullptr;
+  bool sweep_alt = true;  // alternate the direction of consecutive sweeps (launch_all); TPSRHS_SWEEP_ALT
+  int sweep_parity = 0;
   VsDev vs2d = {};  // viscous sponge of the 2-D heavy kernels (MeshDev::vs); enabled = 0: none
 
   MeshDev mesh_dev() const {
     MeshDev m;
     m.blocks = nullptr;
     m.ne = ne;
+    m.reverse = 0;
     m.ndofs = ndofs;
     m.verts = d_verts;
     m.face_info = d_face_info;
@@ -240,16 +243,23 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     op->d_block_speed = dev_alloc<double>(nblocks);
     op->flux_grid = nblocks;
   }
-  auto traces = [&](const MeshDev &m, int grid) {
+  // Alternating sweep direction (TPSRHS_SWEEP_ALT): k_traces and k_flux of a Mult walk the block list one way, k_gradient
+  // the other, and the next Mult starts the other way round -- every sweep begins with what its predecessor wrote last
+  // (xcd_block).  The direction is per sweep, the same for its halo and interior launches.
+  const int dir0 = op->sweep_alt ? op->sweep_parity : 0;
+  auto traces = [&](MeshDev m, int grid) {
+    m.reverse = dir0;
     hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_TA);
     HIP_CHECK(hipGetLastError());
   };
-  auto gradient = [&](const MeshDev &m, int grid) {
+  auto gradient = [&](MeshDev m, int grid) {
+    m.reverse = op->sweep_alt ? 1 - dir0 : 0;
     hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_TA, op->d_Up, op->d_gradUp,
                        op->d_TB);
     HIP_CHECK(hipGetLastError());
   };
-  auto flux = [&](const MeshDev &m, int grid) {
+  auto flux = [&](MeshDev m, int grid) {
+    m.reverse = dir0;
     hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_gradUp, op->d_TA, op->d_TB, y,
                        op->d_block_speed, op->rk);
     HIP_CHECK(hipGetLastError());
@@ -300,6 +310,7 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     HIP_CHECK(hipEventRecord(op->ev[0], s));
   }
   const MeshDev all = op->mesh_dev();
+  if (op->sweep_alt) op->sweep_parity ^= 1;  // (read into dir0 above: the next Mult starts from the other end)
   if (op->topo.num_shared == 0) {
     traces(all, nblocks);
     if (op->timing) HIP_CHECK(hipEventRecord(op->ev[1], s));

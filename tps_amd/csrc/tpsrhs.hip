@@ -348,6 +348,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   op->device = rt ? rt->device : 0;
   HIP_CHECK(hipSetDevice(op->device));
   op->stream = rt ? static_cast<hipStream_t>(rt->stream) : nullptr;
+  if (const char *env = std::getenv("TPSRHS_SWEEP_ALT")) op->sweep_alt = env[0] != '0';  // (A/B switch; default on)
   op->halo = rt ? rt->halo : nullptr;
   op->halo_ctx = rt ? rt->halo_ctx : nullptr;
   op->reduce = rt ? rt->reduce : nullptr;
