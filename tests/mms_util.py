@@ -352,3 +352,175 @@ def lp_errors_box(X, U, ms, t, p, gamma=1.4):
     d2 = (vals - exact) ** 2
     integ = lambda a: float(np.sqrt(np.sum(a * w3[None] * vol[:, None, None, None])))  # noqa: E731
     return integ(d2[0]), integ(d2[1] + d2[2] + d2[3]), integ(d2[4])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# test/mms.ternary_2d.test: `ternary_2d_2t_periodic_ambipolar`, a manufactured solution of the TPS team's MASA fork [third
+# party, absent] for the two-temperature ambipolar ternary mixture with constant transport and one reaction with detailed
+# balance.  Every parameter is in src/masa_handler.cpp:501-546, 652-672; the FORM is not in the reference.  Found by
+# running the family the parameter names suggest (tools/mms_ternary_periodic.py; the record is profiles/
+# r04_mms_ternary_periodic.txt):  f = f0 + dfx gx(2 pi kfx (x / Lx - offset_fx)) + dfy gy(2 pi kfy (y / Ly - offset_fy))  with
+# (gx, gy) = (cos, cos) for rho, Y_ion, T, T_e and MASA's velocity convention (sin, cos) for u, (cos, sin) for v.
+TERNARY_FORM = "cos-|u=sc-|v=cs-"
+TERNARY_REF = (9.4069e-4, 0.1560, 0.0449, 1.3975e-3, 2.6037e-3, 3.0008e-3)  # test/mms.ternary_2d.test:42-67
+TERNARY_LX = TERNARY_LY = 5.0
+
+# src/masa_handler.cpp:501-546 (initTernary2DBase) and :652-658 (initTernary2D2TPeriodicAmbipolar)
+TERNARY_P = dict(u=(1.5, 0.1, 0.2, 1.0, 2.0, -0.33, 0.47), v=(0.91, 0.13, 0.11, 2.0, 1.0, 0.11, 0.92),
+         rho=(1.2, 0.17, 0.09, 1.0, 1.0, 0.74, 0.19), Y0=(0.34, 0.13, 0.07, 2.0, 1.0, 0.17, 0.58),
+         T=(500.0, 37.0, 29.0, 1.0, 1.0, 0.71, 0.29), TE=(700.0, 49.3, 23.1, 2.0, 1.0, 0.31, 0.91))
+
+
+def ternary_physics():
+    """test/inputs/mms.ternary_plasma.2d.ini:120-185 in mixture order (Ar.+1, E, Ar)"""
+    from tps_amd import capi
+
+    ph = capi.argon_ternary_physics(capi.NS, two_temperature=True, transport=capi.CONSTANT, reactions="balance")
+    mx, nsp = ph.mixture, 3
+    m_ar, m_e = 39.948e-3, 10.0e-3
+    for sp, (mw, ef) in enumerate(((m_ar - m_e, 1.521e4), (m_e, 0.0), (m_ar, 0.0))):
+        mx.gas_params[sp + capi.SPECIES_MW * nsp] = mw
+        mx.gas_params[sp + capi.FORMATION_ENERGY * nsp] = ef
+        mx.molar_cv[sp] = 1.5
+    ct = ph.constant_transport
+    ct.viscosity, ct.bulk_viscosity, ct.thermal_conductivity, ct.electron_thermal_conductivity = 1.1, 0.3, 0.6, 0.3
+    for sp, (d, f) in enumerate(((1.3, 2.3), (3.1, 0.9), (1.9, 4.1))):
+        ct.diffusivity[sp], ct.mt_freq[sp] = d, f
+    ch = ph.chemistry
+    ch.num_reactions = 1
+    ch.minimum_temperature = 0.0
+    ch.reaction_energies[0] = 1.521e4
+    ch.detailed_balance[0] = 1
+    ch.reaction_models[0] = capi.ARRHENIUS
+    for sp, (r, p) in enumerate(((0, 1), (1, 2), (1, 0))):  # Ar + E <=> Ar.+1 + 2 E
+        ch.reactant_stoich[sp], ch.product_stoich[sp] = r, p
+    for k, v in enumerate((4.7, 1.2, 6.49e4)):
+        ch.rate_params[k] = v
+    for k, v in enumerate((1.39, 0.7, 6.197e2)):
+        ch.equilibrium_constant_params[k] = v
+    return ph
+
+
+def ternary_exact_state(ph, X, form=None):
+    """form: "cos-" (every field g = cos, offsets subtracted) or, for the search over the velocity components,
+    "cos-|u=sc+|v=cs-": per-field overrides, two letters = g of the x term and of the y term, then the offset sign"""
+    parts = (form or TERNARY_FORM).split("|")
+    base = parts[0]
+    over = dict(p.split("=") for p in parts[1:])
+    trig = {"s": np.sin, "c": np.cos}
+
+    def fld(name):
+        f0, dx, dy, kx, ky, ox, oy = TERNARY_P[name]
+        spec = over.get(name, base[0] * 2 + base[-1])
+        gx, gy, sgn = trig[spec[0]], trig[spec[1]], (-1.0 if spec[2] == "-" else 1.0)
+        return f0 + dx * gx(2 * np.pi * kx * (X[0] / TERNARY_LX + sgn * ox)) + dy * gy(2 * np.pi * ky * (X[1] / TERNARY_LY + sgn * oy))
+
+    from tps_amd import capi, cases
+
+    rho, u, v, y0, th, te = (fld(n) for n in ("rho", "u", "v", "Y0", "T", "TE"))
+    m_i = ph.mixture.gas_params[0 + capi.SPECIES_MW * 3]
+    return cases.plasma_conserved(ph, 2, rho, [u, v], th, [rho * y0 / m_i], te)
+
+
+def _lagrange(nodes, x):
+    """values of the Lagrange basis on `nodes` at the points x: (len(x), len(nodes))"""
+    out = np.ones((x.size, nodes.size))
+    for a in range(nodes.size):
+        for b in range(nodes.size):
+            if b != a:
+                out[:, a] *= (x - nodes[b]) / (nodes[a] - nodes[b])
+    return out
+
+
+def _oracle_mult_factory(mesh, disc, ph):
+    from oracle_lib import Oracle
+
+    return Oracle(mesh, disc, ph, threads=8).mult
+
+
+def ternary_fine_source(ph, form, Xc, n_fine, p_fine=5, mult_factory=None):
+    """Q = -RHS(U_exact) at the points Xc: the operator itself (`mult_factory(mesh, disc, physics)` -> U -> Mult(U); default the
+    oracle) at order p_fine on the collocated pair on an n_fine^2 mesh -- its residual converges to the PDE at O(h^5) --,
+    evaluated at Xc by Lagrange interpolation inside the fine elements"""
+    from oracle_lib import Oracle
+    from tps_amd import capi, meshgen
+
+    m = meshgen.box_quad(n_fine, n_fine, lengths=(TERNARY_LX, TERNARY_LY))
+    disc = capi.Disc(p_fine, 0, 0, 0, 0)
+    Xf = Oracle(m, disc, ph).node_coords()
+    y = (mult_factory or _oracle_mult_factory)(m, disc, ph)(ternary_exact_state(ph, Xf, form))
+    npe = (p_fine + 1) ** 2
+    neq = y.shape[0]
+    h = TERNARY_LX / n_fine
+    gn = 0.5 * (np.polynomial.legendre.leggauss(p_fine + 1)[0] + 1.0)
+    # element of every target point (points on element borders go to the element on their right / above, periodic)
+    ix = np.floor(Xc[0] / h + 1e-12).astype(int) % n_fine
+    iy = np.floor(Xc[1] / h + 1e-12).astype(int) % n_fine
+    xi = np.clip(Xc[0] / h - np.floor(Xc[0] / h + 1e-12), 0.0, 1.0)
+    eta = np.clip(Xc[1] / h - np.floor(Xc[1] / h + 1e-12), 0.0, 1.0)
+    # element numbering / node numbering of the generated box: read them off the node coordinates
+    Xe = Xf.reshape(2, -1, npe)
+    cx = np.floor(Xe[0].mean(axis=1) / h).astype(int)
+    cy = np.floor(Xe[1].mean(axis=1) / h).astype(int)
+    emap = -np.ones((n_fine, n_fine), dtype=int)
+    emap[cx, cy] = np.arange(cx.size)
+    e = emap[ix, iy]
+    lx, ly = _lagrange(gn, xi), _lagrange(gn, eta)
+    # local node -> (a, b) indices from the first element's coordinates
+    a_of = np.argmin(np.abs((Xe[0][0] - Xe[0][0].min())[:, None] / h - (gn - gn[0])[None, :]), axis=1)
+    b_of = np.argmin(np.abs((Xe[1][0] - Xe[1][0].min())[:, None] / h - (gn - gn[0])[None, :]), axis=1)
+    w = lx[:, a_of] * ly[:, b_of]  # (npts, npe)
+    ye = y.reshape(neq, -1, npe)
+    return -np.einsum("kpn,pn->kp", ye[:, e, :], w)
+
+
+def ternary_rel_errors(Xc, U, Uex, p=2):
+    """M2ulPhyS::checkSolutionError (src/masa_handler.cpp:153-163): per component ||U_h - U_exact|| / ||U_exact||, both by
+    mfem::GridFunction::ComputeLpError's default rule (Gauss-Legendre, order 2p + 3) on the Gauss-Lobatto nodal basis.
+    `Uex`: callable points -> exact conserved state."""
+    npe = (p + 1) ** 2
+    ne = Xc.shape[1] // npe
+    nq = (2 * p + 3) // 2 + 1
+    gq, wq = np.polynomial.legendre.leggauss(nq)
+    gq, wq = 0.5 * (gq + 1.0), 0.5 * wq
+    Xe = Xc.reshape(2, ne, npe)
+    lo = Xe.min(axis=2)
+    h = Xe.max(axis=2) - lo  # Gauss-Lobatto nodes include the end points
+    gl = np.array([0.0, 0.5, 1.0]) if p == 2 else None
+    a_of = np.rint((Xe[0][0] - lo[0][0]) / h[0][0] * p).astype(int)
+    b_of = np.rint((Xe[1][0] - lo[1][0]) / h[1][0] * p).astype(int)
+    L = _lagrange(gl, gq)  # (nq, p+1)
+    W = np.einsum("in,jn->ijn", L[:, a_of], L[:, b_of])  # (nq, nq, npe)
+    neq = U.shape[0]
+    vals = np.einsum("ken,ijn->keij", U.reshape(neq, ne, npe), W)
+    xq = lo[0][:, None, None] + gq[None, :, None] * h[0][:, None, None] + 0 * gq[None, None, :]
+    yq = lo[1][:, None, None] + gq[None, None, :] * h[1][:, None, None] + 0 * gq[None, :, None]
+    ex = Uex(np.stack([xq.ravel(), yq.ravel()])).reshape(neq, ne, nq, nq)
+    w2 = wq[:, None] * wq[None, :] * (h[0] * h[1])[:, None, None]
+    num = np.sqrt(np.sum((vals - ex) ** 2 * w2[None], axis=(1, 2, 3)))
+    den = np.sqrt(np.sum(ex ** 2 * w2[None], axis=(1, 2, 3)))
+    return num / den
+
+
+
+def ternary_run(form=None, n_fine=40, steps=500, dt=1e-5, mult_factory=None):
+    """test/mms.ternary_2d.test: 10 x 10 periodic quads on [0, 5]^2 (`beam_mesh -nx 1 -nt 5 -b 5 -rs 1`), order 2, Gauss-Lobatto
+    pair, 500 RK4 steps of 1e-5 s from the exact state with the (steady) source at every stage; returns the six relative errors"""
+    from oracle_lib import Oracle
+    from tps_amd import capi, meshgen
+
+    form = form or TERNARY_FORM
+    ph = ternary_physics()
+    m = meshgen.box_quad(10, 10, lengths=(TERNARY_LX, TERNARY_LY))
+    disc = capi.Disc(2, 1, 1, 0, 0)
+    Xc = Oracle(m, disc, ph).node_coords()
+    Q = ternary_fine_source(ph, form, Xc, n_fine, mult_factory=mult_factory)
+    mult = (mult_factory or _oracle_mult_factory)(m, disc, ph)
+    x = ternary_exact_state(ph, Xc, form)
+    for _ in range(steps):
+        k1 = mult(x) + Q
+        k2 = mult(x + 0.5 * dt * k1) + Q
+        k3 = mult(x + 0.5 * dt * k2) + Q
+        k4 = mult(x + dt * k3) + Q
+        x = x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+    return ternary_rel_errors(Xc, x, lambda X: ternary_exact_state(ph, X, form))
