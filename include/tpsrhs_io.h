@@ -39,7 +39,7 @@ int tpsrhs_restart_info_read(const char *path, tpsrhs_restart_info *info);
 
 /* Reads dataset /solution/<names[k]> into U[k*ndofs ... ) for k < num_equation.  The file must hold datasets of
  * exactly `ndofs` entries (the reference asserts numInSoln == local_ndofs, src/io.cpp:763) and `order` must equal
- * info->order unless order < 0 (the reference's change of order on restart needs MFEM's interpolation: not here).
+ * info->order unless order < 0 (a file of another order: tpsrhs_restart_read_change_order).
  * 0 on success; tpsrhs_io_last_error() says what failed. */
 int tpsrhs_restart_read(const char *path, int num_equation, int64_t ndofs, const char *const *names, int order, double *U,
                         tpsrhs_restart_info *info);
@@ -54,6 +54,17 @@ int tpsrhs_restart_read(const char *path, int num_equation, int64_t ndofs, const
 int tpsrhs_restart_read_serial(const char *path, int num_equation, int64_t num_elements, int dofs_per_element,
                                const int64_t *global_elements, const char *const *names, int order, double *U,
                                tpsrhs_restart_info *info);
+
+/* CHANGE OF ORDER on restart (`io/restartMode = variableP`; M2ulPhyS::read_restart_files_hdf5 with loadFromAuxSol,
+ * src/io.cpp:174-193, and IOFamily::readChangeOrder, src/io.cpp:797-850): the file holds the solution of THIS rank's
+ * `num_elements` elements at the polynomial order of its "order" attribute (info->order on return); every variable is read
+ * into an auxiliary space of that order and interpolated to the operator's: per element u_new(x_i) = sum_a l_a^old(x_i) u_a
+ * at the nodes x_i of the new order -- what mfem::GridFunction::ProjectGridFunction does between two nodal L2 spaces of one
+ * basis type [third party: MFEM fem/gridfunc.cpp, FiniteElement::Project], applied here as a tensor product.
+ * `basis_type`: tpsrhs_disc::basis_type (0 Gauss-Legendre, 1 Gauss-Lobatto nodes; the same in file and operator, as in the
+ * reference, whose auxiliary collection is `fec->Clone(read_order)`).  U: [num_equation][num_elements * (order+1)^dim]. */
+int tpsrhs_restart_read_change_order(const char *path, int num_equation, int64_t num_elements, int dim, int order, int basis_type,
+                                     const char *const *names, double *U, tpsrhs_restart_info *info);
 
 /* The reference's partitioned write of one rank (src/io.cpp:43-103, 701-724): truncates `path`. */
 int tpsrhs_restart_write(const char *path, int num_equation, int64_t ndofs, const char *const *names, const double *U,

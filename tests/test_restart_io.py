@@ -129,3 +129,60 @@ def test_serialised_restart_is_scattered_by_global_element(tmp_path):
         restart.read_serial(serial, names, [0], npe, order=3)
     with pytest.raises(RuntimeError, match="whole elements"):
         restart.read_serial(serial, names, [0], 25)
+
+
+@pytest.mark.parametrize("dim,basis", [(2, 0), (2, 1), (3, 0), (3, 1)])
+def test_change_of_order_on_restart(tmp_path, dim, basis):
+    """`restartMode = variableP` (src/io.cpp:174-193, 797-850: read at the file's order, ProjectGridFunction to the solution
+    space): a field of tensor degree 2 written at order 2 arrives EXACT at the nodes of order 3 and of order 1 + 3 -> 2 of the
+    same field is exact too; arbitrary data follow the tensor Lagrange interpolation, element by element; on a mesh whose
+    elements are rotated against each other and not affine (the interpolation lives in reference coordinates)."""
+    from tps_amd import meshgen
+    from tps_amd.rhs_operator import node_coordinates
+
+    m = (meshgen.scramble_orientations(meshgen.box_quad(4, 3, lengths=(2.0, 1.5)), 5) if dim == 2
+         else meshgen.scramble_orientations(meshgen.box_hex(3, 3, 3, lengths=(2.0, 1.5, 1.0)), 5))
+    names = restart.variable_names(dim)
+
+    def field(X, k):  # tensor degree 2 in every coordinate (axis-aligned elements: also in the reference coordinates)
+        x, y = X[0], X[1]
+        z = X[2] if dim == 3 else 0.3
+        return (1.0 + k) + 0.5 * x * x * y - 0.7 * y * y * (1 + z) + 0.2 * k * x * y * z * z + 0.1 * x
+
+    def state(order):
+        X = node_coordinates(m, order, basis)
+        return np.stack([field(X, k) for k in range(len(names))])
+
+    p2 = tmp_path / "o2.h5"
+    restart.write(p2, names, state(2), iteration=3, time=0.25, dt=1e-6, order=2, dimension=dim)
+    up, info = restart.read_change_order(p2, names, m.num_elements, dim, 3, basis)
+    assert (info.order, info.iteration, info.time) == (2, 3, 0.25)
+    assert np.abs(up - state(3)).max() < 2e-13
+    p3 = tmp_path / "o3.h5"
+    restart.write(p3, names, state(3), order=3, dimension=dim)
+    down, _ = restart.read_change_order(p3, names, m.num_elements, dim, 2, basis)
+    assert np.abs(down - state(2)).max() < 2e-13
+    same, _ = restart.read_change_order(p3, names, m.num_elements, dim, 3, basis)  # same order: the identity
+    assert np.abs(same - state(3)).max() < 1e-14
+    # arbitrary data on a NON-affine mesh against an independent tensor interpolation in numpy
+    mc = meshgen.ogrid_cylinder(2, 6, 3) if dim == 3 else meshgen.annulus_quad(3, 4, r_in=0.2)
+    rng = np.random.default_rng(11)
+    po, pn = 3, 4
+    U = rng.standard_normal((len(names), mc.num_elements * (po + 1) ** dim))
+    pr = tmp_path / "rand.h5"
+    restart.write(pr, names, U, order=po, dimension=dim)
+    V, _ = restart.read_change_order(pr, names, mc.num_elements, dim, pn, basis)
+
+    def nodes(n):
+        if basis == 0:
+            return 0.5 * (np.polynomial.legendre.leggauss(n)[0] + 1.0)
+        inner = np.polynomial.legendre.Legendre.basis(n - 1).deriv().roots() if n > 2 else np.array([])
+        return 0.5 * (np.concatenate([[-1.0], np.sort(inner.real), [1.0]]) + 1.0)
+
+    xo, xn = nodes(po + 1), nodes(pn + 1)
+    P = np.array([[np.prod([(xi - xo[b]) / (xo[a] - xo[b]) for b in range(po + 1) if b != a]) for a in range(po + 1)] for xi in xn])
+    Ue = U.reshape((len(names), mc.num_elements) + (po + 1,) * dim)  # [.., (z,) y, x]
+    W = np.einsum("kezyx,lz,jy,ix->kelji", Ue, P, P, P) if dim == 3 else np.einsum("keyx,jy,ix->keji", Ue, P, P)
+    assert np.abs(V - W.reshape(V.shape)).max() < 1e-13
+    with pytest.raises(RuntimeError, match="not .* elements of order 3"):
+        restart.read_change_order(pr, names, mc.num_elements + 1, dim, pn, basis)

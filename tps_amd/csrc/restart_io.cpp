@@ -4,6 +4,8 @@
 #include <hdf5.h>
 
 #include <cstring>
+
+#include "basis.hpp"
 #include <string>
 #include <vector>
 
@@ -121,7 +123,7 @@ int tpsrhs_restart_read(const char *path, int num_equation, int64_t ndofs, const
     return fail("restart file holds " + std::to_string(in->ndofs) + " entries per variable, the operator has " + std::to_string(ndofs));
   if (order >= 0 && in->order != order)
     return fail("restart file of polynomial order " + std::to_string(in->order) + ", operator of order " + std::to_string(order) +
-                " (the reference's change of order on restart interpolates with MFEM: not part of this library)");
+                " (tpsrhs_restart_read_change_order interpolates)");
   for (int k = 0; k < num_equation; k++) {  // read_variable_data_hdf5 into data + index * numInSoln
     const std::string p = std::string("/solution/") + names[k];
     Handle d(H5Dopen2(f, p.c_str(), H5P_DEFAULT), H5Dclose);
@@ -150,7 +152,7 @@ int tpsrhs_restart_read_serial(const char *path, int num_equation, int64_t num_e
   if (read_info(f, first.c_str(), in) != 0) return 1;
   if (order >= 0 && in->order != order)
     return fail("restart file of polynomial order " + std::to_string(in->order) + ", operator of order " + std::to_string(order) +
-                " (the reference's change of order on restart interpolates with MFEM: not part of this library)");
+                " (tpsrhs_restart_read_change_order interpolates)");
   const int64_t nglob = in->ndofs, ndofs = num_elements * dofs_per_element;
   if (nglob % dofs_per_element != 0) return fail("serial restart file: " + std::to_string(nglob) + " entries are not whole elements");
   for (int64_t e = 0; e < num_elements; e++)
@@ -170,6 +172,81 @@ int tpsrhs_restart_read_serial(const char *path, int num_equation, int64_t num_e
     double *out = U + static_cast<int64_t>(k) * ndofs;
     for (int64_t e = 0; e < num_elements; e++)
       std::memcpy(out + e * dofs_per_element, all.data() + global_elements[e] * dofs_per_element, sizeof(double) * dofs_per_element);
+  }
+  return 0;
+}
+
+int tpsrhs_restart_read_change_order(const char *path, int num_equation, int64_t num_elements, int dim, int order, int basis_type,
+                                     const char *const *names, double *U, tpsrhs_restart_info *info) {
+  if (!path || !names || !U || num_equation < 1 || num_elements < 0 || (dim != 2 && dim != 3) || order < 1 || order >= tpsrhs::MAXN1 ||
+      (basis_type != 0 && basis_type != 1))
+    return fail("tpsrhs_restart_read_change_order: invalid argument");
+  QuietErrors quiet;
+  Handle f(H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT), H5Fclose);
+  if (f < 0) return fail(std::string("cannot open restart file ") + path);
+  tpsrhs_restart_info local;
+  tpsrhs_restart_info *in = info ? info : &local;
+  const std::string first = std::string("/solution/") + names[0];
+  if (read_info(f, first.c_str(), in) != 0) return 1;
+  const int po = in->order;  // read_order: the file's own attribute (src/io.cpp:120)
+  if (po < 1 || po >= tpsrhs::MAXN1) return fail("restart file of polynomial order " + std::to_string(po) + ": orders 1.." + std::to_string(tpsrhs::MAXN1 - 1));
+  const int no = po + 1, nn = order + 1;
+  int64_t npe_o = 1, npe_n = 1;
+  for (int d = 0; d < dim; d++) {
+    npe_o *= no;
+    npe_n *= nn;
+  }
+  if (in->ndofs != num_elements * npe_o)  // assert((int)numInSoln == aux_dof), src/io.cpp:813
+    return fail("restart file holds " + std::to_string(in->ndofs) + " entries per variable: not " + std::to_string(num_elements) +
+                " elements of order " + std::to_string(po));
+  // P[i][a] = l_a^old(x_i^new): the 1-D factor of FiniteElement::Project between two nodal tensor elements of one basis type
+  double xo[tpsrhs::MAXN1], xn[tpsrhs::MAXN1], w[tpsrhs::MAXN1], P[tpsrhs::MAXN1 * tpsrhs::MAXN1];
+  (basis_type == 0 ? tpsrhs::gauss_legendre01 : tpsrhs::gauss_lobatto01)(no, xo, w);
+  (basis_type == 0 ? tpsrhs::gauss_legendre01 : tpsrhs::gauss_lobatto01)(nn, xn, w);
+  for (int i = 0; i < nn; i++)
+    for (int a = 0; a < no; a++) P[i * no + a] = tpsrhs::lagrange(xo, no, a, xn[i]);
+  const int64_t ndofs = num_elements * npe_n;
+  std::vector<double> old(static_cast<size_t>(in->ndofs));
+  std::vector<double> t1(static_cast<size_t>(nn) * no * no), t2(static_cast<size_t>(nn) * nn * no);
+  for (int k = 0; k < num_equation; k++) {
+    const std::string p = std::string("/solution/") + names[k];
+    Handle d(H5Dopen2(f, p.c_str(), H5P_DEFAULT), H5Dclose);
+    if (d < 0) return fail("restart file: dataset " + p + " missing");
+    Handle sp(H5Dget_space(d), H5Sclose);
+    hsize_t n = 0;
+    if (H5Sget_simple_extent_ndims(sp) != 1 || H5Sget_simple_extent_dims(sp, &n, nullptr) < 0 || static_cast<int64_t>(n) != in->ndofs)
+      return fail("restart file: dataset " + p + " has the wrong size");
+    if (H5Dread(d, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, old.data()) < 0) return fail("restart file: reading " + p + " failed");
+    double *out = U + static_cast<int64_t>(k) * ndofs;
+    const int nz_o = dim == 3 ? no : 1, nz_n = dim == 3 ? nn : 1;
+    for (int64_t e = 0; e < num_elements; e++) {  // nodes of an element are lexicographic, x fastest
+      const double *src = old.data() + e * npe_o;
+      double *dst = out + e * npe_n;
+      for (int c = 0; c < nz_o; c++)  // x: [c][b][a] -> [c][b][i]
+        for (int b = 0; b < no; b++)
+          for (int i = 0; i < nn; i++) {
+            double s = 0.0;
+            for (int a = 0; a < no; a++) s += P[i * no + a] * src[(c * no + b) * no + a];
+            t1[(c * no + b) * nn + i] = s;
+          }
+      for (int c = 0; c < nz_o; c++)  // y: [c][b][i] -> [c][j][i]
+        for (int j = 0; j < nn; j++)
+          for (int i = 0; i < nn; i++) {
+            double s = 0.0;
+            for (int b = 0; b < no; b++) s += P[j * no + b] * t1[(c * no + b) * nn + i];
+            t2[(c * nn + j) * nn + i] = s;
+          }
+      if (dim == 2) {
+        std::memcpy(dst, t2.data(), sizeof(double) * npe_n);
+      } else {
+        for (int l = 0; l < nz_n; l++)  // z: [c][j][i] -> [l][j][i]
+          for (int ji = 0; ji < nn * nn; ji++) {
+            double s = 0.0;
+            for (int c = 0; c < no; c++) s += P[l * no + c] * t2[c * nn * nn + ji];
+            dst[l * nn * nn + ji] = s;
+          }
+      }
+    }
   }
   return 0;
 }

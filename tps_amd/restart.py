@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtpsrhs_io.so")
-EXPORTED_SYMBOLS = ["tpsrhs_restart_variable_names", "tpsrhs_restart_info_read", "tpsrhs_restart_read", "tpsrhs_restart_read_serial", "tpsrhs_restart_write",
+EXPORTED_SYMBOLS = ["tpsrhs_restart_variable_names", "tpsrhs_restart_info_read", "tpsrhs_restart_read", "tpsrhs_restart_read_serial", "tpsrhs_restart_read_change_order", "tpsrhs_restart_write",
                     "tpsrhs_io_last_error"]
 _LIB = None
 
@@ -34,6 +34,8 @@ def load():
                                             C.POINTER(RestartInfo)]
         lib.tpsrhs_restart_read_serial.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_char_p), C.c_int,
                                                    C.c_void_p, C.POINTER(RestartInfo)]
+        lib.tpsrhs_restart_read_change_order.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
+                                                         C.c_void_p, C.POINTER(RestartInfo)]
         lib.tpsrhs_restart_write.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.POINTER(C.c_char_p), C.c_void_p, C.POINTER(RestartInfo)]
         _LIB = lib
     return _LIB
@@ -88,5 +90,16 @@ def read_serial(path, names, global_elements, dofs_per_element, order=-1):
     info = RestartInfo()
     if load().tpsrhs_restart_read_serial(str(path).encode(), len(names), ge.size, int(dofs_per_element), ge.ctypes.data_as(C.c_void_p),
                                          _names(names), int(order), U.ctypes.data_as(C.c_void_p), C.byref(info)) != 0:
+        raise RuntimeError(load().tpsrhs_io_last_error().decode())
+    return U, info
+
+
+def read_change_order(path, names, num_elements, dim, order, basis_type=0):
+    """``io/restartMode = variableP`` (``src/io.cpp:174-193, 797-850``): a file of ANOTHER polynomial order, interpolated element
+    by element to the nodes of ``order``.  -> (U (len(names), num_elements * (order+1)^dim), info with the file's order)"""
+    U = np.zeros((len(names), int(num_elements) * (int(order) + 1) ** int(dim)))
+    info = RestartInfo()
+    if load().tpsrhs_restart_read_change_order(str(path).encode(), len(names), int(num_elements), int(dim), int(order), int(basis_type),
+                                               _names(names), U.ctypes.data_as(C.c_void_p), C.byref(info)) != 0:
         raise RuntimeError(load().tpsrhs_io_last_error().decode())
     return U, info
