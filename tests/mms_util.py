@@ -503,9 +503,11 @@ def ternary_rel_errors(Xc, U, Uex, p=2):
 
 
 
-def ternary_run(form=None, n_fine=40, steps=500, dt=1e-5, mult_factory=None):
+def ternary_run(form=None, n_fine=40, steps=500, dt=1e-5, mult_factory=None, source="point"):
     """test/mms.ternary_2d.test: 10 x 10 periodic quads on [0, 5]^2 (`beam_mesh -nx 1 -nt 5 -b 5 -rs 1`), order 2, Gauss-Lobatto
-    pair, 500 RK4 steps of 1e-5 s from the exact state with the (steady) source at every stage; returns the six relative errors"""
+    pair, 500 RK4 steps of 1e-5 s from the exact state with the (steady) source at every stage; returns the six relative errors.
+    source = "point": the classic manufactured source from the point closures (`ternary_point_source`); "fine": -RHS(U_exact) of
+    the operator itself at order 5 on an n_fine^2 mesh (`ternary_fine_source`) -- they agree to 5e-7"""
     from oracle_lib import Oracle
     from tps_amd import capi, meshgen
 
@@ -513,8 +515,12 @@ def ternary_run(form=None, n_fine=40, steps=500, dt=1e-5, mult_factory=None):
     ph = ternary_physics()
     m = meshgen.box_quad(10, 10, lengths=(TERNARY_LX, TERNARY_LY))
     disc = capi.Disc(2, 1, 1, 0, 0)
-    Xc = Oracle(m, disc, ph).node_coords()
-    Q = ternary_fine_source(ph, form, Xc, n_fine, mult_factory=mult_factory)
+    o = Oracle(m, disc, ph, threads=8)
+    Xc = o.node_coords()
+    if source == "point":
+        Q = ternary_point_source(ph, form, Xc, o)
+    else:
+        Q = ternary_fine_source(ph, form, Xc, n_fine, mult_factory=mult_factory)
     mult = (mult_factory or _oracle_mult_factory)(m, disc, ph)
     x = ternary_exact_state(ph, Xc, form)
     for _ in range(steps):
@@ -524,3 +530,48 @@ def ternary_run(form=None, n_fine=40, steps=500, dt=1e-5, mult_factory=None):
         k4 = mult(x + dt * k3) + Q
         x = x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
     return ternary_rel_errors(Xc, x, lambda X: ternary_exact_state(ph, X, form))
+
+
+_FD8 = np.array([1.0 / 280, -4.0 / 105, 1.0 / 5, -4.0 / 5, 0.0, 4.0 / 5, -1.0 / 5, 4.0 / 105, -1.0 / 280])
+
+
+def ternary_point_source(ph, form, X, oracle, h=0.01):
+    """The manufactured source the classic way: Q = div [F_c(U) - F_v(U, grad Up)] - S(U, Up, grad Up) of the exact fields,
+    with the fluxes and sources of the POINT closures (the oracle's restatements of Fluxes::ComputeConvectiveFluxes /
+    ComputeViscousFluxes and SourceTerm, `oracle_lib.Oracle.convective_flux / viscous_flux / source / prim`) and eighth-order
+    central differences of step h for the two levels of derivatives (the exact fields are entire functions: the truncation
+    error is below 1e-14, the round-off of a difference quotient ~1e-13 relative).  Independent of the DG operators -- volume,
+    face, inverse mass -- which `ternary_fine_source` goes through."""
+    dim, npts = 2, X.shape[1]
+    offs = np.arange(-4, 5) * h
+
+    def up_and_grad(P):  # P: (2, m) points -> U (neq, m), Up (neq, m), gradUp (m, dim, neq)
+        U = ternary_exact_state(ph, P, form)
+        m = P.shape[1]
+        Up = np.array([oracle.prim(U[:, i]) for i in range(m)]).T
+        g = np.zeros((m, dim, U.shape[0]))
+        for d in range(dim):
+            for k, c in enumerate(_FD8):
+                if c == 0.0:
+                    continue
+                Pk = P.copy()
+                Pk[d] += offs[k]
+                Uk = ternary_exact_state(ph, Pk, form)
+                g[:, d, :] += (c / h) * np.array([oracle.prim(Uk[:, i]) for i in range(m)])
+        return U, Up, g
+
+    def flux(P):  # (m, dim, neq)
+        U, _, g = up_and_grad(P)
+        return np.array([oracle.convective_flux(U[:, i]) - oracle.viscous_flux(U[:, i], g[i]) for i in range(P.shape[1])])
+
+    div = np.zeros((npts, ternary_exact_state(ph, X[:, :1], form).shape[0]))
+    for d in range(dim):
+        for k, c in enumerate(_FD8):
+            if c == 0.0:
+                continue
+            Pk = X.copy()
+            Pk[d] += offs[k]
+            div += (c / h) * flux(Pk)[:, d, :]
+    U, Up, g = up_and_grad(X)
+    S = np.array([oracle.source(U[:, i], Up[:, i], g[i]) for i in range(npts)])
+    return (div - S).T

@@ -14,11 +14,16 @@ team's MASA fork only [third party, absent].  It was identified by running the s
 (``tools/mms_ternary_periodic.py``; the complete record of that search is ``profiles/r04_mms_ternary_periodic.txt``): sums of
 one x term and one y term, ``cos`` for the scalars, MASA's (sin, cos) / (cos, sin) convention for the velocity components.
 That form reproduces all six numbers to four significant digits (worst difference 3.4e-5 relative); every neighbouring
-member of the family is off in the third digit or worse in at least one of them.  The source is NOT an independent
-restatement of the fork's: it is ``-RHS(U_exact)`` of the operator under test at order 5 on a fine mesh (converged to seven
-digits), so what the six numbers pin is the discretisation error of the order-2 Gauss-Lobatto operator -- volume, face,
-viscous / diffusive / two-temperature terms, chemistry source, dense inverse mass, RK4 -- around that state, which depends on
-every closure coefficient to first order."""
+member of the family is off in the third digit or worse in at least one of them.
+
+The source is the classic manufactured source, Q = div [F_c(U) - F_v(U, grad Up)] - S(U, Up, grad Up) of the exact fields,
+formed from the POINT closures (the oracle's restatements of ``Fluxes::ComputeConvectiveFluxes / ComputeViscousFluxes`` and
+``SourceTerm``: ``tests/mms_util.py::ternary_point_source``, derivatives by eighth-order differences of the analytic fields,
+accurate to 1e-12) -- what the fork's analytic source is if the closures are the reference's; it does not go through any DG
+operator.  As a cross-check the same source is also taken from the operator under test itself, ``-RHS(U_exact)`` at order 5
+on an 80 x 80 mesh: the two agree to 5e-7 and give the same six numbers to six digits.  So the six numbers pin volume, face,
+viscous / diffusive / two-temperature terms, chemistry source, dense inverse mass and the RK4 sequence of the order-2
+Gauss-Lobatto operator against the PDE the point closures define, and the point closures through the size of the errors."""
 import numpy as np
 import pytest
 
@@ -39,6 +44,23 @@ def _check(e):
 
 def test_mms_ternary_2d_errors_oracle():
     _check(ternary_run())
+
+
+def test_source_from_the_operator_itself_agrees():
+    """-RHS(U_exact) of the order-5 operator on a fine mesh against the point-closure source: the DG operators converge to the
+    PDE the point closures define (5e-7 at 80 x 80), and the six numbers do not depend on which of the two is used"""
+    from oracle_lib import Oracle
+
+    from mms_util import TERNARY_FORM, ternary_fine_source, ternary_physics, ternary_point_source
+    from tps_amd import capi, meshgen
+
+    ph = ternary_physics()
+    o = Oracle(meshgen.box_quad(10, 10, lengths=(5.0, 5.0)), capi.Disc(2, 1, 1, 0, 0), ph, threads=8)
+    Xc = o.node_coords()[:, ::7]
+    qp = ternary_point_source(ph, TERNARY_FORM, Xc, o)
+    qf = ternary_fine_source(ph, TERNARY_FORM, Xc, 60)
+    assert (np.abs(qp - qf).max(axis=1) / np.abs(qf).max(axis=1)).max() < 5e-6
+    assert np.allclose(ternary_run(source="fine", n_fine=60), ternary_run(), rtol=1e-5)
 
 
 def test_a_neighbouring_form_misses():
@@ -68,9 +90,12 @@ def _hip_mult_factory(mesh, disc, ph):
 
 @pytest.mark.gpu
 def test_mms_ternary_2d_errors_hip():
-    """the same with every Mult on the device -- the order-5 source sweep (2-D two-temperature ambipolar kernels of the
-    collocated pair) and the 2 000 Mult calls of the time loop (Gauss-Lobatto pair, dense inverse mass) through libtpsrhs.so"""
+    """the same with every Mult on the device: the 2 000 Mult calls of the time loop (Gauss-Lobatto pair, dense inverse mass)
+    through libtpsrhs.so with the point-closure source; and once more with the source taken from the DEVICE operator itself
+    (the order-5 sweep of the 2-D two-temperature ambipolar kernels of the collocated pair on a 40 x 40 mesh)"""
     e_hip = ternary_run(mult_factory=_hip_mult_factory)
     _check(e_hip)
     e_ref = ternary_run()
     assert np.allclose(e_hip, e_ref, rtol=1e-7)
+    e_self = ternary_run(mult_factory=_hip_mult_factory, source="fine", n_fine=40)
+    assert np.allclose(e_self, e_ref, rtol=2e-5)

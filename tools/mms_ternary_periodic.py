@@ -17,5 +17,5 @@ from mms_util import TERNARY_REF, ternary_run  # noqa: E402
 if __name__ == "__main__":
     print("reference".ljust(34), " ".join("%.5e" % v for v in TERNARY_REF))
     for form in sys.argv[1:] or ["sin-", "cos-", "sin+", "cos+", "cos-|u=sc-", "cos-|v=cs-", "cos-|u=sc-|v=cs-"]:
-        e = ternary_run(form, n_fine=int(os.environ.get("N_FINE", "40")))
+        e = ternary_run(form, n_fine=int(os.environ.get("N_FINE", "40")), source=os.environ.get("SOURCE", "fine"))
         print(form.ljust(34), " ".join("%.5e" % v for v in e), flush=True)
