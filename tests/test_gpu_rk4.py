@@ -155,3 +155,42 @@ def test_time_loop_is_fourth_order_in_dt():
     op.close()
     print("errors", e1, e2, e3, "orders", np.log2(e1 / e2), np.log2(e2 / e3))
     assert 3.6 < np.log2(e1 / e2) < 4.4 and 3.5 < np.log2(e2 / e3) < 4.5
+
+
+@pytest.mark.parametrize("kind,order", [("dry_air", 3), ("argon", 3), ("argon_2T", 2), ("dry_air", 1)])
+def test_traces_formed_in_the_flux_epilogue_change_nothing(monkeypatch, kind, order):
+    """Stages 2..4 of a step take their face-node traces from the previous stage's k_flux epilogue (RkDev::ta_out) instead
+    of a k_traces sweep of their own: the same numbers in the same order, so rk4_step and advance (plain loop and captured
+    graph) give bit-identical states with TPSRHS_FUSE_TRACES=0; an external change of x between two steps is seen."""
+    import torch
+    from tps_amd.rhs_operator import RHSoperator
+
+    if kind == "dry_air":
+        c = cases.cyl3d(4, 12, 3, order, capi.NS, capi.VISC_ISOTH)
+        U = c.state(seed=5)
+        dt = 2e-7
+    else:
+        c = cases.argon_cyl3d(4, 12, 3, order, kind == "argon_2T", capi.CONSTANT, "arrhenius", capi.VISC_ISOTH)
+        U = c.state(seed=5, amp=0.01)
+        dt = 2e-9
+
+    def run(fuse):
+        monkeypatch.setenv("TPSRHS_FUSE_TRACES", "1" if fuse else "0")
+        op = RHSoperator(c.mesh, c.disc, c.physics, c.bcs, stream=torch.cuda.Stream())
+        with torch.cuda.stream(op._stream):
+            x = torch.tensor(np.ascontiguousarray(U).ravel(), dtype=torch.float64, device=op.device)
+            t = 0.0
+            for _ in range(2):
+                t = op.rk4_step(x, t, dt)
+            x[: x.numel() // 7] *= 1.0 + 1e-6  # touched between steps: the next step must sweep its own traces
+            t = op.rk4_step(x, t, dt)
+            a = x.clone()
+            t = op.advance(x, t, dt, 5)[0]  # >= 3 steps on a capturable stream: the captured graph
+            torch.cuda.synchronize()
+        out = a.cpu().numpy(), x.cpu().numpy()
+        op.close()
+        return out
+
+    (a1, b1), (a0, b0) = run(True), run(False)
+    assert np.array_equal(a1, a0) and np.array_equal(b1, b0)
+    assert np.isfinite(b1).all()

@@ -271,6 +271,8 @@ struct RkDev {
   const double *x0, *y2, *y3, *y4;
   double *out;
   unsigned long long *nan_count;
+  double *ta_out;  // non-NULL (stages 1..3 of a step, launch_all): the face-node traces of `out` go here -- the NEXT stage's
+                   // k_traces sweep done where the new state sits in registers (3-D collocated kernels, flux_fuses_traces)
 };
 
 struct MeshDev {
@@ -2417,6 +2419,13 @@ struct FluxLds {
   static_assert(!C::NC || X >= NEQ * C::NODES, "staging of the inverse-mass vectors");
 };
 
+// k_flux of the time loop can form the next stage's face-node traces in its epilogue (RkDev::ta_out) when the two nodal field
+// sets and the traces of one direction pair fit into its LDS pool: the 3-D collocated kernels.
+template <class C, class PH>
+constexpr bool flux_fuses_traces() {
+  return C::DIM == 3 && !C::NC && FluxLds<C, PH>::TOTAL >= 2 * PH::NEQ * C::NODES + 2 * PH::NEQ * C::TN;
+}
+
 template <class PH>
 __device__ inline typename PH::PRef flux_params(typename PH::PRef p) {
   if constexpr (PH::LAUNDER_FLUX)
@@ -2887,6 +2896,9 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
       nc_apply_minv<C, NEQ>(m.minv, sX, node_on, e0 + le_n, le_n, nd, tid, z);
     inv_mass = 1.0;
   }
+  double vout[NEQ];  // the state this lane writes in the time loop (the traces below take it from here)
+#pragma unroll
+  for (int eq = 0; eq < NEQ; eq++) vout[eq] = 0.0;
   if (node_on) {
     const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
     if (rk.mode == 0) {
@@ -2914,8 +2926,28 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
           if (eq >= rk.sp_first && eq < rk.sp_last) v = fmax(v, 0.0);  // Check_Undershoot
         }
         field_ptr(rk.out, eq, m.ndofs)[n] = v;
+        vout[eq] = v;
       }
       if (bad) atomicAdd(rk.nan_count, bad);
+    }
+  }
+  if constexpr (flux_fuses_traces<C, PH>()) {
+    if (rk.mode != 0 && rk.ta_out) {  // uniform: the k_traces sweep of the next stage, from registers (src/rhs_operator.cpp:361-372)
+      block_sync<C::BLOCK>();  // stage 1 has read its input from sU: the pool is free
+      double *sF = pool, *sT = pool + 2 * NEQ * C::NODES;
+      if (node_on) {
+        double up[NEQ];
+        PH::prim(prm, vout, up);
+#pragma unroll
+        for (int eq = 0; eq < NEQ; eq++) {
+          sF[eq * C::NODES + tid] = vout[eq];
+          sF[(NEQ + eq) * C::NODES + tid] = up[eq];
+        }
+      }
+      block_sync<C::BLOCK>();
+      traces_dir<C, PH, 0>(m, e0, sF, sT, rk.ta_out, ct, tid);
+      traces_dir<C, PH, 1>(m, e0, sF, sT, rk.ta_out, ct, tid);
+      traces_dir<C, PH, (C::DIM == 3 ? 2 : 0)>(m, e0, sF, sT, rk.ta_out, ct, tid);
     }
   }
   FSTAMP(7);

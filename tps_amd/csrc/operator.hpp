@@ -140,6 +140,12 @@ struct tpsrhs_operator {
 
   void (*launch)(tpsrhs_operator *, const double *, double *, bool) = nullptr;
   void (*point_eval)(tpsrhs_operator *, int, int64_t, const double *, double *) = nullptr;
+  // Time loop: k_flux of stages 1..3 forms the next stage's face-node traces in its epilogue (RkDev::ta_out, kernels.hpp),
+  // alternating between d_TA and d_TA2; the next stage then starts at k_gradient.  Single-rank 3-D collocated kernels only
+  // (flux_fuses_traces); TPSRHS_FUSE_TRACES=0 keeps the separate sweep.
+  bool fuse_traces = true;
+  bool ta_valid = false;     // d_ta_next holds the traces of the input of the stage that runs next
+  double *d_TA2 = nullptr, *d_ta_next = nullptr;
   bool sweep_alt = true;  // alternate the direction of consecutive sweeps (launch_all); TPSRHS_SWEEP_ALT
   int sweep_parity = 0;
   VsDev vs2d = {};  // viscous sponge of the 2-D heavy kernels (MeshDev::vs); enabled = 0: none
@@ -168,6 +174,7 @@ struct tpsrhs_operator {
     if (d_chem) (void)hipFree(d_chem);
     if (d_params) (void)hipFree(d_params);
     if (d_minv) (void)hipFree(d_minv);
+    if (d_TA2) (void)hipFree(d_TA2);
     if (d_rk) (void)hipFree(d_rk);
     if (d_nan) (void)hipFree(d_nan);
     if (d_forcing) (void)hipFree(d_forcing);
@@ -247,20 +254,40 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
   // the other, and the next Mult starts the other way round -- every sweep begins with what its predecessor wrote last
   // (xcd_block).  The direction is per sweep, the same for its halo and interior launches.
   const int dir0 = op->sweep_alt ? op->sweep_parity : 0;
+  // which trace buffer this Mult reads, whether its k_traces sweep is already done, and where k_flux puts the next one's
+  double *ta = op->d_TA;
+  bool have_traces = false;
+  if constexpr (flux_fuses_traces<C, PH>()) {
+    const int stage = op->rk.mode;
+    if (stage >= 2 && op->ta_valid) {  // the previous stage of this step left them (rk4_stages: its output is this input)
+      ta = op->d_ta_next;
+      have_traces = true;
+    }
+    op->ta_valid = false;
+    if (op->fuse_traces && !gradients_only && op->topo.num_shared == 0 && stage >= 1 && stage <= 3) {
+      if (!op->d_TA2) op->d_TA2 = dev_alloc<double>(static_cast<int64_t>(op->ne) * op->nfaces * 2 * PH::NEQ * C::NF);
+      op->rk.ta_out = (ta == op->d_TA) ? op->d_TA2 : op->d_TA;
+      op->d_ta_next = op->rk.ta_out;
+      op->ta_valid = true;  // (cleared again below if a launch throws)
+    }
+  } else {
+    op->ta_valid = false;
+  }
   auto traces = [&](MeshDev m, int grid) {
+    if (have_traces) return;
     m.reverse = dir0;
-    hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_TA);
+    hipLaunchKernelGGL((k_traces<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, ta);
     HIP_CHECK(hipGetLastError());
   };
   auto gradient = [&](MeshDev m, int grid) {
     m.reverse = op->sweep_alt ? 1 - dir0 : 0;
-    hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_TA, op->d_Up, op->d_gradUp,
+    hipLaunchKernelGGL((k_gradient<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, ta, op->d_Up, op->d_gradUp,
                        op->d_TB);
     HIP_CHECK(hipGetLastError());
   };
   auto flux = [&](MeshDev m, int grid) {
     m.reverse = dir0;
-    hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_gradUp, op->d_TA, op->d_TB, y,
+    hipLaunchKernelGGL((k_flux<C, PH>), dim3(grid), dim3(C::BLOCK), 0, s, m, prm_k, x, op->d_gradUp, ta, op->d_TB, y,
                        op->d_block_speed, op->rk);
     HIP_CHECK(hipGetLastError());
   };
@@ -270,7 +297,7 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
     if constexpr (PH::HAS_NR_BC) {
       if (!op->has_nr) return;
       const int nbc = prm.num_bcs;
-      hipLaunchKernelGGL((k_bc_mean<C, PH>), dim3(nbc), dim3(256), 0, s, op->n_nr_faces, op->d_nr_faces, op->d_TA,
+      hipLaunchKernelGGL((k_bc_mean<C, PH>), dim3(nbc), dim3(256), 0, s, op->n_nr_faces, op->d_nr_faces, ta,
                          op->d_bc_sums);
       HIP_CHECK(hipGetLastError());
       if (op->reduce && op->topo.num_shared > 0) {

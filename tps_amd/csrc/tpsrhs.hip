@@ -349,6 +349,7 @@ void setup(tpsrhs_operator *op, const tpsrhs_mesh *mesh, const tpsrhs_disc *disc
   HIP_CHECK(hipSetDevice(op->device));
   op->stream = rt ? static_cast<hipStream_t>(rt->stream) : nullptr;
   if (const char *env = std::getenv("TPSRHS_SWEEP_ALT")) op->sweep_alt = env[0] != '0';  // (A/B switch; default on)
+  if (const char *env = std::getenv("TPSRHS_FUSE_TRACES")) op->fuse_traces = env[0] != '0';  // (A/B switch; default on)
   op->halo = rt ? rt->halo : nullptr;
   op->halo_ctx = rt ? rt->halo_ctx : nullptr;
   op->reduce = rt ? rt->reduce : nullptr;
@@ -711,6 +712,7 @@ void rk4_stages(tpsrhs_operator *h, double *x, double dt, const double *dt_dev) 
     HIP_CHECK(hipMemsetAsync(h->d_nan, 0, sizeof(unsigned long long), h->stream));
   }
   double *k = h->d_rk, *y = k + n, *z = y + n;
+  h->ta_valid = false;  // a step starts with its own k_traces sweep: x may have been touched since the last call
   const bool mixture = h->phys.working_fluid == TPSRHS_USER_DEFINED;
   const int sp_first = h->nvel + 2;
   const int sp_last = mixture ? sp_first + (h->phys.mixture.ambipolar ? h->phys.mixture.num_species - 2
@@ -742,10 +744,12 @@ void rk4_stages(tpsrhs_operator *h, double *x, double dt, const double *dt_dev) 
         h->launch(h, ins[stage - 1], outs[stage - 1], false);
       } catch (...) {
         h->rk = RkDev{};
+        h->ta_valid = false;
         throw;
       }
       h->rk = RkDev{};
     }
+    h->ta_valid = false;
     return;
   }
   const double *in = x;
