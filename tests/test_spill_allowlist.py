@@ -49,7 +49,14 @@ def census():
 
     if not os.path.isdir(spill_lib.OBJ) or not any(f.endswith(".o") for f in os.listdir(spill_lib.OBJ)):
         pytest.skip("no object files (tps_amd/csrc/_obj): the census runs where the library was built")
-    return spill_lib.census()
+    objs = [os.path.join(spill_lib.OBJ, f) for f in os.listdir(spill_lib.OBJ) if f.endswith(".o")]
+    before = {o: os.stat(o).st_mtime_ns for o in objs}
+    out = spill_lib.census()
+    # the census must READ the objects: round 4 found llvm-objcopy rewriting its input in place (one file name = input AND
+    # output), which bumped every object's mtime past the headers' and made a stale build look fresh to build()
+    touched = [o for o in objs if os.stat(o).st_mtime_ns != before[o]]
+    assert not touched, f"the spill census modified {len(touched)} object files"
+    return out
 
 
 def spillers(census):

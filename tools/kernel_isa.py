@@ -16,7 +16,7 @@ def code_object(obj, tmp):
                         f"--input={obj}", f"--output={co}"], capture_output=True, text=True)
     if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
         fb = os.path.join(tmp, "k.fatbin")
-        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fb}", obj], check=True)
+        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fb}", obj, os.path.join(tmp, "discard.o")], check=True)  # (an explicit output: with one file name llvm-objcopy rewrites its INPUT in place -- and bumps the mtime the build compares)
         subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                         f"--input={fb}", f"--output={co}"], check=True)
     return co

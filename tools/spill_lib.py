@@ -17,7 +17,7 @@ def _code_object(obj, tmp):
                         f"--output={co}"], capture_output=True, text=True)
     if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
         fb = co + ".fatbin"  # the device code sits in the .hip_fatbin section of the host object
-        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fb}", obj], check=True)
+        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fb}", obj, co + ".discard.o"], check=True)  # (an explicit output: with one file name llvm-objcopy rewrites its INPUT in place -- and bumps the mtime the build compares)
         subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets={TARGET}", f"--input={fb}",
                         f"--output={co}"], check=True)
     return co

@@ -145,6 +145,7 @@ struct tpsrhs_operator {
   // (flux_fuses_traces); TPSRHS_FUSE_TRACES=0 keeps the separate sweep.
   bool fuse_traces = true;
   bool ta_valid = false;     // d_ta_next holds the traces of the input of the stage that runs next
+  bool ta_chain = false;     // inside tpsrhs_advance: stage 4 leaves the traces of the new solution for the next step
   double *d_TA2 = nullptr, *d_ta_next = nullptr;
   bool sweep_alt = true;  // alternate the direction of consecutive sweeps (launch_all); TPSRHS_SWEEP_ALT
   int sweep_parity = 0;
@@ -259,12 +260,14 @@ void launch_all(tpsrhs_operator *op, const double *x, double *y, bool gradients_
   bool have_traces = false;
   if constexpr (flux_fuses_traces<C, PH>()) {
     const int stage = op->rk.mode;
-    if (stage >= 2 && op->ta_valid) {  // the previous stage of this step left them (rk4_stages: its output is this input)
+    // the previous stage of this step left them (rk4_stages: its output is this input) -- or, inside tpsrhs_advance
+    // (ta_chain), the last stage of the previous step, whose output x is this step's input
+    if ((stage >= 2 || (stage == 1 && op->ta_chain)) && op->ta_valid) {
       ta = op->d_ta_next;
       have_traces = true;
     }
     op->ta_valid = false;
-    if (op->fuse_traces && !gradients_only && op->topo.num_shared == 0 && stage >= 1 && stage <= 3) {
+    if (op->fuse_traces && !gradients_only && op->topo.num_shared == 0 && stage >= 1 && (stage <= 3 || op->ta_chain)) {
       if (!op->d_TA2) op->d_TA2 = dev_alloc<double>(static_cast<int64_t>(op->ne) * op->nfaces * 2 * PH::NEQ * C::NF);
       op->rk.ta_out = (ta == op->d_TA) ? op->d_TA2 : op->d_TA;
       op->d_ta_next = op->rk.ta_out;

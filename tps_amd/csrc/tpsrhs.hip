@@ -712,7 +712,8 @@ void rk4_stages(tpsrhs_operator *h, double *x, double dt, const double *dt_dev) 
     HIP_CHECK(hipMemsetAsync(h->d_nan, 0, sizeof(unsigned long long), h->stream));
   }
   double *k = h->d_rk, *y = k + n, *z = y + n;
-  h->ta_valid = false;  // a step starts with its own k_traces sweep: x may have been touched since the last call
+  if (!h->ta_chain) h->ta_valid = false;  // a step starts with its own k_traces sweep: x may have been touched since the
+                                          // last call (tpsrhs_advance chains its steps: nothing touches x between them)
   const bool mixture = h->phys.working_fluid == TPSRHS_USER_DEFINED;
   const int sp_first = h->nvel + 2;
   const int sp_last = mixture ? sp_first + (h->phys.mixture.ambipolar ? h->phys.mixture.num_species - 2
@@ -749,7 +750,7 @@ void rk4_stages(tpsrhs_operator *h, double *x, double dt, const double *dt_dev) 
       }
       h->rk = RkDev{};
     }
-    h->ta_valid = false;
+    if (!h->ta_chain) h->ta_valid = false;
     return;
   }
   const double *in = x;
@@ -817,10 +818,12 @@ int tpsrhs_advance(tpsrhs_handle h, double *x, double *time, double *dt, int num
     const char *genv = std::getenv("TPSRHS_GRAPH");
     const bool use_graph = h->stream != nullptr && h->topo.num_shared == 0 && !h->timing && num_steps >= 3 &&
                            !(genv && genv[0] == '0');
+    h->ta_valid = false;
+    h->ta_chain = !h->forcing_active;  // (with forcing terms the stage kernel runs and nothing is fused)
     try {
       int step = 0;
       if (use_graph) {
-        one_step();  // first step outside the graph: allocations, initial boundary state
+        one_step();  // first step outside the graph: allocations, initial boundary state, its own k_traces sweep
         step = 1;
         tpsrhs_operator::StepKey key;
         key.x = x;
@@ -853,9 +856,11 @@ int tpsrhs_advance(tpsrhs_handle h, double *x, double *time, double *dt, int num
       for (; step < num_steps; step++) one_step();
     } catch (...) {
       h->nr_dt_dev = nullptr;
+      h->ta_chain = h->ta_valid = false;
       throw;
     }
     h->nr_dt_dev = nullptr;
+    h->ta_chain = h->ta_valid = false;  // the caller owns x again
     double ctl[3] = {0, 0, 0};
     unsigned long long bad = 0;
     HIP_CHECK(hipMemcpyAsync(ctl, h->d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
