@@ -304,6 +304,9 @@ __device__ inline EddyCtx closure_ctx(const MeshDev &m, bool dist_on, double dis
 // take one contiguous eighth of the block list, so that neighbours (all but those across the seven chunk borders) share
 // an L2.  A bijection of [0, n): XCD x runs the workgroups x, x + 8, ... -- q + (x < r) of them -- and owns the chunk
 // [x q + min(x, r), ...) of that length.
+#ifndef TPSRHS_GRAD_LATE
+#define TPSRHS_GRAD_LATE 1  // (0: A/B)
+#endif
 #ifndef TPSRHS_XCD_ORDER
 #define TPSRHS_XCD_ORDER 1
 #endif
@@ -1875,9 +1878,17 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
   STAMP(0);
   // neighbour Up traces of all direction pairs: issued first, consumed by the jump passes
   NbTraces<C, NEQ> ta0, ta1, ta2;
+  // The light (dry-air) 3-D kernels issue the records of the second and third pair one jump pass ahead of their use instead
+  // of all at the start: 2 x NEQ fewer values live across the volume gradient, 134 -> 128 registers at p = 3 (143 / 145 ->
+  // 127 / 128 at p = 4, 5) = FOUR waves per SIMD without a spill (round 2's 128-register cap cost 4 spilled registers).
+  // Measured, alternating core libraries on one box (profiles/r04_ab_grad_late.txt): cfg2 k_gradient 0.400 -> 0.375 ms, the
+  // Mult 0.823 -> 0.804.  The plasma kernels peak in their viscous phase (152 registers either way) and keep the early issue.
+  constexpr bool LATE = TPSRHS_GRAD_LATE && DIM == 3 && !C::NC && !PH::HEAVY;
   issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta0, tid);
-  issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta1, tid);
-  if (DIM == 3) issue_neighbour_traces<C, (DIM == 3 ? 2 : 0), NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta2, tid);
+  if (!LATE) {
+    issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta1, tid);
+    if (DIM == 3) issue_neighbour_traces<C, (DIM == 3 ? 2 : 0), NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta2, tid);
+  }
   if (node_on) {
     const unsigned n = static_cast<unsigned>(e0 + le_n) * C::NPE + nd;
     double up[NEQ];
@@ -1958,11 +1969,13 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
         block_sync<C::BLOCK>();
       }
     };
+    if (LATE) issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta1, tid);
     trace_lines<C, 0, NEQ>(sUp, sJ, ct, tid);
     block_sync<C::BLOCK>();  // own traces complete (boundary faces copy them)
     store_neighbour_traces<C, NEQ>(ta0, sJ, sJ + NEQ * C::TN, tid);
     block_sync<C::BLOCK>();
     jump(std::integral_constant<int, 0>());
+    if (LATE && DIM == 3) issue_neighbour_traces<C, (DIM == 3 ? 2 : 0), NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta2, tid);
     trace_lines<C, 1, NEQ>(sUp, sJ, ct, tid);
     block_sync<C::BLOCK>();
     store_neighbour_traces<C, NEQ>(ta1, sJ, sJ + NEQ * C::TN, tid);

@@ -212,7 +212,8 @@ struct DryAirPhys {
   // k_gradient of the p = 3 hex (one wave per element, 10 KB of LDS).  Round 2 capped it at 128 VGPRs = four waves per
   // SIMD (natural allocation 133 = three): 0.403 -> 0.382 ms on the builder's box, but with 4 spilled VGPRs + 84 B of
   // scratch, and the driver's box measured it slower (0.423 -> 0.453 ms).  Round 3: no bench kernel may spill
-  // (tests/test_spill_allowlist.py); the cap is a build switch for A/B runs only.
+  // (tests/test_spill_allowlist.py); the cap is a build switch for A/B runs only.  Round 4: the kernel reaches 128 registers
+  // on its own (k_gradient issues the neighbour records pair by pair, kernels.hpp `LATE`): four waves without the cap.
 #ifndef TPSRHS_DRY_GRAD_WAVES
 #define TPSRHS_DRY_GRAD_WAVES 3
 #endif
