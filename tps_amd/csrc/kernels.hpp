@@ -307,6 +307,12 @@ __device__ inline EddyCtx closure_ctx(const MeshDev &m, bool dist_on, double dis
 #ifndef TPSRHS_GRAD_LATE
 #define TPSRHS_GRAD_LATE 1  // (0: A/B)
 #endif
+#ifndef TPSRHS_GRAD_LATE_NC
+#define TPSRHS_GRAD_LATE_NC 0  // (measured: gll_dry unchanged, 264 -> 244 registers notwithstanding)
+#endif
+#ifndef TPSRHS_GRAD_LATE_ALL
+#define TPSRHS_GRAD_LATE_ALL 0
+#endif
 #ifndef TPSRHS_XCD_ORDER
 #define TPSRHS_XCD_ORDER 1
 #endif
@@ -1883,7 +1889,7 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && PH::HEAVY) ? 1 : PH::minw_grad(
   // 127 / 128 at p = 4, 5) = FOUR waves per SIMD without a spill (round 2's 128-register cap cost 4 spilled registers).
   // Measured, alternating core libraries on one box (profiles/r04_ab_grad_late.txt): cfg2 k_gradient 0.400 -> 0.375 ms, the
   // Mult 0.823 -> 0.804.  The plasma kernels peak in their viscous phase (152 registers either way) and keep the early issue.
-  constexpr bool LATE = TPSRHS_GRAD_LATE && DIM == 3 && !C::NC && !PH::HEAVY;
+  constexpr bool LATE = TPSRHS_GRAD_LATE && ((DIM == 3 && (!C::NC || TPSRHS_GRAD_LATE_NC) && !PH::HEAVY) || TPSRHS_GRAD_LATE_ALL);
   issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta0, tid);
   if (!LATE) {
     issue_neighbour_traces<C, 1, NEQ>(sFI, TA, 2 * NEQ * C::NF, NEQ, ta1, tid);
