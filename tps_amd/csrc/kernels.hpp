@@ -310,6 +310,12 @@ __device__ inline EddyCtx closure_ctx(const MeshDev &m, bool dist_on, double dis
 #ifndef TPSRHS_GRAD_LATE_NC
 #define TPSRHS_GRAD_LATE_NC 0  // (measured: gll_dry unchanged, 264 -> 244 registers notwithstanding)
 #endif
+// k_flux of the two-step (plasma) kernels: the nodal gradient (NEQ * DIM values per lane) is parked in the lane's own column
+// of the -- still unused -- flux region of the LDS pool while the state-only closure runs, instead of being held in
+// registers across it (A/B switch)
+#ifndef TPSRHS_FLUX_PARK_GRAD
+#define TPSRHS_FLUX_PARK_GRAD 0
+#endif
 #ifndef TPSRHS_GRAD_LATE_ALL
 #define TPSRHS_GRAD_LATE_ALL 0
 #endif
@@ -2696,9 +2702,14 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
     issue_neighbour_traces<C, 0, NEQ>(sFI, TA, 2 * NEQ * C::NF, 0, ta0, tid);
     if (!L::BOTH_2D) issue_visc_traces<C, 0, NEQ>(sFI, e0, TB, tb0, tid);
   }
+  constexpr bool PARK = TPSRHS_FLUX_PARK_GRAD && PH::TWO_STEP && !C::NC && DIM == 3;
   if (node_on) {
 #pragma unroll
     for (int eq = 0; eq < NEQ; eq++) sU[eq * C::NODES + tid] = u[eq];
+    if constexpr (PARK) {  // (the lane's own column of sGf: overwritten by the lane's own flux at the end of the nodal physics)
+#pragma unroll
+      for (int k = 0; k < NEQ * DIM; k++) sGf[k * C::NODES + tid] = gr[k];
+    }
   }
   block_sync<C::BLOCK>();  // tables + vertices + sU
   FSTAMP(1);
@@ -2732,6 +2743,13 @@ __global__ __launch_bounds__(C::BLOCK, (C::NC && (PH::HEAVY || PH::MINW_FLUX > 2
       speed = PH::max_char_speed(prm, uc, st);
       typename PH::FluxCoef fc;
       if constexpr (PH::TWO_STEP) PH::flux_coeffs(prm, uc, st, fc);
+      if constexpr (PARK) {  // back from the LDS, through a pointer the compiler cannot see through (no store-to-load forwarding,
+                             // which would keep the 2 * NEQ * DIM registers alive across the closure)
+        const double *pg = sGf + tid;
+        asm volatile("" : "+v"(pg) : : "memory");
+#pragma unroll
+        for (int k = 0; k < NEQ * DIM; k++) gr[k] = pg[k * C::NODES];
+      }
       if (PH::HAS_SOURCE) {
         double up[NEQ];
         PH::prim(prm, u, up);
